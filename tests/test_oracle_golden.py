@@ -1,0 +1,252 @@
+"""The oracle against the golden vectors captured from the reference itself (tests/golden/make_golden.py),
+hand-computable known-answer tests for the OpenCV-side ops (PARITY UNPINNED: no cv2 anywhere), and an
+independent cross-check of the integer 3x3 ops against scipy.ndimage."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from oracle import c_oracle as co
+from oracle import m3_oracle as mo
+
+
+def frames_normal(seed, count, shape, mu, sigma):
+    rng = np.random.default_rng(seed)
+    return [np.clip(np.rint(rng.normal(mu, sigma, shape)), 0, 255).astype(np.uint8) for _ in range(count)]
+
+
+@pytest.mark.parametrize("n", [1, 4, 8])
+def test_g1_ring_window(golden_dir, n):
+    g = np.load(os.path.join(golden_dir, "g1_sliding_window.npz"))
+    shape = g[f"n{n}_max"].shape[1:]
+    rng = np.random.default_rng(int(g[f"n{n}_seed"]))
+    frames = rng.integers(0, 256, (3 * n, ) + shape, dtype=np.uint8)
+    win = mo.RingWindow(n, shape)
+    for k, f in enumerate(frames):
+        win.push(f)
+        assert np.array_equal(win.peak, g[f"n{n}_max"][k])
+        assert np.array_equal(win.mean, g[f"n{n}_mean"][k])
+        assert np.array_equal(win.total, g[f"n{n}_sum"][k])
+        assert win.length == g[f"n{n}_len"][k]
+
+
+def _g2_cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "g2_threshold_series.json")))
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_g2_threshold_series(golden_dir, ci):
+    c = _g2_cases(golden_dir)[ci]
+    shape = tuple(c["shape"])
+    mask = np.ones(shape, np.uint8)
+    det = mo.M3Oracle(c["n"], mask, adaptive=c.get("adaptive", True), init_value=c.get("init_value", 7),
+                      sensitivity=c["sensitivity"], area=c["area"], interval=c["interval"])
+    assert list(det.stack.std_roi) == c["std_roi"]
+    cdet = co.CM3(c["n"], mask, det.stack.std_roi, adaptive=c.get("adaptive", True), init_value=c.get("init_value", 7),
+                  sensitivity=c["sensitivity"], interval=c["interval"])
+    for k, f in enumerate(frames_normal(c["seed"], c["steps"], shape, c["mu"], c["sigma"])):
+        det.update(f)
+        cdet.update(f)
+        assert det.bi_threshold == c["bi_threshold"][k], k
+        assert det.bi_threshold_float == c["bi_threshold_float"][k], k
+        assert det.stack.snr == c["snr"][k], k
+        thr, thr_f, snr, _ = cdet.state()
+        assert thr == c["bi_threshold"][k], k
+        assert snr == pytest.approx(c["snr"][k], rel=1e-12, abs=1e-15)
+        # exact-integer route to sigma (what the HIP path uses)
+        if det.stack.sigma is not None and (k + 1 <= c["n"] or (k + 1) % (c["interval"] * c["n"]) == 0) and k >= 1:
+            kk = min(k + 1, c["n"])
+            s1, s2, cnt = mo.noise_sums(det.stack.sub.ring, det.stack.sub.mean, kk)
+            assert mo.sigma_from_sums(s1, s2, cnt) == pytest.approx(float(det.stack.sigma), rel=1e-12)
+
+
+def test_g3_std_roi(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "g3_std_roi.json"))):
+        h, w = c["h"], c["w"]
+        m = np.ones((h, w), np.uint8)
+        kind = c["kind"]
+        if kind == "bottom":
+            m[int(h * 0.62):] = 0
+        elif kind == "bottom_heavy":
+            m[int(h * 0.35):] = 0
+        elif kind == "corner":
+            m[int(h * 0.5):, :int(w * 0.5)] = 0
+        elif kind == "stripe":
+            m[:, int(w * 0.45):int(w * 0.5)] = 0
+        assert list(mo.select_std_roi(m, c["area"])) == c["roi"], c
+
+
+def test_g4_lineset_nms(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "g4_lineset_nms.json"))):
+        lines = np.array(c["lines"], np.int32)
+        for impl in (mo.lineset_nms, co.lineset_nms):
+            out, prob = impl(lines)
+            assert out.tolist() == c["out"]
+            assert np.array_equal(np.asarray(prob, np.float64), np.array(c["nonline"], np.float64))
+
+
+def test_g7_ema(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "g7_ema.json"))):
+        e = mo.WarmupEMA(c["momentum"], c["warmup_speed"])
+        for x, v, m in zip(c["x"], c["value"], c["cur_momentum"]):
+            e.update(x)
+            assert e.value == v and e.m == m
+
+
+# ------------------------------------------------------------------ known-answer tests, OpenCV-side ops
+def test_kat_median3():
+    img = np.array([[10, 200, 30], [40, 50, 60], [70, 80, 255]], np.uint8)
+    # centre: sorted 10 30 40 50 60 70 80 200 255 -> 60; corner (0,0) with replicated border:
+    # window rows (10,10,200),(10,10,200),(40,40,50) -> sorted 10 10 10 10 40 40 50 200 200 -> 40
+    out = mo.median_blur3(img)
+    assert out[1, 1] == 60 and out[0, 0] == 40
+    assert np.array_equal(out, co.median3(img))
+    spike = np.zeros((5, 5), np.uint8)
+    spike[2, 2] = 255
+    assert mo.median_blur3(spike).max() == 0  # an isolated pixel never survives
+
+
+def test_kat_threshold_is_strict():
+    img = np.array([[4, 5, 6]], np.uint8)
+    assert mo.threshold_binary(img, 5).tolist() == [[0, 0, 255]]
+
+
+def test_kat_morphology_border():
+    img = np.zeros((4, 5), np.uint8)
+    img[0, 0] = 255
+    d = mo.dilate3(img)
+    assert d[:2, :2].min() == 255 and d.sum() == 4 * 255
+    # erode ignores out-of-image samples: a full image stays full, a corner block survives at the corner
+    full = np.full((4, 5), 255, np.uint8)
+    assert mo.erode3(full).min() == 255
+    assert mo.erode3(d)[0, 0] == 255 and mo.erode3(d).sum() == 255
+    # close fills a one-pixel hole
+    ring = np.full((5, 5), 255, np.uint8)
+    ring[2, 2] = 0
+    assert mo.morph_close3(ring).min() == 255
+    for f, g in ((mo.dilate3, co.dilate3), (mo.erode3, co.erode3)):
+        assert np.array_equal(f(ring), g(ring))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (6, 1), (17, 33)])
+def test_integer_ops_vs_scipy(shape):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(mo.median_blur3(img), ndi.median_filter(img, size=3, mode="nearest"))
+    assert np.array_equal(mo.dilate3(img), ndi.maximum_filter(img, size=3, mode="constant", cval=0))
+    assert np.array_equal(mo.erode3(img), ndi.minimum_filter(img, size=3, mode="constant", cval=255))
+    assert np.array_equal(co.median3(img), mo.median_blur3(img))
+    assert np.array_equal(co.dilate3(img), mo.dilate3(img))
+    assert np.array_equal(co.erode3(img), mo.erode3(img))
+
+
+def test_kat_cv_rng():
+    # first outputs of the multiply-with-carry generator seeded with 2^64-1, worked by hand:
+    # state0 = 0xFFFFFFFFFFFFFFFF -> 0xFFFFFFFF*4164903690 + 0xFFFFFFFF
+    r = mo.CvRNG()
+    s1 = 0xFFFFFFFF * 4164903690 + 0xFFFFFFFF
+    assert r.next() == s1 & 0xFFFFFFFF and r.state == s1
+    s2 = (s1 & 0xFFFFFFFF) * 4164903690 + (s1 >> 32)
+    assert r.next() == s2 & 0xFFFFFFFF
+    assert mo.CvRNG(0).state == 0xFFFFFFFF
+    assert mo.CvRNG().uniform(3, 3) == 3
+
+
+def _draw(h, w, segs):
+    img = np.zeros((h, w), np.uint8)
+    for (x1, y1, x2, y2) in segs:
+        k = max(abs(x2 - x1), abs(y2 - y1))
+        for t in range(k + 1):
+            img[round(y1 + (y2 - y1) * t / k), round(x1 + (x2 - x1) * t / k)] = 255
+    return img
+
+
+def test_kat_hough_axis_aligned():
+    # A vertical run of 46 px: at angle index 0 (cos=1, sin=0 exactly) every point votes rho=x; the 10th visited
+    # point reaches the threshold, the walk is exactly vertical, so one segment with the exact end points comes out.
+    img = _draw(60, 40, [(7, 5, 7, 50)])
+    for impl in (mo.hough_lines_p, co.hough_lines_p):
+        out = impl(img, 1, np.pi / 180, 10, 10, 0)
+        assert len(out) == 1 and out[0][0] == 7 and out[0][2] == 7 and sorted((out[0][1], out[0][3])) == [5, 50]
+    # A horizontal run: the winning angle is the FIRST index whose bin holds all visited points, which depends on
+    # the visiting order, so only the invariants are hand-checkable: one segment, on the row, inside the run.
+    img = _draw(40, 60, [(10, 20, 29, 20)])
+    for impl in (mo.hough_lines_p, co.hough_lines_p):
+        out = impl(img, 1, np.pi / 180, 10, 10, 0)
+        assert len(out) == 1
+        x1, y1, x2, y2 = out[0]
+        assert y1 == 20 and y2 == 20 and 10 <= min(x1, x2) and max(x1, x2) <= 29 and abs(x2 - x1) >= 10
+
+
+def test_kat_hough_rejects_short_and_sparse():
+    assert len(mo.hough_lines_p(_draw(30, 30, [(5, 5, 12, 5)]), 1, np.pi / 180, 10, 10, 0)) == 0  # 8 px < threshold
+    img = _draw(80, 40, [(9, 5, 9, 14), (9, 25, 9, 34)])  # two vertical 10-px runs, 10-px hole
+    assert len(mo.hough_lines_p(img, 1, np.pi / 180, 10, 25, 3)) == 0  # hole > gap, each part < min length
+    out = mo.hough_lines_p(img, 1, np.pi / 180, 10, 25, 10)  # 10 dark px == gap: bridged (the test is gap > lineGap)
+    assert len(mo.hough_lines_p(img, 1, np.pi / 180, 10, 25, 9)) == 0
+    assert len(out) == 1 and sorted((out[0][1], out[0][3])) == [5, 34]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hough_numpy_vs_c(seed):
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(40, 120)), int(rng.integers(40, 160))
+    segs = []
+    for _ in range(int(rng.integers(1, 6))):
+        segs.append((int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, h))))
+    img = _draw(h, w, [s for s in segs if max(abs(s[2] - s[0]), abs(s[3] - s[1])) > 0])
+    img |= (rng.random((h, w)) < 0.01).astype(np.uint8) * 255
+    for gap in (0, 2.5, 10):
+        a = mo.hough_lines_p(img, 1, np.pi / 180, 10, 10, gap)
+        b = co.hough_lines_p(img, 1, np.pi / 180, 10, 10, gap)
+        assert np.array_equal(a, b)
+
+
+def test_m3_numpy_vs_c_stream():
+    from metdetpy_amd.synth import SkyStream
+    H, W, n = 135, 240, 8
+    s = SkyStream(H, W, 3, speed=8, streak_period=25)
+    mask = np.ones((H, W), np.uint8)
+    py = mo.M3Oracle(n, mask)
+    cc = co.CM3(n, mask, py.stack.std_roi)
+    got_lines = 0
+    for t in range(50):
+        f = s.next()
+        py.update(f)
+        py.detect()
+        cc.update(f)
+        raw = cc.detect()
+        assert np.array_equal(py.dst, cc.dst())
+        assert np.array_equal(py.raw_lines.reshape(-1, 4), raw.reshape(-1, 4))
+        assert cc.state()[0] == py.bi_threshold and cc.lit_count == py.lit_count
+        got_lines += len(raw)
+    assert got_lines > 0
+
+
+def test_dy_mask_equals_run_length_form():
+    """The O(1)-state form used on the GPU: dy = NOT(all of the last len=min(n,t) binaries lit)."""
+    rng = np.random.default_rng(11)
+    n, shape = 5, (12, 20)
+    ring = mo.RingWindow(n, shape)
+    hist = []
+    for t in range(1, 20):
+        act = ((rng.random(shape) < 0.7) * 255).astype(np.uint8)
+        ring.push(act)
+        hist.append(act)
+        ref = ring.total <= (ring.length - 1) * 255
+        ln = min(n, t)
+        all_lit = np.logical_and.reduce([h == 255 for h in hist[-ln:]])
+        assert np.array_equal(ref, ~all_lit)
+
+
+def test_bgr2gray_and_resize_kat():
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    assert mo.bgr_to_gray(px).tolist() == [[255, 0, 29, 150, 76]]
+    img = np.arange(16, dtype=np.uint8).reshape(4, 4) * 10
+    half = mo.resize_linear(img, (2, 2))
+    # exact 2x down-scale == (a+b+c+d+2)>>2
+    want = (img.reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(2, 2, 4).astype(int).sum(-1) + 2) >> 2
+    assert np.array_equal(half, want)
+    assert np.array_equal(mo.resize_linear(img, (4, 4)), img)
