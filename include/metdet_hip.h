@@ -1,0 +1,123 @@
+/* metdet_hip.h -- C-ABI of libmetdet_hip.so: the MI355X (gfx950) implementation of MetDetPy's
+ * per-frame line-detector hot path.
+ *
+ * The reference is pure Python and has no FFI for this path; the entry points below are sized to the
+ * plugin contract the reference's main loop uses (MetDetPy.py:137-142, 197-198):
+ *
+ *     detector = DetectorCls(window_sec, fps, mask, num_cls, cfg, logger)   Detector.py:186-220
+ *     detector.update(frame)                                                Detector.py:225-229
+ *     lines, cls_pred = detector.detect()                                   Detector.py:324-392 / 257-296
+ *
+ * and are what a ctypes stub inside the reference's `LineDetector` subclasses would bind (see
+ * INTEGRATION.md).  Plain pointers and sizes only; no exceptions cross the boundary.  Every function
+ * that returns int returns 0 on success and a negative MDH_E_* code on failure, with a text in
+ * mdh_last_error().  One mdh_ctx is used by one host thread at a time.  The library owns all device
+ * memory; host buffers handed in are only read during the call.
+ */
+#ifndef METDET_HIP_H
+#define METDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDH_MAX_LINES 512        /* raw Hough segments stored per frame (reference discards frames with > 500, Detector.py:30) */
+#define MDH_MAX_WINDOW 255       /* n = int(window_sec * fps) must be 1..255 */
+#define MDH_NUM_ANGLE 180        /* HoughLinesP(theta = pi/180) */
+
+#define MDH_OK 0
+#define MDH_E_ARG (-1)           /* bad argument */
+#define MDH_E_HIP (-2)           /* a HIP runtime call failed */
+#define MDH_E_STATE (-3)         /* call sequence error (detect without update, ...) */
+#define MDH_E_NOMEM (-4)
+
+#define MDH_DET_M3 0             /* M3Detector.detect       (Detector.py:324-392) */
+#define MDH_DET_CLASSIC 1        /* ClassicDetector.detect  (Detector.py:257-296) */
+
+#define MDH_SENS_LOW 0
+#define MDH_SENS_NORMAL 1
+#define MDH_SENS_HIGH 2
+
+/* cfg.detector.cfg of the reference (metstruct.py:357-382) plus what LineDetector.__init__ derives on the host. */
+typedef struct mdh_cfg {
+    int32_t detector;            /* MDH_DET_* */
+    int32_t adaptive_bi_thre;    /* cfg.binary.adaptive_bi_thre */
+    int32_t init_value;          /* cfg.binary.init_value (used when not adaptive, Detector.py:208) */
+    int32_t sensitivity;         /* MDH_SENS_* : T = a*snr^2+b (Detector.py:177-183) */
+    int32_t interval;            /* cfg.binary.interval (Detector.py:61-63) */
+    int32_t roi[4];              /* SNR_SW.std_roi = (row0, col0, row1, col1) chosen by select_subarea (Detector.py:93-122) */
+    int32_t hough_threshold;     /* cfg.hough_line.threshold */
+    int32_t hough_min_len;       /* cfg.hough_line.min_len */
+    int32_t hough_max_gap;       /* cfg.hough_line.max_gap */
+    int32_t dy_mask;             /* cfg.dynamic.dy_mask */
+    int32_t max_batch;           /* largest K accepted by one internal pass of mdh_process_batch (0 -> 64) */
+    int32_t reserved;
+    double mask_area;            /* float(np.sum(mask)) (Detector.py:191) */
+} mdh_cfg;
+
+/* Per-frame scalars: what M3Detector exposes as attributes after detect() (Detector.py:342-392, 394-448). */
+typedef struct mdh_frame_info {
+    int32_t n_raw;               /* lines_num: segments HoughLinesP returned (may exceed MDH_MAX_LINES; only that many are stored) */
+    int32_t n_nms;               /* filtered_line_num: segments after lineset_nms (0 when n_raw == 0 or n_raw > 500) */
+    int32_t lit_count;           /* count(dst == 255) */
+    int32_t bi_threshold;        /* bi_threshold in force for this frame */
+    double bi_threshold_float;
+    double snr;                  /* stack.snr (noise EMA) after this frame's update */
+    double sigma;                /* last noise sigma fed to the EMA (0 before the first) */
+    double dst_sum;              /* 100 * lit_count / mask_area */
+    double hough_gap;            /* maxLineGap handed to HoughLinesP (before cvRound) */
+} mdh_frame_info;
+
+typedef struct mdh_ctx mdh_ctx;
+
+/* LineDetector.__init__ (Detector.py:186-220).  H, W: runtime frame size; n_window = int(window_sec*fps).
+ * Returns NULL on failure (see mdh_last_error). */
+mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh_cfg* cfg);
+void mdh_destroy(mdh_ctx* ctx);
+const char* mdh_last_error(void);
+
+/* LineDetector.update(frame) (Detector.py:225-229): copies the H*W u8 host frame into the window and
+ * refreshes the noise estimate / binary threshold.  Must alternate with mdh_detect. */
+int mdh_update(mdh_ctx* ctx, const uint8_t* frame);
+
+/* {M3,Classic}Detector.detect() (Detector.py:324-392 / 257-296) for the frame given to the last mdh_update.
+ * raw_lines: MDH_MAX_LINES x 4 int32 [x1,y1,x2,y2] in HoughLinesP discovery order; nms_lines / nonline:
+ * output of lineset_nms (utils.py:780-839), nonline = "non-line probability".  Any output may be NULL. */
+int mdh_detect(mdh_ctx* ctx, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);
+
+/* Throughput path: K consecutive update()+detect() pairs in one call, identical results.
+ * frames: K*H*W u8, host memory (on_device = 0) or device memory of ctx's device (on_device = 1).
+ * info: K entries.  raw_lines / nms_lines: K*MDH_MAX_LINES*4 int32, nonline: K*MDH_MAX_LINES doubles
+ * (each may be NULL).  K may exceed cfg.max_batch; it is processed in passes of at most max_batch frames. */
+int mdh_process_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device, mdh_frame_info* info,
+                      int32_t* raw_lines, int32_t* nms_lines, double* nonline);
+
+/* The binary image `dst` (H*W u8 of {0,255}) of frame `index` of the most recent pass (0 .. frames_in_pass-1;
+ * -1 = the last frame).  For visu() and parity tests.  stage: 0 = dst (after the dynamic mask), 1 = the image
+ * before the dynamic mask (MORPH_CLOSE output). */
+int mdh_get_binary(mdh_ctx* ctx, int index, int stage, uint8_t* out);
+
+/* lineset_nms (utils.py:780-839) on the host.  lines: n x 4 int32.  Returns the number of kept segments. */
+int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, double* nonline);
+
+/* Device-memory helpers so a harness can keep synthetic frames resident in HBM. */
+void* mdh_device_alloc(mdh_ctx* ctx, uint64_t bytes);
+int mdh_device_free(mdh_ctx* ctx, void* ptr);
+int mdh_device_upload(mdh_ctx* ctx, void* dst_device, const void* src_host, uint64_t bytes);
+
+/* Per-kernel timing with HIP events on the context's own stream (off by default).
+ * names: MDH_NUM_KERNELS strings; ms / launches: accumulated since the last reset. */
+#define MDH_NUM_KERNELS 8
+int mdh_profile_enable(mdh_ctx* ctx, int on);
+int mdh_profile_read(mdh_ctx* ctx, double* ms, int64_t* launches, int reset);
+const char* mdh_kernel_name(int k);
+
+/* Frames consumed so far (SlidingWindow.timer). */
+int64_t mdh_frames_seen(const mdh_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METDET_HIP_H */

@@ -1,0 +1,200 @@
+"""ctypes binding of libmetdet_hip.so (the C-ABI in include/metdet_hip.h).
+
+There is no CPU fallback: if the library is missing or no AMD GPU is visible, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmetdet_hip.so")
+
+MDH_MAX_LINES = 512
+MDH_MAX_WINDOW = 255
+MDH_NUM_KERNELS = 8
+MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
+SENSITIVITY_ID = {"low": 0, "normal": 1, "high": 2}
+
+
+class MdhCfg(C.Structure):
+    _fields_ = [("detector", C.c_int32), ("adaptive_bi_thre", C.c_int32), ("init_value", C.c_int32),
+                ("sensitivity", C.c_int32), ("interval", C.c_int32), ("roi", C.c_int32 * 4),
+                ("hough_threshold", C.c_int32), ("hough_min_len", C.c_int32), ("hough_max_gap", C.c_int32),
+                ("dy_mask", C.c_int32), ("max_batch", C.c_int32), ("reserved", C.c_int32), ("mask_area", C.c_double)]
+
+
+class MdhFrameInfo(C.Structure):
+    _fields_ = [("n_raw", C.c_int32), ("n_nms", C.c_int32), ("lit_count", C.c_int32), ("bi_threshold", C.c_int32),
+                ("bi_threshold_float", C.c_double), ("snr", C.c_double), ("sigma", C.c_double), ("dst_sum", C.c_double),
+                ("hough_gap", C.c_double)]
+
+
+FRAME_INFO_DTYPE = np.dtype([("n_raw", "<i4"), ("n_nms", "<i4"), ("lit_count", "<i4"), ("bi_threshold", "<i4"),
+                             ("bi_threshold_float", "<f8"), ("snr", "<f8"), ("sigma", "<f8"), ("dst_sum", "<f8"),
+                             ("hough_gap", "<f8")])
+assert FRAME_INFO_DTYPE.itemsize == C.sizeof(MdhFrameInfo)
+
+EXPORTS = [
+    "mdh_create", "mdh_destroy", "mdh_last_error", "mdh_update", "mdh_detect", "mdh_process_batch", "mdh_get_binary",
+    "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
+    "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen"
+]
+
+_lib = None
+
+
+class MetDetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmetdet_hip.so and declare the prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MetDetHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C metdetpy_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
+    L.mdh_create.argtypes = [i32, i32, i32, i32, C.POINTER(MdhCfg)]
+    L.mdh_create.restype = vp
+    L.mdh_destroy.argtypes = [vp]
+    L.mdh_destroy.restype = None
+    L.mdh_last_error.restype = C.c_char_p
+    L.mdh_update.argtypes = [vp, vp]
+    L.mdh_detect.argtypes = [vp, vp, vp, vp, vp]
+    L.mdh_process_batch.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    L.mdh_get_binary.argtypes = [vp, i32, i32, vp]
+    L.mdh_lineset_nms.argtypes = [vp, i32, vp, vp]
+    L.mdh_device_alloc.argtypes = [vp, u64]
+    L.mdh_device_alloc.restype = vp
+    L.mdh_device_free.argtypes = [vp, vp]
+    L.mdh_device_upload.argtypes = [vp, vp, vp, u64]
+    L.mdh_profile_enable.argtypes = [vp, i32]
+    L.mdh_profile_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
+    L.mdh_kernel_name.argtypes = [i32]
+    L.mdh_kernel_name.restype = C.c_char_p
+    L.mdh_frames_seen.argtypes = [vp]
+    L.mdh_frames_seen.restype = i64
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().mdh_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise MetDetHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def lineset_nms(lines: np.ndarray):
+    """utils.py:780-839 on the host side of the library (no GPU needed)."""
+    lines = np.ascontiguousarray(lines, dtype=np.int32).reshape(-1, 4)
+    n = len(lines)
+    out = np.zeros((n, 4), np.int32)
+    prob = np.zeros(n, np.float64)
+    k = load().mdh_lineset_nms(lines.ctypes.data, n, out.ctypes.data, prob.ctypes.data)
+    return out[:k], prob[:k]
+
+
+class Context:
+    """Owns one mdh_ctx (one detector on one GPU)."""
+
+    def __init__(self, H, W, n, cfg: MdhCfg, device: int = 0):
+        self.L = load()
+        self.H, self.W, self.n = int(H), int(W), int(n)
+        self.handle = self.L.mdh_create(int(device), self.H, self.W, self.n, C.byref(cfg))
+        if not self.handle:
+            raise MetDetHipError(f"mdh_create failed: {last_error()}")
+        self.max_batch = cfg.max_batch if cfg.max_batch > 0 else 64
+        self._info1 = np.zeros(1, FRAME_INFO_DTYPE)
+        self._raw1 = np.zeros((MDH_MAX_LINES, 4), np.int32)
+        self._nms1 = np.zeros((MDH_MAX_LINES, 4), np.int32)
+        self._prob1 = np.zeros(MDH_MAX_LINES, np.float64)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.mdh_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, frame: np.ndarray):
+        if frame.shape != (self.H, self.W) or frame.dtype != np.uint8:
+            raise ValueError(f"frame must be uint8 {(self.H, self.W)}, got {frame.dtype} {frame.shape}")
+        f = np.ascontiguousarray(frame)
+        check(self.L.mdh_update(self.handle, f.ctypes.data), "mdh_update")
+
+    def detect(self):
+        check(self.L.mdh_detect(self.handle, self._info1.ctypes.data, self._raw1.ctypes.data, self._nms1.ctypes.data,
+                                self._prob1.ctypes.data), "mdh_detect")
+        info = self._info1[0]
+        nr = min(int(info["n_raw"]), MDH_MAX_LINES)
+        nn = int(info["n_nms"])
+        return info.copy(), self._raw1[:nr].copy(), self._nms1[:nn].copy(), self._prob1[:nn].copy()
+
+    def process_batch(self, frames, K=None, on_device=False):
+        """frames: (K,H,W) uint8 ndarray (host) or an integer device pointer with K given."""
+        if on_device:
+            ptr = int(frames)
+            assert K is not None
+        else:
+            if frames.ndim != 3 or frames.shape[1:] != (self.H, self.W) or frames.dtype != np.uint8:
+                raise ValueError("frames must be uint8 (K,H,W)")
+            frames = np.ascontiguousarray(frames)
+            K = len(frames)
+            ptr = frames.ctypes.data
+        info = np.zeros(K, FRAME_INFO_DTYPE)
+        raw = np.zeros((K, MDH_MAX_LINES, 4), np.int32)
+        nms = np.zeros((K, MDH_MAX_LINES, 4), np.int32)
+        prob = np.zeros((K, MDH_MAX_LINES), np.float64)
+        check(self.L.mdh_process_batch(self.handle, ptr, int(K), int(bool(on_device)), info.ctypes.data, raw.ctypes.data,
+                                       nms.ctypes.data, prob.ctypes.data), "mdh_process_batch")
+        return info, raw, nms, prob
+
+    def process_batch_into(self, ptr, K, on_device, info, raw, nms, prob):
+        check(self.L.mdh_process_batch(self.handle, int(ptr), int(K), int(bool(on_device)), info.ctypes.data,
+                                       raw.ctypes.data if raw is not None else None,
+                                       nms.ctypes.data if nms is not None else None,
+                                       prob.ctypes.data if prob is not None else None), "mdh_process_batch")
+
+    def get_binary(self, index=-1, stage=0):
+        out = np.empty((self.H, self.W), np.uint8)
+        check(self.L.mdh_get_binary(self.handle, int(index), int(stage), out.ctypes.data), "mdh_get_binary")
+        return out
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = self.L.mdh_device_alloc(self.handle, int(nbytes))
+        if not p:
+            raise MetDetHipError(f"mdh_device_alloc({nbytes}) failed: {last_error()}")
+        return p
+
+    def device_free(self, ptr: int):
+        check(self.L.mdh_device_free(self.handle, ptr), "mdh_device_free")
+
+    def device_upload(self, dptr: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        check(self.L.mdh_device_upload(self.handle, dptr, a.ctypes.data, a.nbytes), "mdh_device_upload")
+
+    def profile_enable(self, on=True):
+        check(self.L.mdh_profile_enable(self.handle, int(on)), "mdh_profile_enable")
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * MDH_NUM_KERNELS)()
+        nl = (C.c_int64 * MDH_NUM_KERNELS)()
+        check(self.L.mdh_profile_read(self.handle, ms, nl, int(reset)), "mdh_profile_read")
+        return {self.L.mdh_kernel_name(k).decode(): (ms[k], nl[k]) for k in range(MDH_NUM_KERNELS)}
+
+    @property
+    def frames_seen(self) -> int:
+        return self.L.mdh_frames_seen(self.handle)

@@ -1,0 +1,613 @@
+// metdet_hip.hip -- host side of libmetdet_hip.so: the C-ABI of include/metdet_hip.h over the gfx950
+// kernels in metdet_kernels.hpp.  No torch, no Triton, no CUDA-compat layer; one HIP stream per context.
+//
+// Host logic mirrored from the reference (all data-independent, so it stays on the host):
+//   * when the noise sigma is due          SNR_SW.update            Detector.py:81-91
+//   * the EMA momentum warm-up schedule    EMA.adjust_weight        utils.py:360-368
+//   * lineset_nms                          utils.py:780-839
+// Everything that touches pixels runs on the device; the running scalars (snr, threshold) live on the device
+// too, so a pass of K frames is queued without any host round trip.
+#include "metdet_kernels.hpp"
+
+#include "../../include/metdet_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static void set_err(const std::string& s) { g_err = s; }
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            set_err(std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" +            \
+                    std::to_string(__LINE__) + ")");                                                   \
+            return MDH_E_HIP;                                                                          \
+        }                                                                                              \
+    } while (0)
+
+enum KernelKind { KK_NOISE_SUMS = 0, KK_NOISE_FINAL, KK_STACK_THR, KK_MORPH, KK_DY_ALIVE, KK_DY_APPLY, KK_HOUGH, KK_CLASSIC };
+static const char* kKernelNames[MDH_NUM_KERNELS] = {"noise_sums", "noise_finalize", "stack_threshold", "morph_close",
+                                                    "dy_alive",   "dy_apply",       "hough_ppht",      "classic"};
+
+struct ProfSpan {
+    int kind;
+    hipEvent_t a, b;
+};
+
+struct mdh_ctx {
+    int device = 0;
+    int H = 0, W = 0, WW = 0, n = 0, R = 0, Kmax = 0;
+    size_t HW = 0, words = 0;
+    mdh_cfg cfg{};
+    hipStream_t stream = nullptr;
+    int64_t t = 0;  // frames consumed (SlidingWindow.timer)
+    // EMA schedule (host mirror of utils.py:334-368)
+    double ema_m0 = 0, ema_warm = 0;
+    int64_t ema_t = 0;
+    double coef_a = 0, coef_b = 0;
+    int numrho = 0;
+    // device buffers
+    uint8_t* d_ring = nullptr;
+    uint8_t* d_zero = nullptr;
+    const uint8_t** d_ptrtab = nullptr;
+    const uint8_t** h_ptrtab = nullptr;
+    NoiseJob *d_jobs = nullptr, *h_jobs = nullptr;
+    long long* d_sums = nullptr;
+    ScalarState* d_state = nullptr;
+    FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
+    int* d_thr = nullptr;
+    u64 *d_bbits = nullptr, *d_act = nullptr, *d_alive = nullptr, *d_dst = nullptr, *d_work = nullptr, *d_planes = nullptr;
+    int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr;
+    int* d_accum = nullptr;
+    unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
+    int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
+    double *d_gap = nullptr, *h_gap = nullptr;
+    float* d_trig = nullptr;
+    uint8_t* d_expand = nullptr;
+    std::vector<const uint8_t*> hist;  // device pointers of the last n-1 frames, oldest first
+    // pass bookkeeping
+    bool pending = false;      // mdh_update done, mdh_detect not yet
+    int last_K = 0;            // frames of the most recent pass
+    int64_t last_t_base = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfSpan> spans;
+    double prof_ms[MDH_NUM_KERNELS] = {0};
+    int64_t prof_n[MDH_NUM_KERNELS] = {0};
+};
+
+extern "C" const char* mdh_last_error(void) { return g_err.c_str(); }
+extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KERNELS) ? kKernelNames[k] : ""; }
+extern "C" int64_t mdh_frames_seen(const mdh_ctx* c) { return c ? c->t : -1; }
+
+template <typename T>
+static int dev_alloc(T*& p, size_t count, bool zero = true) {
+    HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(p, 0, count * sizeof(T)));
+    return MDH_OK;
+}
+template <typename T>
+static int host_alloc(T*& p, size_t count) {
+    HIPCHK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    memset(p, 0, count * sizeof(T));
+    return MDH_OK;
+}
+
+static void free_all(mdh_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* dev[] = {c->d_ring,  c->d_zero,     c->d_ptrtab,   c->d_jobs,  c->d_sums,    c->d_state,   c->d_fscal, c->d_thr,
+                   c->d_bbits, c->d_act,      c->d_alive,    c->d_dst,   c->d_work,    c->d_planes,  c->d_rowcount,
+                   c->d_litcount, c->d_accum, c->d_nz_orig,  c->d_nz_work, c->d_lines, c->d_nraw,    c->d_gap,   c->d_trig,
+                   c->d_expand};
+    for (void* p : dev)
+        if (p) hipFree(p);
+    void* host[] = {c->h_ptrtab, c->h_jobs, c->h_fscal, c->h_litcount, c->h_lines, c->h_nraw, c->h_gap};
+    for (void* p : host)
+        if (p) hipHostFree(p);
+    for (auto& s : c->spans) {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(mdh_ctx* c) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t K = c->Kmax, HW = c->HW, words = c->words;
+    int rc;
+#define TRY(x) if ((rc = (x)) != MDH_OK) return rc
+    TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
+    TRY(dev_alloc(c->d_zero, HW));
+    TRY(dev_alloc(c->d_ptrtab, c->n - 1 + K));
+    TRY(host_alloc(c->h_ptrtab, c->n - 1 + K));
+    TRY(dev_alloc(c->d_jobs, K));
+    TRY(host_alloc(c->h_jobs, K));
+    TRY(dev_alloc(c->d_sums, 2 * K));
+    TRY(dev_alloc(c->d_state, 1));
+    TRY(dev_alloc(c->d_fscal, K));
+    TRY(host_alloc(c->h_fscal, K));
+    TRY(dev_alloc(c->d_thr, K));
+    TRY(dev_alloc(c->d_bbits, K * words));
+    TRY(dev_alloc(c->d_act, (size_t)c->R * words));
+    TRY(dev_alloc(c->d_alive, K * words));
+    TRY(dev_alloc(c->d_dst, K * words));
+    TRY(dev_alloc(c->d_work, K * words));
+    if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
+    TRY(dev_alloc(c->d_rowcount, K * c->H));
+    TRY(dev_alloc(c->d_litcount, K));
+    TRY(host_alloc(c->h_litcount, K));
+    TRY(dev_alloc(c->d_accum, K * (size_t)NUM_ANGLE * c->numrho));
+    TRY(dev_alloc(c->d_nz_orig, K * HW, false));
+    TRY(dev_alloc(c->d_nz_work, K * HW, false));
+    TRY(dev_alloc(c->d_lines, K * (size_t)MAX_LINES * 4));
+    TRY(host_alloc(c->h_lines, K * (size_t)MAX_LINES * 4));
+    TRY(dev_alloc(c->d_nraw, K));
+    TRY(host_alloc(c->h_nraw, K));
+    TRY(dev_alloc(c->d_gap, K));
+    TRY(host_alloc(c->h_gap, K));
+    TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
+    TRY(dev_alloc(c->d_expand, HW));
+#undef TRY
+    // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
+    float trig[2 * NUM_ANGLE];
+    const float theta = (float)(3.14159265358979323846 / 180.0);
+    for (int k = 0; k < NUM_ANGLE; ++k) {
+        trig[2 * k] = (float)(cos((double)k * theta) * 1.0f);
+        trig[2 * k + 1] = (float)(sin((double)k * theta) * 1.0f);
+    }
+    HIPCHK(hipMemcpy(c->d_trig, trig, sizeof(trig), hipMemcpyHostToDevice));
+    ScalarState st{};
+    static const double kA[3] = {2.0, 1.2, 0.9}, kB[3] = {4.4, 3.6, 3.0};
+    static const int kInit[3] = {7, 5, 3};
+    c->coef_a = kA[c->cfg.sensitivity];
+    c->coef_b = kB[c->cfg.sensitivity];
+    st.thr = c->cfg.adaptive_bi_thre ? kInit[c->cfg.sensitivity] : c->cfg.init_value;  // Detector.py:204-209
+    st.thr_f = st.thr;
+    HIPCHK(hipMemcpy(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
+    c->ema_m0 = 1 - (double)c->cfg.interval / 60;  // Detector.py:61
+    c->ema_warm = c->n;                            // warmup_speed = n (Detector.py:62)
+    c->ema_t = 0;
+    c->hist.assign(c->n - 1, c->d_zero);
+    return MDH_OK;
+}
+
+extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh_cfg* cfg) {
+    if (!cfg || H <= 0 || W <= 0 || H > 32767 || W > 32767 || n_window < 1 || n_window > MDH_MAX_WINDOW) {
+        set_err("mdh_create: bad geometry or window (need 1 <= n <= 255, 0 < H,W <= 32767)");
+        return nullptr;
+    }
+    if (cfg->sensitivity < 0 || cfg->sensitivity > 2 || cfg->interval < 1 ||
+        (cfg->detector != MDH_DET_M3 && cfg->detector != MDH_DET_CLASSIC)) {
+        set_err("mdh_create: bad cfg (sensitivity / interval / detector)");
+        return nullptr;
+    }
+    const int* r = cfg->roi;
+    if (r[0] < 0 || r[1] < 0 || r[2] > H || r[3] > W || r[2] <= r[0] || r[3] <= r[1]) {
+        set_err("mdh_create: std_roi outside the frame or empty");
+        return nullptr;
+    }
+    if (!(cfg->mask_area > 0)) {
+        set_err("mdh_create: mask_area must be > 0");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err("mdh_create: no HIP device visible -- libmetdet_hip needs an AMD GPU (there is no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        set_err("mdh_create: device index out of range");
+        return nullptr;
+    }
+    mdh_ctx* c = new mdh_ctx();
+    c->device = device;
+    c->H = H;
+    c->W = W;
+    c->WW = (W + 63) / 64;
+    c->n = n_window;
+    c->Kmax = cfg->max_batch > 0 ? cfg->max_batch : 64;
+    c->R = c->n - 1 + c->Kmax;
+    if (c->R < c->n) c->R = c->n;
+    c->HW = (size_t)H * W;
+    c->words = (size_t)H * c->WW;
+    c->cfg = *cfg;
+    c->numrho = (W + H) * 2 + 1;
+    if (create_impl(c) != MDH_OK) {
+        std::string keep = g_err;
+        free_all(c);
+        set_err(keep);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void mdh_destroy(mdh_ctx* c) { free_all(c); }
+
+// ------------------------------------------------------------------------------------------------ profiling
+static inline void span_begin(mdh_ctx* c, int kind) {
+    if (!c->prof) return;
+    ProfSpan s;
+    s.kind = kind;
+    hipEventCreate(&s.a);
+    hipEventCreate(&s.b);
+    hipEventRecord(s.a, c->stream);
+    c->spans.push_back(s);
+}
+static inline void span_end(mdh_ctx* c) {
+    if (!c->prof) return;
+    hipEventRecord(c->spans.back().b, c->stream);
+}
+static void spans_collect(mdh_ctx* c) {
+    for (auto& s : c->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->prof_ms[s.kind] += ms;
+            c->prof_n[s.kind] += 1;
+        }
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    c->spans.clear();
+}
+extern "C" int mdh_profile_enable(mdh_ctx* c, int on) {
+    if (!c) return MDH_E_ARG;
+    c->prof = on != 0;
+    return MDH_OK;
+}
+extern "C" int mdh_profile_read(mdh_ctx* c, double* ms, int64_t* launches, int reset) {
+    if (!c) return MDH_E_ARG;
+    for (int k = 0; k < MDH_NUM_KERNELS; ++k) {
+        if (ms) ms[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_n[k];
+        if (reset) {
+            c->prof_ms[k] = 0;
+            c->prof_n[k] = 0;
+        }
+    }
+    return MDH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ passes
+static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
+    PassGeom g;
+    g.H = c->H; g.W = c->W; g.WW = c->WW; g.n = c->n; g.K = K; g.t_base = t_base; g.R = c->R;
+    return g;
+}
+
+// Stage K frames (absolute timers t_base+1 .. t_base+K): build the pointer table [hist (n-1) | pass frames (K)].
+static int stage_frames(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
+    const int64_t t_base = c->t;
+    for (int e = 0; e < c->n - 1; ++e) c->h_ptrtab[e] = c->hist[e];
+    for (int i = 0; i < K; ++i) {
+        const int64_t slot = (t_base + i) % c->R;
+        if (on_device) {
+            c->h_ptrtab[c->n - 1 + i] = frames + (size_t)i * c->HW;
+        } else {
+            c->h_ptrtab[c->n - 1 + i] = c->d_ring + (size_t)slot * c->HW;
+        }
+    }
+    if (!on_device) {
+        // contiguous host frames -> ring slots (t_base + i) % R : at most two runs
+        int i = 0;
+        while (i < K) {
+            const int64_t slot = (t_base + i) % c->R;
+            const int run = (int)std::min<int64_t>(K - i, c->R - slot);
+            HIPCHK(hipMemcpyAsync(c->d_ring + (size_t)slot * c->HW, frames + (size_t)i * c->HW, (size_t)run * c->HW,
+                                  hipMemcpyHostToDevice, c->stream));
+            i += run;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->d_ptrtab, c->h_ptrtab, sizeof(uint8_t*) * (c->n - 1 + K), hipMemcpyHostToDevice, c->stream));
+    return MDH_OK;
+}
+
+// LineDetector.update for the K staged frames: noise sums where due, then the scalar chain.
+static int run_noise(mdh_ctx* c, int K) {
+    const int64_t t_base = c->t;
+    const int n = c->n;
+    const int64_t std_interval = (int64_t)c->cfg.interval * n;  // Detector.py:63
+    int nj = 0;
+    for (int i = 0; i < K; ++i) {
+        const int64_t t = t_base + 1 + i;
+        int k_used = 0;
+        if (t > n && t % std_interval == 0) k_used = n;      // Detector.py:82
+        else if (t > 1 && t <= n) k_used = (int)t;           // Detector.py:87
+        if (!k_used) continue;
+        double m = c->ema_m0;
+        if (c->ema_warm != 0) {  // utils.py:360-368
+            const double ramp = (double)c->ema_t * (1 - c->ema_m0) * c->ema_warm;
+            if (ramp < 1) {
+                const double u = 1 - ramp;
+                m = c->ema_m0 * (1 - u * u);
+            } else {
+                c->ema_warm = 0;
+            }
+        }
+        c->ema_t += 1;
+        NoiseJob& j = c->h_jobs[nj++];
+        j.frame = i;
+        j.k_used = k_used;
+        j.m_cur = m;
+        j.one_minus = 1 - m;
+    }
+    const int* r = c->cfg.roi;
+    const int rh = r[2] - r[0], rw = r[3] - r[1];
+    PassGeom g = geom(c, K, t_base);
+    if (nj) {
+        HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->stream));
+        const int npx = rh * rw;
+        dim3 grid(std::max(1, std::min((npx + 255) / 256, 256)), nj);
+        span_begin(c, KK_NOISE_SUMS);
+        hipLaunchKernelGGL(k_noise_sums, grid, dim3(256), 0, c->stream, c->d_ptrtab, c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
+        span_end(c);
+    }
+    span_begin(c, KK_NOISE_FINAL);
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(64), 0, c->stream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_fscal,
+                       c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
+    span_end(c);
+    HIPCHK(hipGetLastError());
+    return MDH_OK;
+}
+
+// {M3,Classic}Detector.detect for the K staged frames, up to the raw Hough segments; results land in pinned memory.
+static int run_detect(mdh_ctx* c, int K) {
+    const int64_t t_base = c->t;
+    PassGeom g = geom(c, K, t_base);
+    const int words = (int)c->words;
+    HIPCHK(hipMemsetAsync(c->d_rowcount, 0, sizeof(int) * (size_t)K * c->H, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_litcount, 0, sizeof(int) * K, c->stream));
+    if (c->cfg.detector == MDH_DET_M3) {
+        span_begin(c, KK_STACK_THR);
+        hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr,
+                           c->d_bbits, g);
+        span_end(c);
+        const int nb = (c->H + MORPH_RB - 1) / MORPH_RB;
+        span_begin(c, KK_MORPH);
+        hipLaunchKernelGGL(k_morph_close, dim3((nb * c->WW + 255) / 256, K), dim3(256), 0, c->stream, c->d_bbits, c->d_act, g);
+        span_end(c);
+        if (c->cfg.dy_mask) {
+            span_begin(c, KK_DY_ALIVE);
+            hipLaunchKernelGGL(k_dy_alive, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_act, c->d_alive, g);
+            span_end(c);
+        }
+        span_begin(c, KK_DY_APPLY);
+        hipLaunchKernelGGL(k_dy_apply, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_act, c->d_alive, c->d_dst,
+                           c->d_work, c->d_rowcount, c->d_litcount, g, c->cfg.dy_mask);
+        span_end(c);
+    } else {
+        span_begin(c, KK_CLASSIC);
+        hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, c->d_planes, g);
+        hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_planes, c->d_dst,
+                           c->d_work, c->d_rowcount, c->d_litcount, g);
+        span_end(c);
+    }
+    HoughParams P;
+    P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
+    P.threshold = c->cfg.hough_threshold;
+    P.line_length = c->cfg.hough_min_len;  // cvRound(int) == int
+    P.max_gap = c->cfg.hough_max_gap;
+    P.fixed_gap = c->cfg.detector == MDH_DET_CLASSIC;
+    P.mask_area = c->cfg.mask_area;
+    P.dst_bits = c->d_dst; P.work_bits = c->d_work; P.rowcount = c->d_rowcount; P.litcount = c->d_litcount;
+    P.accum = c->d_accum; P.nz_orig = c->d_nz_orig; P.nz_work = c->d_nz_work; P.nz_cap = (long long)c->HW;
+    P.out_lines = c->d_lines; P.out_nraw = c->d_nraw; P.out_gap = c->d_gap; P.trig = c->d_trig;
+    span_begin(c, KK_HOUGH);
+    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), 0, c->stream, P);
+    span_end(c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_fscal, c->d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_nraw, c->d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_litcount, c->d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_gap, c->d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_lines, c->d_lines, sizeof(int) * (size_t)K * MAX_LINES * 4, hipMemcpyDeviceToHost, c->stream));
+    return MDH_OK;
+}
+
+// After a pass: remember where the last n-1 frames live (copying caller-owned device frames into the ring).
+static int retire_frames(mdh_ctx* c, int K, int on_device) {
+    const int64_t t_base = c->t;
+    const int keep = c->n - 1;
+    std::vector<const uint8_t*> nh(keep);
+    for (int e = 0; e < keep; ++e) {
+        // entry e of the new history = table entry K + e of this pass
+        const int src = K + e;
+        if (src < keep) {
+            nh[e] = c->hist[src];
+        } else {
+            const int i = src - keep;
+            uint8_t* slot = c->d_ring + (size_t)((t_base + i) % c->R) * c->HW;
+            if (on_device)
+                HIPCHK(hipMemcpyAsync(slot, c->h_ptrtab[keep + i], c->HW, hipMemcpyDeviceToDevice, c->stream));
+            nh[e] = slot;
+        }
+    }
+    c->hist.swap(nh);
+    return MDH_OK;
+}
+
+extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, double* nonline) {
+    // utils.py:780-839.  Order: squared length descending; ties: later index first (stable ascending sort, reversed).
+    if (n <= 0) return 0;
+    std::vector<int64_t> len2(n);
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) {
+        const int64_t dx = (int64_t)lines[4 * i + 2] - lines[4 * i], dy = (int64_t)lines[4 * i + 3] - lines[4 * i + 1];
+        len2[i] = dx * dx + dy * dy;
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len2[a] < len2[b]; });
+    std::reverse(order.begin(), order.end());
+    std::vector<char> taken(n, 0);
+    int kept = 0;
+    for (int pos = 0; pos < n; ++pos) {
+        const int p = order[pos];
+        if (taken[p]) continue;
+        taken[p] = 1;
+        const int32_t* L = lines + 4 * p;
+        const int64_t A = (int64_t)L[3] - L[1], B = (int64_t)L[0] - L[2], C = (int64_t)L[2] * L[1] - (int64_t)L[3] * L[0];
+        const int64_t pcx = ((int64_t)L[2] + L[0]) >> 1, pcy = ((int64_t)L[3] + L[1]) >> 1;  // floor //2
+        int64_t widest = 0;
+        for (int qp = pos; qp < n; ++qp) {
+            const int q = order[qp];
+            if (taken[q]) continue;
+            const int32_t* M = lines + 4 * q;
+            const int64_t qcx = ((int64_t)M[2] + M[0]) >> 1, qcy = ((int64_t)M[3] + M[1]) >> 1;
+            const int64_t d2 = (pcx - qcx) * (pcx - qcx) + (pcy - qcy) * (pcy - qcy);
+            if (d2 < len2[p] / 4) {
+                taken[q] = 1;
+                widest = std::max<int64_t>(widest, std::llabs(A * qcx + B * qcy + C));
+            }
+        }
+        if (out_lines) memcpy(out_lines + 4 * kept, L, 4 * sizeof(int32_t));
+        if (nonline) {
+            const double v = (double)widest / std::sqrt((double)(A * A + B * B)) / std::sqrt((double)len2[p]) * 2;
+            nonline[kept] = v > 1 ? 1 : v;
+        }
+        ++kept;
+    }
+    return kept;
+}
+
+// Wait for the pass and hand results to the caller.
+static int finish_pass(mdh_ctx* c, int K, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    spans_collect(c);
+    std::vector<int32_t> tmp_l(4 * MAX_LINES);
+    std::vector<double> tmp_p(MAX_LINES);
+    for (int i = 0; i < K; ++i) {
+        const int n_raw = c->h_nraw[i];
+        const int stored = std::min(n_raw, MAX_LINES);
+        const int32_t* L = c->h_lines + (size_t)i * MAX_LINES * 4;
+        if (raw_lines) memcpy(raw_lines + (size_t)i * MAX_LINES * 4, L, sizeof(int32_t) * 4 * stored);
+        int n_nms = 0;
+        if (n_raw > 0 && n_raw <= 500) {  // NUM_LINES_TOOMUCH (Detector.py:30, 358-360)
+            n_nms = mdh_lineset_nms(L, stored, nms_lines ? nms_lines + (size_t)i * MAX_LINES * 4 : tmp_l.data(),
+                                    nonline ? nonline + (size_t)i * MAX_LINES : tmp_p.data());
+        }
+        if (info) {
+            mdh_frame_info& o = info[i];
+            o.n_raw = n_raw;
+            o.n_nms = n_nms;
+            o.lit_count = c->h_litcount[i];
+            o.bi_threshold = c->h_fscal[i].thr;
+            o.bi_threshold_float = c->h_fscal[i].thr_f;
+            o.snr = c->h_fscal[i].snr;
+            o.sigma = c->h_fscal[i].sigma;
+            o.dst_sum = (double)c->h_litcount[i] / c->cfg.mask_area * 100;  // Detector.py:342
+            o.hough_gap = c->h_gap[i];
+        }
+    }
+    return MDH_OK;
+}
+
+extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
+    if (!c || !frame) { set_err("mdh_update: null argument"); return MDH_E_ARG; }
+    if (c->pending) { set_err("mdh_update: previous frame not yet consumed by mdh_detect"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = stage_frames(c, frame, 1, 0)) != MDH_OK) return rc;
+    if ((rc = run_noise(c, 1)) != MDH_OK) return rc;
+    // the caller may reuse `frame` after return (the reference copies it, utils.py:280)
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pending = true;
+    return MDH_OK;
+}
+
+extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
+    if (!c) { set_err("mdh_detect: null context"); return MDH_E_ARG; }
+    if (!c->pending) { set_err("mdh_detect: call mdh_update first"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = run_detect(c, 1)) != MDH_OK) return rc;
+    if ((rc = retire_frames(c, 1, 0)) != MDH_OK) return rc;
+    if ((rc = finish_pass(c, 1, info, raw_lines, nms_lines, nonline)) != MDH_OK) return rc;
+    c->last_K = 1;
+    c->last_t_base = c->t;
+    c->t += 1;
+    c->pending = false;
+    return MDH_OK;
+}
+
+extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int on_device, mdh_frame_info* info,
+                                 int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
+    if (!c || !frames || K < 0) { set_err("mdh_process_batch: bad argument"); return MDH_E_ARG; }
+    if (c->pending) { set_err("mdh_process_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int done = 0;
+    while (done < K) {
+        const int k = std::min(K - done, c->Kmax);
+        const uint8_t* f = frames + (size_t)done * c->HW;
+        int rc;
+        if ((rc = stage_frames(c, f, k, on_device)) != MDH_OK) return rc;
+        if ((rc = run_noise(c, k)) != MDH_OK) return rc;
+        if ((rc = run_detect(c, k)) != MDH_OK) return rc;
+        if ((rc = retire_frames(c, k, on_device)) != MDH_OK) return rc;
+        if ((rc = finish_pass(c, k, info ? info + done : nullptr, raw_lines ? raw_lines + (size_t)done * MAX_LINES * 4 : nullptr,
+                              nms_lines ? nms_lines + (size_t)done * MAX_LINES * 4 : nullptr,
+                              nonline ? nonline + (size_t)done * MAX_LINES : nullptr)) != MDH_OK)
+            return rc;
+        c->last_K = k;
+        c->last_t_base = c->t;
+        c->t += k;
+        done += k;
+    }
+    return MDH_OK;
+}
+
+extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {
+    if (!c || !out) { set_err("mdh_get_binary: null argument"); return MDH_E_ARG; }
+    if (c->last_K <= 0) { set_err("mdh_get_binary: no pass has run yet"); return MDH_E_STATE; }
+    if (index < 0) index = c->last_K - 1;
+    if (index >= c->last_K) { set_err("mdh_get_binary: index beyond the last pass"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const u64* bits;
+    if (stage == 0) {
+        bits = c->d_dst + (size_t)index * c->words;
+    } else if (stage == 1 && c->cfg.detector == MDH_DET_M3) {
+        const int64_t t = c->last_t_base + 1 + index;
+        bits = c->d_act + (size_t)((t - 1) % c->R) * c->words;
+    } else {
+        set_err("mdh_get_binary: unknown stage");
+        return MDH_E_ARG;
+    }
+    const int total = (int)c->HW;
+    hipLaunchKernelGGL(k_expand_bits, dim3((total + 255) / 256), dim3(256), 0, c->stream, bits, c->d_expand, c->H, c->W, c->WW);
+    HIPCHK(hipMemcpyAsync(out, c->d_expand, c->HW, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MDH_OK;
+}
+
+extern "C" void* mdh_device_alloc(mdh_ctx* c, uint64_t bytes) {
+    if (!c) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+        set_err("mdh_device_alloc: hipMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+extern "C" int mdh_device_free(mdh_ctx* c, void* p) {
+    if (!c) return MDH_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(p));
+    return MDH_OK;
+}
+extern "C" int mdh_device_upload(mdh_ctx* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c || !dst || !src) return MDH_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MDH_OK;
+}

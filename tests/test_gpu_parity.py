@@ -1,0 +1,228 @@
+"""HIP path vs the CPU oracle, through the C-ABI (run on the MI355X box: pytest -m gpu).
+
+Bar: bit-exact -- binary images, lit counts, threshold series, raw Hough segments (discovery order), NMS output.
+The noise EMA is float64 on both sides but summed differently (exact int64 sums on the GPU vs np.std): rtol 1e-12.
+"""
+import numpy as np
+import pytest
+
+from metdetpy_amd import ClassicDetector, M3Detector
+from metdetpy_amd.synth import SkyStream
+from oracle import c_oracle as co
+from oracle import m3_oracle as mo
+from tests.helpers import binary_cfg, busy_frames, frames_normal, oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(frames, n, mask, cfg, *, batch=None, check_act=True, max_batch=64):
+    """Feed the same frames to the GPU detector and the oracle; assert parity frame by frame."""
+    H, W = mask.shape
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=max_batch)
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
+    assert tuple(det.stack.std_roi) == tuple(orc.stack.std_roi)
+    total_lines = 0
+
+    def compare(t, lines, cls_pred, info, dst, act):
+        nonlocal total_lines
+        o_lines, o_pred = orc._last
+        assert int(info["bi_threshold"]) == orc.bi_threshold, f"frame {t}: threshold"
+        assert float(info["snr"]) == pytest.approx(float(orc.stack.snr), rel=1e-12, abs=1e-300), f"frame {t}: snr"
+        if act is not None:
+            assert np.array_equal(act, orc.act), f"frame {t}: pre-mask binary differs at {np.argwhere(act != orc.act)[:5]}"
+        assert np.array_equal(dst, orc.dst), f"frame {t}: dst differs at {np.argwhere(dst != orc.dst)[:5]}"
+        assert int(info["lit_count"]) == orc.lit_count
+        assert float(info["dst_sum"]) == orc.dst_sum
+        assert float(info["hough_gap"]) == orc.gap
+        assert int(info["n_raw"]) == orc.lines_num, f"frame {t}: raw segment count"
+        assert np.array_equal(np.asarray(lines).reshape(-1, 4), np.asarray(o_lines).reshape(-1, 4)), f"frame {t}: NMS lines"
+        assert np.array_equal(cls_pred, o_pred), f"frame {t}: cls_pred"
+        total_lines += len(o_lines)
+
+    if batch is None:
+        for t, f in enumerate(frames):
+            det.update(f)
+            lines, pred = det.detect()
+            orc.update(f)
+            orc._last = orc.detect()
+            info = det._ctx._info1[0]
+            assert np.array_equal(det.linesp_ext.reshape(-1, 4),
+                                  (orc.raw_lines if orc.lines_num <= 500 else orc.raw_lines[:0]).reshape(-1, 4)), f"frame {t}: raw"
+            compare(t, lines, pred, info, det.dst, det._ctx.get_binary(-1, 1) if check_act else None)
+    else:
+        t = 0
+        arr = np.stack(frames)
+        while t < len(arr):
+            chunk = arr[t:t + batch]
+            res, info = det.detect_batch(chunk)
+            for i in range(len(chunk)):
+                orc.update(chunk[i])
+                orc._last = orc.detect()
+                passes_before = (i // max_batch) * max_batch
+                in_last_pass = i >= ((len(chunk) - 1) // max_batch) * max_batch
+                dst = det._ctx.get_binary(i - passes_before, 0) if in_last_pass else None
+                if dst is None:  # only the last internal pass is retained on the device
+                    assert int(info[i]["lit_count"]) == orc.lit_count
+                    dst = orc.dst
+                compare(t + i, res[i][0], res[i][1], info[i], dst, None)
+            t += len(chunk)
+    det.close()
+    return total_lines
+
+
+@pytest.mark.parametrize("shape,n", [((54, 96), 4), ((67, 131), 8), ((64, 64), 3), ((135, 240), 8)])
+def test_m3_busy_frames_single(shape, n):
+    mask = np.ones(shape, np.uint8)
+    # fixed threshold: the busy frames would drive the adaptive one out of range (bright structure inside the noise ROI)
+    cfg = binary_cfg(adaptive=False, init_value=9)
+    total = run_pair(busy_frames(7 + n, 3 * n + 6, shape), n, mask, cfg)
+    assert total > 0
+
+
+@pytest.mark.parametrize("sens", ["low", "normal", "high"])
+def test_m3_sensitivities_and_fixed_threshold(sens):
+    shape, n = (108, 192), 5
+    mask = np.ones(shape, np.uint8)
+    s = SkyStream(*shape, 77, speed=6, streak_period=14, streak_life=8)
+    total = run_pair([s.next() for _ in range(45)], n, mask, binary_cfg(sens))
+    assert total > 0
+    run_pair(busy_frames(22, 2 * n, shape), n, mask, binary_cfg(sens, adaptive=False, init_value=6, dy_mask=False))
+
+
+def test_m3_threshold_series_matches_reference_golden(golden_dir):
+    """The GPU threshold/snr series against the series the REFERENCE produced (tests/golden/g2)."""
+    import json, os
+    for c in json.load(open(os.path.join(golden_dir, "g2_threshold_series.json"))):
+        shape = tuple(c["shape"])
+        mask = np.ones(shape, np.uint8)
+        cfg = binary_cfg(c["sensitivity"], adaptive=c.get("adaptive", True), init_value=c.get("init_value", 7), area=c["area"],
+                         interval=c["interval"])
+        det = M3Detector(1, c["n"], mask, 10, cfg, None)
+        assert list(det.stack.std_roi) == c["std_roi"]
+        frames = np.stack(frames_normal(c["seed"], c["steps"], shape, c["mu"], c["sigma"]))
+        _, info = det.detect_batch(frames)
+        assert info["bi_threshold"].tolist() == c["bi_threshold"]
+        assert np.allclose(info["snr"], c["snr"], rtol=1e-12, atol=0)
+        assert np.allclose(info["bi_threshold_float"], c["bi_threshold_float"], rtol=1e-12, atol=0)
+        det.close()
+
+
+def test_m3_sky_stream_batched_equals_oracle():
+    H, W, n = 270, 480, 8
+    s = SkyStream(H, W, 20220413, speed=10, streak_period=30)
+    mask = np.ones((H, W), np.uint8)
+    frames = [s.next() for _ in range(70)]
+    total = run_pair(frames, n, mask, binary_cfg(), batch=33, max_batch=16)
+    assert total > 0
+
+
+def test_m3_batch_equals_single_frame_protocol():
+    shape, n = (90, 160), 6
+    mask = np.ones(shape, np.uint8)
+    frames = busy_frames(5, 40, shape)
+    cfg = binary_cfg(adaptive=False, init_value=9)
+    a = M3Detector(1, n, mask, 10, cfg, None)
+    b = M3Detector(1, n, mask, 10, cfg, None, max_batch=7)
+    singles = []
+    for f in frames:
+        a.update(f)
+        singles.append(a.detect())
+    res, _ = b.detect_batch(np.stack(frames))
+    for (l1, p1), (l2, p2) in zip(singles, res):
+        assert np.array_equal(np.asarray(l1).reshape(-1, 4), np.asarray(l2).reshape(-1, 4)) and np.array_equal(p1, p2)
+    a.close(); b.close()
+
+
+def test_m3_masked_and_ragged_width():
+    # width not a multiple of 64, mask with a dark bottom (moves the noise ROI), frames pre-masked like the loader does
+    shape, n = (61, 203), 4
+    mask = np.ones(shape, np.uint8)
+    mask[40:, :] = 0
+    frames = [f * mask for f in busy_frames(9, 20, shape)]
+    run_pair(frames, n, mask, binary_cfg(area=0.25, adaptive=False, init_value=8))
+    s = SkyStream(*shape, 5, speed=5, streak_period=10, streak_life=6, mask01=mask)
+    run_pair([s.next() for _ in range(30)], n, mask, binary_cfg(area=0.25))
+
+
+def test_m3_edge_inputs():
+    shape, n = (48, 80), 4
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg()
+    frames = [np.zeros(shape, np.uint8)] * 3 + [np.full(shape, 255, np.uint8)] * 3 + busy_frames(3, 6, shape)
+    run_pair(frames, n, mask, cfg)
+    # n = 1: the window is the frame itself, diff is always 0
+    run_pair(busy_frames(4, 5, shape), 1, mask, cfg)
+
+
+def test_m3_too_many_lines_guard():
+    """A frame with > 500 segments is discarded (Detector.py:358-360) but lines_num still reports the count."""
+    shape, n = (256, 256), 2
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=5, dy_mask=False, hough=(10, 10, 0))
+    base = np.full(shape, 10, np.uint8)
+    comb = base.copy()
+    for y in range(2, 250, 4):
+        for x0 in range(2, 240, 16):
+            comb[y:y + 2, x0:x0 + 14] = 250   # ~900 separate 2x14 dashes -> > 700 segments
+    det = M3Detector(1, n, mask, 10, cfg, None)
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
+    for f in (base, comb):
+        det.update(f); lines, pred = det.detect()
+        orc.update(f); o_lines, o_pred = orc.detect()
+    assert orc.lines_num > 500 and det.lines_num == orc.lines_num
+    assert len(lines) == 0 and pred.shape == (0, 10) and len(o_lines) == 0
+    assert np.array_equal(det.dst, orc.dst)
+    det.close()
+
+
+def test_hough_many_points_global_list():
+    """More lit pixels than the LDS point list holds (8192): the global-memory list path."""
+    shape, n = (200, 320), 2
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=5, dy_mask=False)
+    rng = np.random.default_rng(1)
+    base = np.full(shape, 10, np.uint8)
+    blob = base.copy()
+    blob[20:120, 30:200] = 200          # 17 000 px block
+    blob[150:153, 10:300] = 220
+    run_pair([base, blob, base], n, mask, cfg)
+
+
+@pytest.mark.parametrize("n_eff", [4, 3])
+def test_classic_detector(n_eff):
+    shape = (80, 144)
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=12, hough=(10, 10, 3))
+    fps = 25.0
+    det = ClassicDetector(1, fps, mask, 10, cfg, None)
+    assert det.stack_maxsize == int(4 / fps * fps)
+    orc = mo.ClassicOracle(mask, threshold=12, hough_threshold=10, hough_min_len=10, hough_max_gap=3, hough_fn=co.hough_lines_p)
+    got = 0
+    for t, f in enumerate(busy_frames(31, 16, shape)):
+        det.update(f); lines, pred = det.detect()
+        orc.update(f); o_lines, o_pred = orc.detect()
+        assert np.array_equal(np.asarray(lines).reshape(-1, 4), o_lines.reshape(-1, 4)), t
+        assert np.array_equal(pred, o_pred)
+        if t >= 3:
+            assert np.array_equal(det.dst, orc.dst), t
+        got += len(o_lines)
+    assert got > 0
+    det.close()
+
+
+def test_api_errors():
+    shape = (32, 64)
+    mask = np.ones(shape, np.uint8)
+    det = M3Detector(1, 4, mask, 10, binary_cfg(), None)
+    with pytest.raises(RuntimeError):
+        det.detect()
+    with pytest.raises(ValueError):
+        det.update(np.zeros((31, 64), np.uint8))
+    det.update(np.zeros(shape, np.uint8))
+    from metdetpy_amd._lib import MetDetHipError
+    with pytest.raises(MetDetHipError):
+        det._ctx.update(np.zeros(shape, np.uint8))  # two updates in a row
+    det.detect()
+    det.close()
+    with pytest.raises(ValueError):
+        M3Detector(1, 300, mask, 10, binary_cfg(), None)
