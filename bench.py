@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the M3 line-detector hot path on synthetic 1920x1080 uint8 streams (BASELINE config C2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one native pass (mdh_process_batch) over a batch of `--batch` consecutive frames of a seeded synthetic
+night-sky stream that is already resident in HBM (a pool of `--batch` frames per GPU, cycled): update + detect incl.
+Hough and NMS, results on the host.  N > 1: one process per GPU (torchrun), one independent stream per GPU
+(BASELINE config C4), no data-path collective; RCCL only gathers the per-rank detection counts at the end.
+`value` = frames all ranks processed / max-over-ranks time.
+
+Also on the JSON line:
+  roofline      dominant pixel kernel (stack_threshold): algorithmic HBM reads per launch ((n+1)*H*W per frame,
+                SURVEY.md 8d) / mean launch duration measured with HIP events on the library's own stream.
+  cpu_baseline  the C port of the CPU oracle (oracle/metdet_oracle.c, OpenMP) timed on this box's host cores over a
+                bounded sample of the same stream (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+WORKLOADS = {
+    # name: (H, W, n, seed, use_mask)
+    "C2": dict(H=1080, W=1920, n=8, seed=20220413, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
+    "C3": dict(H=2160, W=3840, n=16, seed=20220414, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
+    "C1s": dict(H=540, W=960, n=8, seed=20220412, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="frames per step (and frames resident in HBM per GPU)")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def make_cfg():
+    from metdetpy_amd import BinaryCfg, BinaryCoreCfg, DynamicCfg, HoughLineCfg
+    # config/m3det_normal.json detector block
+    return BinaryCfg(BinaryCoreCfg(True, 7, "normal", 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
+
+
+def load_mask(H, W):
+    """test/mask-east.jpg binarised by the loader rule (fixture committed as tests/golden/mask_east_*.npy)."""
+    path = os.path.join(ROOT, "tests", "golden", f"mask_east_{W}x{H}.npz")
+    if os.path.exists(path):
+        return np.load(path)["mask"]
+    return None
+
+
+def cpu_baseline(frames, n, mask, seconds):
+    """Time the C port of the oracle (update + detect up to raw Hough + NMS) on the host cores."""
+    from oracle import c_oracle as co
+    from metdetpy_amd.utils import select_std_roi
+    roi = select_std_roi(mask, 0.1)
+    det = co.CM3(n, mask, roi)
+    threads = int(co.lib().om3_num_threads())
+    warm = min(2 * n, len(frames))
+    for i in range(warm):
+        det.update(frames[i])
+        det.detect()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        f = frames[(warm + done) % len(frames)]
+        det.update(f)
+        raw = det.detect()
+        if 0 < len(raw) <= 500:
+            co.lineset_nms(raw)
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or done >= 4 * len(frames):
+            break
+    return dict(value=done / dt, unit="frames/s", cores=threads, kind="port",
+                sample=f"{done} frames of the same stream after {warm} warm-up frames, oracle/metdet_oracle.c "
+                       f"(gcc -O3 -fopenmp, {threads} threads), host cpu_count={os.cpu_count()}")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    wl = WORKLOADS[a.workload]
+    H, W, n = wl["H"], wl["W"], wl["n"]
+    from metdetpy_amd import M3Detector
+    from metdetpy_amd import _lib
+    from metdetpy_amd.synth import SkyStream
+
+    mask = np.ones((H, W), np.uint8)
+    if a.workload == "C3":
+        m = load_mask(H, W)
+        if m is not None:
+            mask = m
+    B = a.batch
+    stream = SkyStream(H, W, wl["seed"] + rank, mask01=None if mask.all() else mask)
+    frames = stream.take(B)
+    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=B)
+    ctx = det._ctx
+    pool = ctx.device_alloc(frames.nbytes)
+    ctx.device_upload(pool, frames)
+    info = np.zeros(B, _lib.FRAME_INFO_DTYPE)
+    raw = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
+    nms = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
+    prob = np.zeros((B, _lib.MDH_MAX_LINES), np.float64)
+
+    def step():
+        ctx.process_batch_into(pool, B, True, info, raw, nms, prob)
+
+    def fence():
+        # the library synchronises its own stream inside every call; the barrier aligns the ranks
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    if not a.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    lit = segs = kept = 0
+    for _ in range(a.steps):
+        step()
+        segs += int(info["n_raw"].sum())
+        kept += int(info["n_nms"].sum())
+        lit += int(info["lit_count"].sum())
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read(reset=True) if not a.no_profile else {}
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_all = float(tmax.item())
+        counts = torch.tensor([segs, kept, lit], device="cuda", dtype=torch.int64)
+        gathered = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(gathered, counts)  # the final detection gather (RCCL)
+        tot = torch.stack(gathered).sum(0).tolist()
+    else:
+        dt_all = dt
+        tot = [segs, kept, lit]
+    frames_total = a.steps * B * world
+    fps = frames_total / dt_all
+    out = {
+        "metric": "frames/sec at 1920x1080 (1/2/4/8 GPU) + detection parity vs CPU ref",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt_all / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_normal detector cfg, {B} frames/step resident in HBM, "
+                               f"one independent stream per GPU", "frame": [W, H], "window": n, "frames_per_step": B,
+                   "parallelism": f"streams x{world}"},
+        "detections": {"raw_segments": tot[0], "nms_segments": tot[1], "lit_pixels": tot[2]},
+    }
+    if rank == 0:
+        if prof:
+            ms, launches = prof["stack_threshold"]
+            per_launch_frames = B  # one launch covers the whole pass (max_batch == batch)
+            alg_bytes = (n + 1) * H * W * per_launch_frames
+            avg_s = ms / max(launches, 1) * 1e-3
+            achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.workload}.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("stack_threshold_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "kernel": "stack_threshold", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                               "algorithmic_bytes_per_launch": alg_bytes}
+            out["kernels_ms_per_step"] = {k: v[0] / a.steps for k, v in prof.items() if v[1]}
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(frames, n, mask, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    ctx.device_free(pool)
+    det.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

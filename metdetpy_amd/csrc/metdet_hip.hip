@@ -71,12 +71,16 @@ struct mdh_ctx {
     double *d_gap = nullptr, *h_gap = nullptr;
     float* d_trig = nullptr;
     uint8_t* d_expand = nullptr;
+    long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     std::vector<const uint8_t*> hist;  // device pointers of the last n-1 frames, oldest first
     // pass bookkeeping
     bool pending = false;      // mdh_update done, mdh_detect not yet
     int last_K = 0;            // frames of the most recent pass
     int64_t last_t_base = 0;
     // profiling
+    bool force_generic = false;  // MDH_FORCE_GENERIC=1: use the n-reads kernel (A/B and parity testing)
+    bool hough_serial = false;   // MDH_HOUGH_SERIAL=1: one-point-at-a-time PPHT replay
+    bool hough_global_acc = false;  // MDH_HOUGH_GLOBAL_ACC=1: never use the LDS accumulator windows
     bool prof = false;
     std::vector<ProfSpan> spans;
     double prof_ms[MDH_NUM_KERNELS] = {0};
@@ -107,7 +111,7 @@ static void free_all(mdh_ctx* c) {
     void* dev[] = {c->d_ring,  c->d_zero,     c->d_ptrtab,   c->d_jobs,  c->d_sums,    c->d_state,   c->d_fscal, c->d_thr,
                    c->d_bbits, c->d_act,      c->d_alive,    c->d_dst,   c->d_work,    c->d_planes,  c->d_rowcount,
                    c->d_litcount, c->d_accum, c->d_nz_orig,  c->d_nz_work, c->d_lines, c->d_nraw,    c->d_gap,   c->d_trig,
-                   c->d_expand};
+                   c->d_expand, c->d_hdbg};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {c->h_ptrtab, c->h_jobs, c->h_fscal, c->h_litcount, c->h_lines, c->h_nraw, c->h_gap};
@@ -158,6 +162,7 @@ static int create_impl(mdh_ctx* c) {
     TRY(host_alloc(c->h_gap, K));
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
+    if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
 #undef TRY
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
@@ -197,6 +202,11 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         set_err("mdh_create: std_roi outside the frame or empty");
         return nullptr;
     }
+    if (cfg->init_value < 0 || cfg->init_value > 65535 || cfg->hough_threshold < 1 || cfg->hough_min_len < 0 ||
+        cfg->hough_max_gap < 0) {
+        set_err("mdh_create: init_value must be 0..65535, hough threshold >= 1, min_len / max_gap >= 0");
+        return nullptr;
+    }
     if (!(cfg->mask_area > 0)) {
         set_err("mdh_create: mask_area must be > 0");
         return nullptr;
@@ -223,6 +233,12 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->words = (size_t)H * c->WW;
     c->cfg = *cfg;
     c->numrho = (W + H) * 2 + 1;
+    const char* fg = getenv("MDH_FORCE_GENERIC");
+    c->force_generic = fg && fg[0] == '1';
+    const char* hs = getenv("MDH_HOUGH_SERIAL");
+    c->hough_serial = hs && hs[0] == '1';
+    const char* hg = getenv("MDH_HOUGH_GLOBAL_ACC");
+    c->hough_global_acc = hg && hg[0] == '1';
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
         free_all(c);
@@ -312,6 +328,39 @@ static int stage_frames(mdh_ctx* c, const uint8_t* frames, int K, int on_device)
     return MDH_OK;
 }
 
+// a1+a4+a6: time-blocked register-window kernel for 2 <= n <= 32, generic n-reads kernel otherwise.
+template <int N>
+static void launch_tb(mdh_ctx* c, const PassGeom& g) {
+    const int words = (int)c->words;
+    const int waves = (words + 3) / 4;
+    int nchunks = (4096 + waves - 1) / waves;
+    nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
+    const int Tc = (g.K + nchunks - 1) / nchunks;
+    nchunks = (g.K + Tc - 1) / Tc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_tb<N>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream,
+                       c->d_ptrtab, c->d_thr, c->d_bbits, g, Tc);
+}
+
+static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
+    const int words = (int)c->words;
+    if (c->force_generic) {
+        hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, g.K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr,
+                           c->d_bbits, g);
+        return;
+    }
+    switch (g.n) {
+#define TB_CASE(N) case N: launch_tb<N>(c, g); break;
+        TB_CASE(2) TB_CASE(3) TB_CASE(4) TB_CASE(5) TB_CASE(6) TB_CASE(7) TB_CASE(8) TB_CASE(9) TB_CASE(10) TB_CASE(11)
+        TB_CASE(12) TB_CASE(13) TB_CASE(14) TB_CASE(15) TB_CASE(16) TB_CASE(17) TB_CASE(18) TB_CASE(19) TB_CASE(20)
+        TB_CASE(21) TB_CASE(22) TB_CASE(23) TB_CASE(24) TB_CASE(25) TB_CASE(26) TB_CASE(27) TB_CASE(28) TB_CASE(29)
+        TB_CASE(30) TB_CASE(31) TB_CASE(32)
+#undef TB_CASE
+        default:
+            hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, g.K), dim3(256), 0, c->stream, c->d_ptrtab,
+                               c->d_thr, c->d_bbits, g);
+    }
+}
+
 // LineDetector.update for the K staged frames: noise sums where due, then the scalar chain.
 static int run_noise(mdh_ctx* c, int K) {
     const int64_t t_base = c->t;
@@ -370,8 +419,7 @@ static int run_detect(mdh_ctx* c, int K) {
     HIPCHK(hipMemsetAsync(c->d_litcount, 0, sizeof(int) * K, c->stream));
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR);
-        hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr,
-                           c->d_bbits, g);
+        launch_stack_threshold(c, g);
         span_end(c);
         const int nb = (c->H + MORPH_RB - 1) / MORPH_RB;
         span_begin(c, KK_MORPH);
@@ -399,6 +447,9 @@ static int run_detect(mdh_ctx* c, int K) {
     P.line_length = c->cfg.hough_min_len;  // cvRound(int) == int
     P.max_gap = c->cfg.hough_max_gap;
     P.fixed_gap = c->cfg.detector == MDH_DET_CLASSIC;
+    P.serial = c->hough_serial;
+    P.no_lds_acc = c->hough_global_acc;
+    P.dbg = c->d_hdbg;
     P.mask_area = c->cfg.mask_area;
     P.dst_bits = c->d_dst; P.work_bits = c->d_work; P.rowcount = c->d_rowcount; P.litcount = c->d_litcount;
     P.accum = c->d_accum; P.nz_orig = c->d_nz_orig; P.nz_work = c->d_nz_work; P.nz_cap = (long long)c->HW;
@@ -411,7 +462,6 @@ static int run_detect(mdh_ctx* c, int K) {
     HIPCHK(hipMemcpyAsync(c->h_nraw, c->d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_litcount, c->d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_gap, c->d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_lines, c->d_lines, sizeof(int) * (size_t)K * MAX_LINES * 4, hipMemcpyDeviceToHost, c->stream));
     return MDH_OK;
 }
 
@@ -484,6 +534,15 @@ extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, 
 static int finish_pass(mdh_ctx* c, int K, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
     HIPCHK(hipStreamSynchronize(c->stream));
     spans_collect(c);
+    // second, strided copy: only as many segments per frame as the fullest frame of the pass holds
+    int most = 0;
+    for (int i = 0; i < K; ++i) most = std::max(most, std::min(c->h_nraw[i], MAX_LINES));
+    if (most > 0) {
+        const size_t pitch = sizeof(int) * 4 * MAX_LINES;
+        HIPCHK(hipMemcpy2DAsync(c->h_lines, pitch, c->d_lines, pitch, sizeof(int) * 4 * (size_t)most, K, hipMemcpyDeviceToHost,
+                                c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     std::vector<int32_t> tmp_l(4 * MAX_LINES);
     std::vector<double> tmp_p(MAX_LINES);
     for (int i = 0; i < K; ++i) {
@@ -586,6 +645,12 @@ extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {
     hipLaunchKernelGGL(k_expand_bits, dim3((total + 255) / 256), dim3(256), 0, c->stream, bits, c->d_expand, c->H, c->W, c->WW);
     HIPCHK(hipMemcpyAsync(out, c->d_expand, c->HW, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return MDH_OK;
+}
+
+extern "C" int mdh_debug_hough(mdh_ctx* c, long long* out, int K) {
+    if (!c || !c->d_hdbg || K > c->Kmax) return MDH_E_ARG;
+    HIPCHK(hipMemcpy(out, c->d_hdbg, sizeof(long long) * 8 * K, hipMemcpyDeviceToHost));
     return MDH_OK;
 }
 

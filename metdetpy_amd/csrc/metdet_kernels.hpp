@@ -49,20 +49,23 @@ __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __rest
                                                     long long* __restrict__ sums, PassGeom g, int r0, int c0, int rh, int rw) {
     const NoiseJob job = jobs[blockIdx.y];
     const int npx = rh * rw;
+    const int k = job.k_used;
     long long s1 = 0, s2 = 0;
     // frames of the window of pass-frame i are table entries i .. i+n-1; the last k_used of them end at i+n-1
     const int e_last = job.frame + g.n - 1;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += gridDim.x * blockDim.x) {
         const int y = r0 + p / rw, x = c0 + p % rw;
         const size_t off = (size_t)y * g.W + x;
-        int tot = 0;
-        for (int k = 0; k < job.k_used; ++k) tot += ptrtab[e_last - k][off];
-        const int m = (tot / job.k_used) & 0xFF;
-        for (int k = 0; k < job.k_used; ++k) {
-            const int d = (int)ptrtab[e_last - k][off] - m;
-            s1 += d;
-            s2 += d * d;
+        // one sweep: sum x and sum x^2, then  sum (x-m) = sx - k m,  sum (x-m)^2 = sxx - 2 m sx + k m^2  (exact)
+        int sx = 0, sxx = 0;
+        for (int j = 0; j < k; ++j) {
+            const int v = ptrtab[e_last - j][off];
+            sx += v;
+            sxx += v * v;
         }
+        const int m = (sx / k) & 0xFF;
+        s1 += sx - k * m;
+        s2 += sxx - 2 * m * sx + k * m * m;
     }
     // wave reduction, then one atomic pair per wave
     for (int o = 32; o > 0; o >>= 1) {
@@ -149,6 +152,110 @@ __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* 
     const bool b = valid && (sum < c * len);
     const u64 m = __ballot(b);
     if (lane == 0) bbits[((size_t)i * g.H + y) * g.WW + w] = m;
+}
+
+// Time-blocked version (the fast path): one wave owns 256 pixels (4 bit words) and walks through a run of
+// consecutive frames keeping the n-frame window in registers, so every frame byte is fetched ONCE per pass
+// instead of n times.  Lane l holds pixels {l, 64+l, 128+l, 192+l} of the chunk as two packed u16 pairs, which
+// makes the four ballots come out in natural bit order.  All arithmetic is packed 16-bit (v_pk_*_u16).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const* __restrict__ ptrtab,
+                                                            const int* __restrict__ thr_tab, u64* __restrict__ bbits,
+                                                            PassGeom g, int Tc) {
+    constexpr int U = N < 8 ? N : 8;  // frames fetched per load burst
+    const int lane = threadIdx.x & 63;
+    const int words = g.H * g.WW;
+    const int gw0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (gw0 >= words) return;
+    const int i0 = blockIdx.y * Tc;
+    const int steps = min(Tc, g.K - i0);
+    if (steps <= 0) return;
+    // Frames are read through raw buffer descriptors (uniform base in SGPRs + 32-bit lane offset, no 64-bit
+    // address math; offsets past the frame return 0, which is how padding lanes are handled).
+    int off[4];
+    const int frame_bytes = g.H * g.W;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gw = gw0 + q;
+        bool ok = gw < words;
+        const int y = ok ? gw / g.WW : 0;
+        const int w = ok ? gw - y * g.WW : 0;
+        const int x = w * 64 + lane;
+        ok = ok && x < g.W;
+        off[q] = ok ? y * g.W + x : 0x7FFFFFFF;
+    }
+    auto fetch = [&](int e, unsigned& p01, unsigned& p23) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
+        const unsigned b0 = __builtin_amdgcn_raw_buffer_load_b8(r, off[0], 0, 0);
+        const unsigned b1 = __builtin_amdgcn_raw_buffer_load_b8(r, off[1], 0, 0);
+        const unsigned b2 = __builtin_amdgcn_raw_buffer_load_b8(r, off[2], 0, 0);
+        const unsigned b3 = __builtin_amdgcn_raw_buffer_load_b8(r, off[3], 0, 0);
+        p01 = b0 | (b1 << 16);
+        p23 = b2 | (b3 << 16);
+    };
+    union PK {
+        unsigned u;
+        u16x2 v;
+    };
+    PK w01[N], w23[N];
+    u16x2 s01 = {0, 0}, s23 = {0, 0};
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        fetch(i0 + k, w01[k].u, w23[k].u);
+        s01 += w01[k].v;
+        s23 += w23[k].v;
+    }
+    w01[N - 1].u = 0;
+    w23[N - 1].u = 0;
+    const int e_max = g.K + N - 2;  // last valid table entry
+    for (int sb = 0; sb < steps; sb += N) {
+#pragma unroll
+        for (int ub = 0; ub < N; ub += U) {
+            PK a01[U], a23[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ub + u < N) {
+                    const int e = min(i0 + sb + ub + u + N - 1, e_max);
+                    fetch(e, a01[u].u, a23[u].u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ub + u < N) {
+                    const int s = sb + ub + u;
+                    if (s < steps) {
+                        const int slot = (ub + u + N - 1) % N;
+                        s01 += a01[u].v - w01[slot].v;
+                        s23 += a23[u].v - w23[slot].v;
+                        w01[slot] = a01[u];
+                        w23[slot] = a23[u];
+                        u16x2 m01 = w01[0].v, m23 = w23[0].v;
+#pragma unroll
+                        for (int k = 1; k < N; ++k) {
+                            m01 = __builtin_elementwise_max(m01, w01[k].v);
+                            m23 = __builtin_elementwise_max(m23, w23[k].v);
+                        }
+                        const int i = i0 + s;
+                        const unsigned short T = (unsigned short)thr_tab[i];
+                        const unsigned short len = (unsigned short)window_len(g, i);
+                        const u16x2 Tv = {T, T}, Lv = {len, len};
+                        // b = (max > T) && (sum < (max - T) * len)
+                        PK e01, e23;
+                        e01.v = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(m01, Tv) * Lv, s01);
+                        e23.v = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(m23, Tv) * Lv, s23);
+                        const u64 b0 = __ballot((e01.u & 0xFFFFu) != 0), b1 = __ballot(e01.u > 0xFFFFu);
+                        const u64 b2 = __ballot((e23.u & 0xFFFFu) != 0), b3 = __ballot(e23.u > 0xFFFFu);
+                        if (lane < 4 && gw0 + lane < words) {
+                            const u64 v = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+                            bbits[(size_t)i * words + gw0 + lane] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,6 +498,8 @@ struct HoughParams {
     int H, W, WW, numrho, half;
     int threshold, line_length, max_gap;
     int fixed_gap;         // Classic: maxLineGap = max_gap; M3: adaptive (Detector.py:342-344)
+    int serial;            // 1 = one-point-at-a-time replay even when the list fits in LDS (A/B and parity testing)
+    int no_lds_acc;        // 1 = keep the whole accumulator in global memory (A/B and parity testing)
     double mask_area;
     const u64* dst_bits;   // [K][H][WW] pristine
     u64* work_bits;        // [K][H][WW] consumed
@@ -404,6 +513,7 @@ struct HoughParams {
     int* out_nraw;         // [K]
     double* out_gap;       // [K]
     const float* trig;     // [180][2] (cos, sin) as float32 of the float64 value
+    long long* dbg;        // optional [K][8] cycle stamps (MDH_HOUGH_DEBUG=1), else null
 };
 
 #define HOUGH_LDS_PTS 8192
@@ -421,146 +531,315 @@ __device__ __forceinline__ int rho_bin(int x, int y, float c, float s, int half)
     return __float2int_rn(__fadd_rn(__fmul_rn((float)x, c), __fmul_rn((float)y, s))) + half;
 }
 
-template <bool LDS_LIST>
-__device__ void ppht_run(const HoughParams& P, int i, int N, int line_gap, unsigned* list) {
-    const int lane = threadIdx.x;
-    const size_t words = (size_t)P.H * P.WW;
-    u64* work = P.work_bits + (size_t)i * words;
-    unsigned* work32 = (unsigned*)work;
-    int* acc = P.accum + (size_t)i * NUM_ANGLE * P.numrho;
-    float tc[3], ts[3];
+// Per-wave context of one frame's PPHT.
+struct Ppht {
+    const HoughParams& P;
+    u64* work;
+    unsigned* work32;
+    int* acc;
+    float tc[3], ts[3];  // this lane's 3 angles
+    int line_gap, frame, found, lane;
+    int groups, lines;  // statistics (debug)
+    // LDS-resident part of the accumulator: for angle n the rho bins [lo, hi] live in 16-bit LDS cells starting at
+    // `off` (two cells per dword, each biased by CELL_BIAS so that +-1 on one half never carries into the other);
+    // bins outside the window stay in the global accumulator.
+    unsigned* cells;
+    int lo[3], hi[3], off[3];
+    bool touched_global;
+};
+#define CELL_BIAS 0x4000
+
+__device__ __forceinline__ bool work_bit(const Ppht& C, int x, int y) {
+    return (ld_l2(&C.work[(size_t)y * C.P.WW + (x >> 6)]) >> (x & 63)) & 1;
+}
+
+// ++accum[n][rho(x,y)] for this lane's angles; key = ((new value + bias) << 8) | (255 - n): the wave-wide maximum of
+// the key is the FIRST maximum of the reference's scan over n.  Counts can be negative (OpenCV takes votes back for
+// line pixels that never voted), hence the bias.
+#define KEY_BIAS (1 << 22)
+__device__ __forceinline__ int key_value(unsigned key) { return (int)(key >> 8) - KEY_BIAS; }
+__device__ __forceinline__ void vote_issue(Ppht& C, int x, int y, int (&old)[3]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const int n = lane + 64 * q;
-        tc[q] = n < NUM_ANGLE ? P.trig[2 * n] : 0.f;
-        ts[q] = n < NUM_ANGLE ? P.trig[2 * n + 1] : 0.f;
+        const int n = C.lane + 64 * q;
+        old[q] = -1;
+        if (n < NUM_ANGLE) {
+            const int r = rho_bin(x, y, C.tc[q], C.ts[q], C.P.half);
+            if (r >= C.lo[q] && r <= C.hi[q]) {
+                const int c = C.off[q] + r - C.lo[q];
+                const int sh = (c & 1) * 16;
+                const unsigned o = atomicAdd(&C.cells[c >> 1], 1u << sh);
+                old[q] = (int)((o >> sh) & 0xFFFFu) - CELL_BIAS;
+            } else {
+                old[q] = atomicAdd(&C.acc[(size_t)n * C.P.numrho + r], 1);
+                C.touched_global = true;
+            }
+        }
     }
+}
+__device__ __forceinline__ unsigned vote_key(const Ppht& C, const int (&old)[3]) {
+    unsigned key = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = C.lane + 64 * q;
+        if (n < NUM_ANGLE) {
+            const unsigned k = ((unsigned)(old[q] + 1 + KEY_BIAS) << 8) | (unsigned)(255 - n);
+            key = k > key ? k : key;
+        }
+    }
+    return key;
+}
+__device__ __forceinline__ void unvote(Ppht& C, int x, int y) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = C.lane + 64 * q;
+        if (n < NUM_ANGLE) {
+            const int r = rho_bin(x, y, C.tc[q], C.ts[q], C.P.half);
+            if (r >= C.lo[q] && r <= C.hi[q]) {
+                const int c = C.off[q] + r - C.lo[q];
+                atomicSub(&C.cells[c >> 1], 1u << ((c & 1) * 16));
+            } else {
+                atomicSub(&C.acc[(size_t)n * C.P.numrho + r], 1);
+                C.touched_global = true;
+            }
+        }
+    }
+}
+
+// The point (x, y) reached the threshold at angle index bn: extract the segment, clear its pixels from the
+// working mask, take their votes back if the segment is long enough, emit it (hough.cpp, second half of the loop).
+__device__ void ppht_line(Ppht& C, int x, int y, int bn) {
+    ++C.lines;
+    const HoughParams& P = C.P;
+    const int lane = C.lane;
+    const float a = -P.trig[2 * bn + 1], b = P.trig[2 * bn];
+    int x0 = x, y0 = y, dx0, dy0;
+    bool xflag;
+    if (fabsf(a) > fabsf(b)) {
+        xflag = true;
+        dx0 = a > 0 ? 1 : -1;
+        dy0 = __float2int_rn(__fdiv_rn(__fmul_rn(b, 65536.f), fabsf(a)));
+        y0 = (y0 << 16) + 32768;
+    } else {
+        xflag = false;
+        dy0 = b > 0 ? 1 : -1;
+        dx0 = __float2int_rn(__fdiv_rn(__fmul_rn(a, 65536.f), fabsf(b)));
+        x0 = (x0 << 16) + 32768;
+    }
+    int end_step[2], end_x[2], end_y[2];
+    for (int k = 0; k < 2; ++k) {
+        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+        int gap = 0, last_lit = 0;
+        bool done = false;
+        for (int s0 = 0; !done; s0 += 64) {
+            const int s = s0 + lane;
+            const int X = x0 + dx * s, Y = y0 + dy * s;
+            const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
+            const bool inside = j1 >= 0 && j1 < P.W && i1 >= 0 && i1 < P.H;
+            bool lit = false;
+            if (inside) lit = work_bit(C, j1, i1);
+            const u64 mi = __ballot(inside), ml = __ballot(lit);
+            for (int bb = 0; bb < 64; ++bb) {
+                if (!((mi >> bb) & 1)) { done = true; break; }
+                if ((ml >> bb) & 1) {
+                    gap = 0;
+                    last_lit = s0 + bb;
+                } else if (++gap > C.line_gap) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+        end_step[k] = last_lit;
+        const int X = x0 + dx * last_lit, Y = y0 + dy * last_lit;
+        end_x[k] = xflag ? X : X >> 16;
+        end_y[k] = xflag ? Y >> 16 : Y;
+    }
+    const bool good = abs(end_x[1] - end_x[0]) >= P.line_length || abs(end_y[1] - end_y[0]) >= P.line_length;
+    for (int k = 0; k < 2; ++k) {
+        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+        for (int s0 = 0; s0 <= end_step[k]; s0 += 64) {
+            const int s = s0 + lane;
+            bool was = false;
+            if (s <= end_step[k]) {
+                const int X = x0 + dx * s, Y = y0 + dy * s;
+                const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
+                const unsigned bit = 1u << (j1 & 31);
+                const unsigned old = atomicAnd(&C.work32[((size_t)i1 * P.WW + (j1 >> 6)) * 2 + ((j1 >> 5) & 1)], ~bit);
+                was = old & bit;
+            }
+            u64 ms = __ballot(was);
+            if (good) {
+                while (ms) {
+                    const int bb = __builtin_ctzll(ms);
+                    ms &= ms - 1;
+                    const int sb = s0 + bb;
+                    const int X = x0 + dx * sb, Y = y0 + dy * sb;
+                    unvote(C, xflag ? X : X >> 16, xflag ? Y >> 16 : Y);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (good) {
+        if (C.found < MAX_LINES && lane == 0) {
+            int* o = P.out_lines + ((size_t)C.frame * MAX_LINES + C.found) * 4;
+            o[0] = end_x[0]; o[1] = end_y[0]; o[2] = end_x[1]; o[3] = end_y[1];
+        }
+        ++C.found;
+    }
+}
+
+__device__ __forceinline__ u64 rng_step(u64 s) { return (u64)(unsigned)s * 4164903690ull + (s >> 32); }
+
+// Serial replay (any list size; the list lives in global memory when it does not fit in LDS).
+template <bool LDS_LIST>
+__device__ void ppht_serial(Ppht& C, int N, unsigned* list) {
     u64 state = 0xFFFFFFFFFFFFFFFFull;
-    int found = 0;
     for (int count = N; count > 0; --count) {
-        state = (u64)(unsigned)state * 4164903690ull + (state >> 32);
+        state = rng_step(state);
         const int idx = (int)((unsigned)state % (unsigned)count);
         unsigned pt;
         if (LDS_LIST) {
             pt = list[idx];
             const unsigned last = list[count - 1];
-            if (lane == 0) list[idx] = last;
+            if (C.lane == 0) list[idx] = last;
         } else {
             pt = ld_l2(&list[idx]);
             const unsigned last = ld_l2(&list[count - 1]);
-            if (lane == 0) st_l2(&list[idx], last);
+            if (C.lane == 0) st_l2(&list[idx], last);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const int x = pt & 0xFFFF, y = pt >> 16;
-        if (!((ld_l2(&work[(size_t)y * P.WW + (x >> 6)]) >> (x & 63)) & 1)) continue;
-        // vote: ++accum[n][r], keep the first maximum
-        int bv = -1, bn = 0;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int n = lane + 64 * q;
-            if (n < NUM_ANGLE) {
-                const int r = rho_bin(x, y, tc[q], ts[q], P.half);
-                const int val = atomicAdd(&acc[(size_t)n * P.numrho + r], 1) + 1;
-                if (val > bv) { bv = val; bn = n; }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int ov = __shfl_xor(bv, o), on = __shfl_xor(bn, o);
-            if (ov > bv || (ov == bv && on < bn)) { bv = ov; bn = on; }
-        }
-        if (bv < P.threshold) continue;
-        // line through (x, y) at angle bn
-        const float a = -P.trig[2 * bn + 1], b = P.trig[2 * bn];
-        int x0 = x, y0 = y, dx0, dy0;
-        bool xflag;
-        if (fabsf(a) > fabsf(b)) {
-            xflag = true;
-            dx0 = a > 0 ? 1 : -1;
-            dy0 = __float2int_rn(__fdiv_rn(__fmul_rn(b, 65536.f), fabsf(a)));
-            y0 = (y0 << 16) + 32768;
-        } else {
-            xflag = false;
-            dy0 = b > 0 ? 1 : -1;
-            dx0 = __float2int_rn(__fdiv_rn(__fmul_rn(a, 65536.f), fabsf(b)));
-            x0 = (x0 << 16) + 32768;
-        }
-        int end_step[2], end_x[2], end_y[2];
-        for (int k = 0; k < 2; ++k) {
-            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-            int gap = 0, last_lit = 0;
-            bool done = false;
-            for (int s0 = 0; !done; s0 += 64) {
-                const int s = s0 + lane;
-                const int X = x0 + dx * s, Y = y0 + dy * s;
-                const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
-                const bool inside = j1 >= 0 && j1 < P.W && i1 >= 0 && i1 < P.H;
-                bool lit = false;
-                if (inside) lit = (ld_l2(&work[(size_t)i1 * P.WW + (j1 >> 6)]) >> (j1 & 63)) & 1;
-                const u64 mi = __ballot(inside), ml = __ballot(lit);
-                for (int bb = 0; bb < 64; ++bb) {
-                    if (!((mi >> bb) & 1)) { done = true; break; }
-                    if ((ml >> bb) & 1) {
-                        gap = 0;
-                        last_lit = s0 + bb;
-                    } else if (++gap > line_gap) {
-                        done = true;
-                        break;
-                    }
-                }
-            }
-            end_step[k] = last_lit;
-            const int X = x0 + dx * last_lit, Y = y0 + dy * last_lit;
-            end_x[k] = xflag ? X : X >> 16;
-            end_y[k] = xflag ? Y >> 16 : Y;
-        }
-        const bool good = abs(end_x[1] - end_x[0]) >= P.line_length || abs(end_y[1] - end_y[0]) >= P.line_length;
-        for (int k = 0; k < 2; ++k) {
-            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-            for (int s0 = 0; s0 <= end_step[k]; s0 += 64) {
-                const int s = s0 + lane;
-                bool was = false;
-                if (s <= end_step[k]) {
-                    const int X = x0 + dx * s, Y = y0 + dy * s;
-                    const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
-                    const unsigned bit = 1u << (j1 & 31);
-                    const unsigned old = atomicAnd(&work32[((size_t)i1 * P.WW + (j1 >> 6)) * 2 + ((j1 >> 5) & 1)], ~bit);
-                    was = old & bit;
-                }
-                u64 ms = __ballot(was);
-                if (good) {
-                    while (ms) {
-                        const int bb = __builtin_ctzll(ms);
-                        ms &= ms - 1;
-                        const int sb = s0 + bb;
-                        const int X = x0 + dx * sb, Y = y0 + dy * sb;
-                        const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            const int n = lane + 64 * q;
-                            if (n < NUM_ANGLE) atomicSub(&acc[(size_t)n * P.numrho + rho_bin(j1, i1, tc[q], ts[q], P.half)], 1);
-                        }
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (good) {
-            if (found < MAX_LINES && lane == 0) {
-                int* o = P.out_lines + ((size_t)i * MAX_LINES + found) * 4;
-                o[0] = end_x[0]; o[1] = end_y[0]; o[2] = end_x[1]; o[3] = end_y[1];
-            }
-            ++found;
-        }
+        if (!work_bit(C, x, y)) continue;
+        int old[3];
+        vote_issue(C, x, y, old);
+        const unsigned key = vote_key(C, old);
+        if (!__any(key_value(key) >= C.P.threshold)) continue;
+        const unsigned best = __builtin_amdgcn_wave_reduce_max_u32(key, 0);
+        ppht_line(C, x, y, 255 - (int)(best & 0xFF));
     }
-    if (lane == 0) P.out_nraw[i] = found;
 }
 
+// Group-speculative replay (list in LDS).  The visiting order depends only on the RNG and the list length, never
+// on pixel data, so PPHT_G consecutive draws are resolved at once: lane k takes draw k (index = rnd_k % (count-k)),
+// the swap-removes are applied together when they cannot interact (no index inside the tail window, no repeated
+// index; otherwise one ordinary serial draw is made), the working-mask bits of the G points are fetched in one
+// round trip and the votes of all live points are issued back to back (same-address atomics complete in issue
+// order, so each point's returned counts are exactly the sequential ones).  If some point reaches the threshold,
+// the votes of the points after it are taken back, its line is processed, and the rest of the group is re-examined
+// against the updated mask -- the result is identical to the one-point-at-a-time loop.
+#define PPHT_G 16
+__device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
+    const int lane = C.lane;
+    u64 state = 0xFFFFFFFFFFFFFFFFull;
+    int count = N;
+    while (count > 0) {
+        int gn = count < PPHT_G ? count : PPHT_G;
+        u64 st = state, my_state = 0;
+        unsigned my_rnd = 0;
+#pragma unroll
+        for (int k = 0; k < PPHT_G; ++k) {
+            if (k < gn) {
+                st = rng_step(st);
+                if (lane == k) {
+                    my_rnd = (unsigned)st;
+                    my_state = st;
+                }
+            }
+        }
+        const bool in_grp = lane < gn;
+        const int my_idx = in_grp ? (int)(my_rnd % (unsigned)(count - lane)) : -1 - lane;
+        // Largest prefix g of the draws whose swap-removes cannot interact: every index must lie below the tail
+        // window [count-g, count) (i.e. its distance from the end is >= g) and must not repeat an earlier one.
+        int lim = in_grp ? count - 1 - my_idx : PPHT_G;
+#pragma unroll
+        for (int j = 0; j < PPHT_G - 1; ++j) {
+            const int v = __builtin_amdgcn_readlane(my_idx, j);
+            if (in_grp && j < lane && v == my_idx) lim = lane < lim ? lane : lim;
+        }
+        const int g = min(gn, (int)__builtin_amdgcn_wave_reduce_min_u32((unsigned)lim, 0));
+        unsigned my_pt = 0;
+        if (g == 0) {  // the first draw removes the last element itself: ordinary serial step
+            state = rng_step(state);
+            const int idx = (int)((unsigned)state % (unsigned)count);
+            my_pt = list[idx];
+            const unsigned last = list[count - 1];
+            if (lane == 0) list[idx] = last;
+            gn = 1;
+        } else {
+            const bool mine = lane < g;
+            unsigned tail = 0;
+            if (mine) {
+                my_pt = list[my_idx];
+                tail = list[count - 1 - lane];
+            }
+            if (mine) list[my_idx] = tail;
+            gn = g;
+#pragma unroll
+            for (int k = 0; k < PPHT_G; ++k)
+                if (k == g - 1)
+                    state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), k) << 32) |
+                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, k);
+        }
+        count -= gn;
+        ++C.groups;
+        u64 pending = (1ull << gn) - 1;
+        const int px = my_pt & 0xFFFF, py = my_pt >> 16;
+        while (pending) {
+            bool alive = false;
+            if ((pending >> lane) & 1) alive = work_bit(C, px, py);
+            const u64 am = __ballot(alive);
+            if (!am) break;
+            int old[PPHT_G][3];
+#pragma unroll
+            for (int k = 0; k < PPHT_G; ++k) {
+                if ((am >> k) & 1) {
+                    const unsigned pt = __builtin_amdgcn_readlane(my_pt, k);
+                    vote_issue(C, pt & 0xFFFF, pt >> 16, old[k]);
+                }
+            }
+            int trig = -1;
+            unsigned trig_key = 0;
+#pragma unroll
+            for (int k = 0; k < PPHT_G; ++k) {
+                if (trig < 0 && ((am >> k) & 1)) {
+                    const unsigned key = vote_key(C, old[k]);
+                    if (__any(key_value(key) >= C.P.threshold)) {
+                        trig = k;
+                        trig_key = key;
+                    }
+                }
+            }
+            if (trig < 0) break;
+            // points after the trigger voted too early: take those votes back, they are re-examined below
+            const u64 later = am & ~((2ull << trig) - 1);
+#pragma unroll
+            for (int k = 1; k < PPHT_G; ++k) {
+                if ((later >> k) & 1) {
+                    const unsigned pt = __builtin_amdgcn_readlane(my_pt, k);
+                    unvote(C, pt & 0xFFFF, pt >> 16);
+                }
+            }
+            const unsigned best = __builtin_amdgcn_wave_reduce_max_u32(trig_key, 0);
+            unsigned tp = 0;
+#pragma unroll
+            for (int k = 0; k < PPHT_G; ++k)
+                if (k == trig) tp = __builtin_amdgcn_readlane(my_pt, k);
+            ppht_line(C, tp & 0xFFFF, tp >> 16, 255 - (int)(best & 0xFF));
+            pending = later;
+        }
+    }
+}
+
+#define HOUGH_LDS_CELLS 61440  // 16-bit accumulator cells in LDS (120 KiB)
 __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     __shared__ unsigned lds_list[HOUGH_LDS_PTS];
+    __shared__ unsigned lds_cells[HOUGH_LDS_CELLS / 2];
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = P.litcount[i];
+    const long long c0 = clock64();
     // maxLineGap (Detector.py:342-344) -> cvRound
     double gap = P.max_gap;
     if (!P.fixed_gap) {
@@ -580,6 +859,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     unsigned* nzo = P.nz_orig + (size_t)i * P.nz_cap;
     // row-major list of set pixels: wave scan over the per-row counts, rows emit their own bits
     int total = 0;
+    int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;  // bounding box of the lit pixels
     for (int yb = 0; yb < P.H; yb += 64) {
         const int y = yb + lane;
         const int c = y < P.H ? P.rowcount[i * P.H + y] : 0;
@@ -596,33 +876,97 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
                     const int bpos = __builtin_ctzll(word);
                     word &= word - 1;
                     nzo[pos++] = ((unsigned)y << 16) | (unsigned)(w * 64 + bpos);
+                    bx0 = min(bx0, w * 64 + bpos);
+                    bx1 = max(bx1, w * 64 + bpos);
                 }
             }
+            by0 = min(by0, y);
+            by1 = max(by1, y);
         }
         total += __shfl(incl, 63);
     }
     __threadfence_block();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long c1 = clock64();
+    Ppht C{P, P.work_bits + (size_t)i * words, (unsigned*)(P.work_bits + (size_t)i * words),
+           P.accum + (size_t)i * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0,
+           lds_cells, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, false};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = lane + 64 * q;
+        C.tc[q] = n < NUM_ANGLE ? P.trig[2 * n] : 0.f;
+        C.ts[q] = n < NUM_ANGLE ? P.trig[2 * n + 1] : 0.f;
+    }
+    // Accumulator windows: rho is monotone in x and in y for a fixed angle (rounded float products and sum), so over
+    // the bounding box its extremes are at the corners.  If all 180 windows fit, every vote of every pixel is an LDS
+    // atomic; otherwise the whole frame uses the global accumulator.
+    if (!P.no_lds_acc && N <= HOUGH_LDS_PTS) {
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, o));
+            bx1 = max(bx1, __shfl_xor(bx1, o));
+            by0 = min(by0, __shfl_xor(by0, o));
+            by1 = max(by1, __shfl_xor(by1, o));
+        }
+        int size[3], base = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = lane + 64 * q;
+            size[q] = 0;
+            if (n < NUM_ANGLE) {
+                const int r00 = rho_bin(bx0, by0, C.tc[q], C.ts[q], P.half), r10 = rho_bin(bx1, by0, C.tc[q], C.ts[q], P.half);
+                const int r01 = rho_bin(bx0, by1, C.tc[q], C.ts[q], P.half), r11 = rho_bin(bx1, by1, C.tc[q], C.ts[q], P.half);
+                C.lo[q] = min(min(r00, r10), min(r01, r11));
+                C.hi[q] = max(max(r00, r10), max(r01, r11));
+                size[q] = C.hi[q] - C.lo[q] + 1;
+            }
+            int incl = size[q];
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tt = __shfl_up(incl, d);
+                if (lane >= d) incl += tt;
+            }
+            C.off[q] = base + incl - size[q];
+            base += __shfl(incl, 63);
+        }
+        if (base <= HOUGH_LDS_CELLS) {
+            for (int p = lane; p < (base + 1) / 2; p += 64) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { C.lo[q] = 0; C.hi[q] = -1; }
+        }
+    }
     if (N <= HOUGH_LDS_PTS) {
         for (int p = lane; p < N; p += 64) lds_list[p] = ld_l2(&nzo[p]);
         __syncthreads();
-        ppht_run<true>(P, i, N, line_gap, lds_list);
+        if (P.serial)
+            ppht_serial<true>(C, N, lds_list);
+        else
+            ppht_grouped(C, N, lds_list);
     } else {
         unsigned* nzw = P.nz_work + (size_t)i * P.nz_cap;
         for (int p = lane; p < N; p += 64) st_l2(&nzw[p], ld_l2(&nzo[p]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ppht_run<false>(P, i, N, line_gap, nzw);
+        ppht_serial<false>(C, N, nzw);
     }
-    // leave the accumulator all-zero: every cell ever touched belongs to some point of the original list
-    int* acc = P.accum + (size_t)i * NUM_ANGLE * P.numrho;
-    for (int p = 0; p < N; ++p) {
-        const unsigned pt = ld_l2(&nzo[p]);
-        const int x = pt & 0xFFFF, y = pt >> 16;
+    if (lane == 0) P.out_nraw[i] = C.found;
+    const long long c2 = clock64();
+    // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
+    if (__any(C.touched_global)) {
+        int* acc = P.accum + (size_t)i * NUM_ANGLE * P.numrho;
+        for (int p = 0; p < N; ++p) {
+            const unsigned pt = ld_l2(&nzo[p]);
+            const int x = pt & 0xFFFF, y = pt >> 16;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int n = lane + 64 * q;
-            if (n < NUM_ANGLE)
-                acc[(size_t)n * P.numrho + rho_bin(x, y, P.trig[2 * n], P.trig[2 * n + 1], P.half)] = 0;
+            for (int q = 0; q < 3; ++q) {
+                const int n = lane + 64 * q;
+                if (n < NUM_ANGLE) {
+                    const int r = rho_bin(x, y, C.tc[q], C.ts[q], P.half);
+                    if (r < C.lo[q] || r > C.hi[q]) acc[(size_t)n * P.numrho + r] = 0;
+                }
+            }
         }
+    }
+    if (P.dbg && lane == 0) {
+        long long* d = P.dbg + (size_t)i * 8;
+        d[0] = N; d[1] = c1 - c0; d[2] = c2 - c1; d[3] = clock64() - c2; d[4] = C.found; d[5] = C.groups; d[6] = C.lines; d[7] = c0;
     }
 }

@@ -226,3 +226,68 @@ def test_api_errors():
     det.close()
     with pytest.raises(ValueError):
         M3Detector(1, 300, mask, 10, binary_cfg(), None)
+
+
+@pytest.mark.parametrize("n", [2, 7, 12, 17, 25, 32, 40])
+def test_m3_window_sizes_time_blocked_and_generic(n):
+    """Every register-window instantiation family (2..32) and the generic n-reads kernel (n > 32), in batched
+    passes long enough to be split into several time chunks, with a width that leaves padding lanes."""
+    shape = (40, 150)
+    mask = np.ones(shape, np.uint8)
+    frames = busy_frames(100 + n, 3 * n + 20, shape)
+    total = run_pair(frames, n, mask, binary_cfg(adaptive=False, init_value=9), batch=len(frames), max_batch=len(frames))
+    assert total > 0
+    s = SkyStream(*shape, n, speed=4, streak_period=9, streak_life=6)
+    run_pair([s.next() for _ in range(2 * n + 24)], n, mask, binary_cfg(), batch=2 * n + 24, max_batch=2 * n + 24)
+
+
+def test_m3_generic_kernel_equals_time_blocked(monkeypatch):
+    shape, n = (64, 200), 8
+    mask = np.ones(shape, np.uint8)
+    frames = np.stack(busy_frames(55, 50, shape))
+    cfg = binary_cfg(adaptive=False, init_value=9)
+    a = M3Detector(1, n, mask, 10, cfg, None)
+    ra, ia = a.detect_batch(frames)
+    da = a.dst
+    a.close()
+    monkeypatch.setenv("MDH_FORCE_GENERIC", "1")
+    b = M3Detector(1, n, mask, 10, cfg, None)
+    rb, ib = b.detect_batch(frames)
+    assert np.array_equal(da, b.dst)
+    b.close()
+    assert np.array_equal(ia, ib)
+    for (l1, p1), (l2, p2) in zip(ra, rb):
+        assert np.array_equal(np.asarray(l1).reshape(-1, 4), np.asarray(l2).reshape(-1, 4)) and np.array_equal(p1, p2)
+
+
+def test_hough_serial_replay_equals_grouped(monkeypatch):
+    """MDH_HOUGH_SERIAL=1 selects the one-point-at-a-time PPHT replay; both must equal the oracle."""
+    monkeypatch.setenv("MDH_HOUGH_SERIAL", "1")
+    shape, n = (135, 240), 8
+    mask = np.ones(shape, np.uint8)
+    total = run_pair(busy_frames(15, 30, shape), n, mask, binary_cfg(adaptive=False, init_value=9), batch=30, max_batch=30)
+    assert total > 0
+
+
+def test_hough_global_accumulator_path(monkeypatch):
+    """MDH_HOUGH_GLOBAL_ACC=1 keeps every accumulator cell in global memory (the path taken when the rho windows
+    of the lit pixels' bounding box do not fit in LDS); it must equal the oracle as well."""
+    monkeypatch.setenv("MDH_HOUGH_GLOBAL_ACC", "1")
+    shape, n = (135, 240), 8
+    mask = np.ones(shape, np.uint8)
+    total = run_pair(busy_frames(16, 24, shape), n, mask, binary_cfg(adaptive=False, init_value=9), batch=24, max_batch=24)
+    assert total > 0
+
+
+def test_hough_windows_too_big_for_lds_fall_back():
+    """Lit pixels spread over a 1920x1080 frame: the 180 rho windows of their bounding box exceed the LDS budget."""
+    shape, n = (1080, 1920), 2
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=5, dy_mask=False)
+    base = np.full(shape, 10, np.uint8)
+    img = base.copy()
+    img[100:103, 50:400] = 200
+    img[900:903, 1500:1900] = 200
+    for k in range(300):
+        img[300 + k:303 + k, 700 + k:703 + k] = 220
+    run_pair([base, img, base], n, mask, cfg, check_act=False)
