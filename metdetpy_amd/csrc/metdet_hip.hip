@@ -60,11 +60,12 @@ struct mdh_ctx {
     const uint8_t** h_ptrtab = nullptr;
     NoiseJob *d_jobs = nullptr, *h_jobs = nullptr;
     long long* d_sums = nullptr;
-    ScalarState* d_state = nullptr;
+    ScalarState *d_state = nullptr, *d_jobres = nullptr;
     FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
     int* d_thr = nullptr;
-    u64 *d_bbits = nullptr, *d_act = nullptr, *d_alive = nullptr, *d_dst = nullptr, *d_work = nullptr, *d_planes = nullptr;
+    u64 *d_bbits = nullptr, *d_act = nullptr, *d_dst = nullptr, *d_work = nullptr, *d_planes = nullptr;
     int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr;
+    unsigned char* d_bandflag = nullptr;  // [K][bands][WW]: the (band, word column) block of b holds a set bit
     int* d_accum = nullptr;
     unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
     int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
@@ -79,6 +80,8 @@ struct mdh_ctx {
     int64_t last_t_base = 0;
     // profiling
     bool force_generic = false;  // MDH_FORCE_GENERIC=1: use the n-reads kernel (A/B and parity testing)
+    bool force_bytes = false;    // MDH_FORCE_BYTES=1: never use the wide-load window kernel
+    bool force_ppl8 = false;     // MDH_FORCE_PPL8=1: 8 pixels per lane even when 16 would do
     bool hough_serial = false;   // MDH_HOUGH_SERIAL=1: one-point-at-a-time PPHT replay
     bool hough_global_acc = false;  // MDH_HOUGH_GLOBAL_ACC=1: never use the LDS accumulator windows
     bool prof = false;
@@ -108,10 +111,10 @@ static void free_all(mdh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* dev[] = {c->d_ring,  c->d_zero,     c->d_ptrtab,   c->d_jobs,  c->d_sums,    c->d_state,   c->d_fscal, c->d_thr,
-                   c->d_bbits, c->d_act,      c->d_alive,    c->d_dst,   c->d_work,    c->d_planes,  c->d_rowcount,
+    void* dev[] = {c->d_ring,  c->d_zero,     c->d_ptrtab,   c->d_jobs,  c->d_sums,    c->d_state, c->d_jobres,   c->d_fscal, c->d_thr,
+                   c->d_bbits, c->d_act,      c->d_dst,   c->d_work,    c->d_planes,  c->d_rowcount,
                    c->d_litcount, c->d_accum, c->d_nz_orig,  c->d_nz_work, c->d_lines, c->d_nraw,    c->d_gap,   c->d_trig,
-                   c->d_expand, c->d_hdbg};
+                   c->d_expand, c->d_hdbg, c->d_bandflag};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {c->h_ptrtab, c->h_jobs, c->h_fscal, c->h_litcount, c->h_lines, c->h_nraw, c->h_gap};
@@ -139,16 +142,17 @@ static int create_impl(mdh_ctx* c) {
     TRY(host_alloc(c->h_jobs, K));
     TRY(dev_alloc(c->d_sums, 2 * K));
     TRY(dev_alloc(c->d_state, 1));
+    TRY(dev_alloc(c->d_jobres, K + 1));
     TRY(dev_alloc(c->d_fscal, K));
     TRY(host_alloc(c->h_fscal, K));
     TRY(dev_alloc(c->d_thr, K));
     TRY(dev_alloc(c->d_bbits, K * words));
     TRY(dev_alloc(c->d_act, (size_t)c->R * words));
-    TRY(dev_alloc(c->d_alive, K * words));
     TRY(dev_alloc(c->d_dst, K * words));
     TRY(dev_alloc(c->d_work, K * words));
     if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
     TRY(dev_alloc(c->d_rowcount, K * c->H));
+    TRY(dev_alloc(c->d_bandflag, K * (size_t)((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW));
     TRY(dev_alloc(c->d_litcount, K));
     TRY(host_alloc(c->h_litcount, K));
     TRY(dev_alloc(c->d_accum, K * (size_t)NUM_ANGLE * c->numrho));
@@ -235,6 +239,10 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->numrho = (W + H) * 2 + 1;
     const char* fg = getenv("MDH_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    const char* fb = getenv("MDH_FORCE_BYTES");
+    c->force_bytes = fb && fb[0] == '1';
+    const char* f8 = getenv("MDH_FORCE_PPL8");
+    c->force_ppl8 = f8 && f8[0] == '1';
     const char* hs = getenv("MDH_HOUGH_SERIAL");
     c->hough_serial = hs && hs[0] == '1';
     const char* hg = getenv("MDH_HOUGH_GLOBAL_ACC");
@@ -338,15 +346,46 @@ static void launch_tb(mdh_ctx* c, const PassGeom& g) {
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_tb<N>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream,
-                       c->d_ptrtab, c->d_thr, c->d_bbits, g, Tc);
+                       c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc);
+}
+
+template <int N, int PPL>
+static void launch_wide(mdh_ctx* c, const PassGeom& g) {
+    const int words = (int)c->words;
+    const int waves = (words + PPL - 1) / PPL;
+    int nchunks = (4096 + waves - 1) / waves;
+    nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
+    const int Tc = (g.K + nchunks - 1) / nchunks;
+    nchunks = (g.K + Tc - 1) / Tc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream,
+                       c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc);
 }
 
 static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
     const int words = (int)c->words;
     if (c->force_generic) {
         hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, g.K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr,
-                           c->d_bbits, g);
+                           c->d_bbits, c->d_bandflag, g);
         return;
+    }
+    // wide loads need contiguous 64-byte words (W % 64 == 0) and aligned frame bases
+    unsigned align = 16;
+    if (c->W % 64 != 0 || c->force_bytes) align = 1;
+    for (int e = 0; e < c->n - 1 + g.K && align > 1; ++e)
+        while (align > 1 && ((uintptr_t)c->h_ptrtab[e] & (align - 1))) align >>= 1;
+    if (align >= 16 && g.n >= 2 && g.n <= 8 && !c->force_ppl8) {
+        switch (g.n) {
+#define W16_CASE(N) case N: launch_wide<N, 16>(c, g); return;
+            W16_CASE(2) W16_CASE(3) W16_CASE(4) W16_CASE(5) W16_CASE(6) W16_CASE(7) W16_CASE(8)
+#undef W16_CASE
+        }
+    }
+    if (align >= 8 && g.n >= 2 && g.n <= 16) {
+        switch (g.n) {
+#define W8_CASE(N) case N: launch_wide<N, 8>(c, g); return;
+            W8_CASE(2) W8_CASE(3) W8_CASE(4) W8_CASE(5) W8_CASE(6) W8_CASE(7) W8_CASE(8) W8_CASE(9) W8_CASE(10) W8_CASE(11) W8_CASE(12) W8_CASE(13) W8_CASE(14) W8_CASE(15) W8_CASE(16)
+#undef W8_CASE
+        }
     }
     switch (g.n) {
 #define TB_CASE(N) case N: launch_tb<N>(c, g); break;
@@ -357,7 +396,7 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
 #undef TB_CASE
         default:
             hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, g.K), dim3(256), 0, c->stream, c->d_ptrtab,
-                               c->d_thr, c->d_bbits, g);
+                               c->d_thr, c->d_bbits, c->d_bandflag, g);
     }
 }
 
@@ -396,15 +435,23 @@ static int run_noise(mdh_ctx* c, int K) {
     if (nj) {
         HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->stream));
-        const int npx = rh * rw;
-        dim3 grid(std::max(1, std::min((npx + 255) / 256, 256)), nj);
+        bool aligned4 = (c->W % 4) == 0;
+        for (int e = 0; e < c->n - 1 + K && aligned4; ++e) aligned4 = ((uintptr_t)c->h_ptrtab[e] & 3) == 0;
         span_begin(c, KK_NOISE_SUMS);
-        hipLaunchKernelGGL(k_noise_sums, grid, dim3(256), 0, c->stream, c->d_ptrtab, c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
+        if (aligned4) {
+            const int xa = r[1] & ~3;
+            const int nx4 = (r[1] + rw - xa + 3) >> 2;
+            hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->stream, c->d_ptrtab,
+                               c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
+        } else {
+            hipLaunchKernelGGL(k_noise_sums_bytes, dim3((rh * rw + 255) / 256, nj), dim3(256), 0, c->stream, c->d_ptrtab,
+                               c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
+        }
         span_end(c);
     }
     span_begin(c, KK_NOISE_FINAL);
-    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(64), 0, c->stream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_fscal,
-                       c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->stream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
+                       c->d_fscal, c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
     span_end(c);
     HIPCHK(hipGetLastError());
     return MDH_OK;
@@ -417,28 +464,25 @@ static int run_detect(mdh_ctx* c, int K) {
     const int words = (int)c->words;
     HIPCHK(hipMemsetAsync(c->d_rowcount, 0, sizeof(int) * (size_t)K * c->H, c->stream));
     HIPCHK(hipMemsetAsync(c->d_litcount, 0, sizeof(int) * K, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, (size_t)K * ((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW, c->stream));
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR);
         launch_stack_threshold(c, g);
         span_end(c);
         const int nb = (c->H + MORPH_RB - 1) / MORPH_RB;
         span_begin(c, KK_MORPH);
-        hipLaunchKernelGGL(k_morph_close, dim3((nb * c->WW + 255) / 256, K), dim3(256), 0, c->stream, c->d_bbits, c->d_act, g);
+        hipLaunchKernelGGL(k_morph_close, dim3((nb * c->WW + 255) / 256, K), dim3(256), 0, c->stream, c->d_bbits, c->d_bandflag,
+                           c->d_act, g);
         span_end(c);
-        if (c->cfg.dy_mask) {
-            span_begin(c, KK_DY_ALIVE);
-            hipLaunchKernelGGL(k_dy_alive, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_act, c->d_alive, g);
-            span_end(c);
-        }
         span_begin(c, KK_DY_APPLY);
-        hipLaunchKernelGGL(k_dy_apply, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_act, c->d_alive, c->d_dst,
-                           c->d_work, c->d_rowcount, c->d_litcount, g, c->cfg.dy_mask);
+        hipLaunchKernelGGL(k_dy_apply, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_act, c->d_dst,
+                           c->d_rowcount, c->d_litcount, g, c->cfg.dy_mask);
         span_end(c);
     } else {
         span_begin(c, KK_CLASSIC);
         hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, c->d_planes, g);
         hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_planes, c->d_dst,
-                           c->d_work, c->d_rowcount, c->d_litcount, g);
+                           c->d_rowcount, c->d_litcount, g);
         span_end(c);
     }
     HoughParams P;

@@ -18,6 +18,7 @@ typedef unsigned __int128 u128;
 #define MDH_WAVE 64
 #define NUM_ANGLE 180
 #define MAX_LINES 512
+#define MORPH_RB 8  // rows per band of the morphology kernel (and granularity of the "band has set bits" flags)
 
 // ------------------------------------------------------------------------------------------------
 // Parameters shared by the pixel-stage kernels.
@@ -47,16 +48,79 @@ struct NoiseJob {
 
 __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __restrict__ ptrtab, const NoiseJob* __restrict__ jobs,
                                                     long long* __restrict__ sums, PassGeom g, int r0, int c0, int rh, int rw) {
+    // One thread = 4 horizontally adjacent pixels (one aligned dword per frame) of one ROI row.
     const NoiseJob job = jobs[blockIdx.y];
-    const int npx = rh * rw;
     const int k = job.k_used;
+    const int xa = c0 & ~3;                      // first aligned column
+    const int nx4 = (c0 + rw - xa + 3) >> 2;     // dwords per ROI row
     long long s1 = 0, s2 = 0;
     // frames of the window of pass-frame i are table entries i .. i+n-1; the last k_used of them end at i+n-1
     const int e_last = job.frame + g.n - 1;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += gridDim.x * blockDim.x) {
-        const int y = r0 + p / rw, x = c0 + p % rw;
-        const size_t off = (size_t)y * g.W + x;
+    const int frame_bytes = g.H * g.W;
+    for (int tid = blockIdx.x * blockDim.x + threadIdx.x; tid < rh * nx4; tid += gridDim.x * blockDim.x) {
+        const int row = tid / nx4, x4 = tid - row * nx4;
+        const int x = xa + 4 * x4;
+        const int off = (r0 + row) * g.W + x;
         // one sweep: sum x and sum x^2, then  sum (x-m) = sx - k m,  sum (x-m)^2 = sxx - 2 m sx + k m^2  (exact)
+        int sx[4] = {0, 0, 0, 0}, sxx[4] = {0, 0, 0, 0};
+        for (int j0 = 0; j0 < k; j0 += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // 8 independent loads in flight; slots past k read offset "far" -> 0
+                const int e = e_last - min(j0 + j, k - 1);
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, j0 + j < k ? off : 0x7FFFFFF0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int pv = (v[j] >> (8 * b)) & 0xFF;
+                    sx[b] += pv;
+                    sxx[b] += pv * pv;
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = x + b;
+            if (xx >= c0 && xx < c0 + rw) {
+                const int m = (sx[b] / k) & 0xFF;
+                s1 += sx[b] - k * m;
+                s2 += sxx[b] - 2 * m * sx[b] + k * m * m;
+            }
+        }
+    }
+    // wave reduction, block reduction through LDS, then ONE atomic pair per block (same-address atomics serialise)
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    __shared__ long long part[8];
+    if ((threadIdx.x & 63) == 0) {
+        part[(threadIdx.x >> 6) * 2] = s1;
+        part[(threadIdx.x >> 6) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t1 = part[0] + part[2] + part[4] + part[6], t2 = part[1] + part[3] + part[5] + part[7];
+        atomicAdd((unsigned long long*)&sums[2 * blockIdx.y + 0], (unsigned long long)t1);
+        atomicAdd((unsigned long long*)&sums[2 * blockIdx.y + 1], (unsigned long long)t2);
+    }
+}
+
+// Same sums with one byte load per pixel: used when rows or frame bases are not 4-byte aligned.
+__global__ void __launch_bounds__(256) k_noise_sums_bytes(const uint8_t* const* __restrict__ ptrtab,
+                                                          const NoiseJob* __restrict__ jobs, long long* __restrict__ sums,
+                                                          PassGeom g, int r0, int c0, int rh, int rw) {
+    const NoiseJob job = jobs[blockIdx.y];
+    const int k = job.k_used;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    long long s1 = 0, s2 = 0;
+    const int e_last = job.frame + g.n - 1;
+    if (tid < rh * rw) {
+        const int row = tid / rw, col = tid - row * rw;
+        const size_t off = (size_t)(r0 + row) * g.W + c0 + col;
         int sx = 0, sxx = 0;
         for (int j = 0; j < k; ++j) {
             const int v = ptrtab[e_last - j][off];
@@ -64,15 +128,14 @@ __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __rest
             sxx += v * v;
         }
         const int m = (sx / k) & 0xFF;
-        s1 += sx - k * m;
-        s2 += sxx - 2 * m * sx + k * m * m;
+        s1 = sx - k * m;
+        s2 = sxx - 2 * m * sx + k * m * m;
     }
-    // wave reduction, then one atomic pair per wave
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_xor(s1, o);
         s2 += __shfl_xor(s2, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && (s1 | s2)) {
         atomicAdd((unsigned long long*)&sums[2 * blockIdx.y + 0], (unsigned long long)s1);
         atomicAdd((unsigned long long*)&sums[2 * blockIdx.y + 1], (unsigned long long)s2);
     }
@@ -91,34 +154,48 @@ struct FrameScalars {
     int thr, pad;
 };
 
-// a3: EMA update (utils.py:352-358) and T = round(a*snr^2 + b) (Detector.py:227-229), one thread, frame order.
-__global__ void k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs, const long long* __restrict__ sums,
-                                 ScalarState* __restrict__ st, FrameScalars* __restrict__ out, int* __restrict__ thr_tab,
-                                 int K, double roi_px, int adaptive, double coef_a, double coef_b) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    ScalarState s = *st;
-    int j = 0;
-    for (int i = 0; i < K; ++i) {
-        if (j < njobs && jobs[j].frame == i) {
+// a3: EMA update (utils.py:352-358) and T = round(a*snr^2 + b) (Detector.py:227-229).  The chain over the due
+// frames is sequential (one thread); the per-frame tables are then filled by the whole block.
+__global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
+                                                        const long long* __restrict__ sums, ScalarState* __restrict__ st,
+                                                        ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
+                                                        int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
+                                                        double coef_a, double coef_b) {
+    // jobres[0] = state on entry, jobres[j+1] = state after job j
+    if (threadIdx.x == 0) {
+        ScalarState s = *st;
+        jobres[0] = s;
+        for (int j = 0; j < njobs; ++j) {
             const double cnt = (double)jobs[j].k_used * roi_px;
             const double mu = (double)sums[2 * j] / cnt;
             double var = (double)sums[2 * j + 1] / cnt - mu * mu;
             if (var < 0) var = 0;
             s.sigma = sqrt(var);
             s.ema_v = jobs[j].m_cur * s.ema_v + jobs[j].one_minus * s.sigma;
-            ++j;
+            if (adaptive && s.ema_v != 0) {
+                s.thr_f = coef_a * (s.ema_v * s.ema_v) + coef_b;
+                s.thr = (int)rint(s.thr_f);  // Python round(): half to even
+            }
+            jobres[j + 1] = s;
         }
-        if (adaptive && s.ema_v != 0) {
-            s.thr_f = coef_a * (s.ema_v * s.ema_v) + coef_b;
-            s.thr = (int)rint(s.thr_f);  // Python round(): half to even
+        *st = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        // number of jobs whose frame is <= i (jobs are sorted by frame)
+        int lo = 0, hi = njobs;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (jobs[mid].frame <= i) lo = mid + 1; else hi = mid;
         }
+        const ScalarState s = jobres[lo];
         thr_tab[i] = s.thr;
         out[i].thr_f = s.thr_f;
         out[i].snr = s.ema_v;
         out[i].sigma = s.sigma;
         out[i].thr = s.thr;
     }
-    *st = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -128,7 +205,7 @@ __global__ void k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs, c
 // Generic-n version: one lane per pixel, n byte loads per pixel (the "algorithmic" (n+1) reads of SURVEY 8d).
 __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* const* __restrict__ ptrtab,
                                                                  const int* __restrict__ thr_tab, u64* __restrict__ bbits,
-                                                                 PassGeom g) {
+                                                                 unsigned char* __restrict__ bandflag, PassGeom g) {
     const int i = blockIdx.y;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -151,7 +228,10 @@ __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* 
     const int c = mx > T ? mx - T : 0;
     const bool b = valid && (sum < c * len);
     const u64 m = __ballot(b);
-    if (lane == 0) bbits[((size_t)i * g.H + y) * g.WW + w] = m;
+    if (lane == 0) {
+        bbits[((size_t)i * g.H + y) * g.WW + w] = m;
+        if (m) bandflag[((size_t)i * ((g.H + MORPH_RB - 1) / MORPH_RB) + y / MORPH_RB) * g.WW + w] = 1;
+    }
 }
 
 // Time-blocked version (the fast path): one wave owns 256 pixels (4 bit words) and walks through a run of
@@ -163,7 +243,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <int N>
 __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const* __restrict__ ptrtab,
                                                             const int* __restrict__ thr_tab, u64* __restrict__ bbits,
-                                                            PassGeom g, int Tc) {
+                                                            unsigned char* __restrict__ bandflag, PassGeom g, int Tc) {
     constexpr int U = N < 8 ? N : 8;  // frames fetched per load burst
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
@@ -172,6 +252,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
     const int i0 = blockIdx.y * Tc;
     const int steps = min(Tc, g.K - i0);
     if (steps <= 0) return;
+    const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
     // Frames are read through raw buffer descriptors (uniform base in SGPRs + 32-bit lane offset, no 64-bit
     // address math; offsets past the frame return 0, which is how padding lanes are handled).
     int off[4];
@@ -250,10 +331,142 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
                         if (lane < 4 && gw0 + lane < words) {
                             const u64 v = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
                             bbits[(size_t)i * words + gw0 + lane] = v;
+                            if (v) bandflag[(size_t)i * nbands * g.WW + (size_t)((gw0 + lane) / g.WW / MORPH_RB) * g.WW + (gw0 + lane) % g.WW] = 1;  // rare
                         }
                     }
                 }
             }
+        }
+    }
+}
+
+// Wide-load variant of the time-blocked kernel for frames whose width is a multiple of 64 (bit words are then
+// contiguous runs of 64 bytes) and whose frame bases are PPL-byte aligned: a lane owns PPL = 16 (or 8) CONSECUTIVE
+// pixels fetched with one 128-bit (64-bit) buffer load per frame, i.e. 16x (8x) fewer load instructions than the
+// byte kernel, which is issue-bound on its byte loads.  Pixel r and pixel r + PPL/2 share a packed u16 register
+// (one v_perm_b32 each), so the per-lane result bits come out as two contiguous runs.
+template <int N, int PPL>
+__global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
+                                                              const int* __restrict__ thr_tab, u64* __restrict__ bbits,
+                                                              unsigned char* __restrict__ bandflag, PassGeom g, int Tc) {
+    constexpr int RW = PPL / 2;   // packed pair registers per window entry
+    constexpr int DW = PPL / 4;   // dwords per load
+    constexpr int LPW = 64 / PPL; // lanes per 64-pixel word
+    constexpr int U = PPL == 16 ? (N < 4 ? N : 4) : (N < 8 ? N : 8);
+    typedef unsigned dvec __attribute__((ext_vector_type(DW)));
+    const int lane = threadIdx.x & 63;
+    const int words = g.H * g.WW;
+    const int gw0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPL;  // a wave covers PPL words
+    if (gw0 >= words) return;
+    const int i0 = blockIdx.y * Tc;
+    const int steps = min(Tc, g.K - i0);
+    if (steps <= 0) return;
+    const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const int q = lane % LPW;
+    const int gw = gw0 + lane / LPW;
+    const int frame_bytes = g.H * g.W;
+    const int off = gw < words ? gw * 64 + q * PPL : 0x7FFFFFF0;  // past the frame -> zeros
+    union PK {
+        unsigned u;
+        u16x2 v;
+    };
+    auto fetch = [&](int e) -> dvec {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
+        if constexpr (PPL == 16) {
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        } else {
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        }
+    };
+    auto unpack = [&](const dvec& d, PK (&p)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            // low half <- byte r%4 of dword r/4 (pixel r), high half <- same byte of dword r/4 + DW/2 (pixel r + RW)
+            const unsigned sel = 0x0C000C00u | (unsigned)(r & 3) | ((unsigned)(4 + (r & 3)) << 16);
+            p[r].u = __builtin_amdgcn_perm(d[r / 4 + DW / 2], d[r / 4], sel);
+        }
+    };
+    PK win[N][RW];
+    u16x2 sum[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) sum[r] = (u16x2){0, 0};
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        unpack(fetch(i0 + k), win[k]);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) sum[r] += win[k][r].v;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) win[N - 1][r].u = 0;
+    const int e_max = g.K + N - 2;
+    // Bursts of U frames; the loads of burst b+1 are issued before burst b is consumed (double buffering), so a
+    // wave always has loads in flight while it computes.
+    constexpr int NB = (N + U - 1) / U;  // bursts per window period
+    dvec cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = fetch(min(i0 + u + N - 1, e_max));
+    for (int sb = 0; sb < steps; sb += N) {
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+            const int ub = bi * U;
+            // prefetch the following burst (wraps into the next period)
+            const int nb_first = (bi + 1 < NB) ? sb + (bi + 1) * U : sb + N;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in_period = (bi + 1 < NB) ? ((bi + 1) * U + u < N) : (u < N);
+                if (in_period) nxt[u] = fetch(min(i0 + nb_first + u + N - 1, e_max));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ub + u < N) {
+                    const int s = sb + ub + u;
+                    if (s < steps) {
+                        const int slot = (ub + u + N - 1) % N;
+                        PK a[RW];
+                        unpack(cur[u], a);
+                        const int i = i0 + s;
+                        const unsigned short T = (unsigned short)thr_tab[i];
+                        const unsigned short len = (unsigned short)window_len(g, i);
+                        const u16x2 Tv = {T, T}, Lv = {len, len}, one = {1, 1};
+                        unsigned acc = 0;
+                        u16x2 mx[RW], top = {0, 0};
+#pragma unroll
+                        for (int r = 0; r < RW; ++r) {
+                            sum[r] += a[r].v - win[slot][r].v;
+                            win[slot][r] = a[r];
+                            u16x2 m = win[0][r].v;
+#pragma unroll
+                            for (int k = 1; k < N; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
+                            mx[r] = m;
+                            top = __builtin_elementwise_max(top, m);
+                        }
+                        // b needs max > T; on a quiet sky no pixel of the whole wave gets there, so the multiply /
+                        // compare / bit-pack chain is skipped wave-uniformly
+                        PK tp;
+                        tp.v = __builtin_elementwise_sub_sat(top, Tv);
+                        if (__any(tp.u != 0)) {
+#pragma unroll
+                            for (int r = 0; r < RW; ++r) {
+                                PK z;  // 1 per half where  sum < (max - T) * len
+                                z.v = __builtin_elementwise_min(
+                                    __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(mx[r], Tv) * Lv, sum[r]), one);
+                                acc |= z.u << r;
+                            }
+                        }
+                        // bits 0..RW-1 = pixels 0..RW-1, bits 16..16+RW-1 = pixels RW..PPL-1
+                        const unsigned bits = (acc & ((1u << RW) - 1)) | ((acc >> (16 - RW)) & (((1u << RW) - 1) << RW));
+                        u64 v = (u64)bits << (q * PPL);
+#pragma unroll
+                        for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
+                        if (q == 0 && gw < words) {
+                            bbits[(size_t)i * words + gw] = v;
+                            if (v) bandflag[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW] = 1;  // rare
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         }
     }
 }
@@ -321,8 +534,8 @@ __device__ __forceinline__ u128 hor_and3_open(u128 d, const Win& q) {
 // a5 + a6 + a7: act = MORPH_CLOSE( median3(diff) > T ) computed from b = (diff > T):
 //   median3(diff) > T  <=>  at least 5 of the 9 (border-replicated) neighbours have diff > T.
 // One thread owns one word column and a band of RB rows and slides down it with 3-row pipelines.
-#define MORPH_RB 8
-__global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbits, u64* __restrict__ act_ring, PassGeom g) {
+__global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbits, const unsigned char* __restrict__ bandflag,
+                                                     u64* __restrict__ act_ring, PassGeom g) {
     const int i = blockIdx.y;
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,19 +546,42 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
     const u64* src = bbits + (size_t)i * g.H * g.WW;
     const long long t = g.t_base + 1 + i;
     u64* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
+    // the stencils reach 3 rows and 3 columns: if the 3x3 neighbourhood of (band, word column) blocks of b holds no
+    // set bit, the output block is all zero
+    {
+        unsigned any = 0;
+        for (int db = -1; db <= 1; ++db) {
+            const int bb = band + db;
+            if (bb < 0 || bb >= nb) continue;
+            const unsigned char* f = bandflag + ((size_t)i * nb + bb) * g.WW;
+            any |= f[w];
+            if (w > 0) any |= f[w - 1];
+            if (w + 1 < g.WW) any |= f[w + 1];
+        }
+        if (!any) {
+            for (int ya = y0; ya < y0 + MORPH_RB && ya < g.H; ++ya) dst[(size_t)ya * g.WW + w] = 0;
+            return;
+        }
+    }
     u128 hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
     u128 mA = 0, mB = 0;
     u128 dA = 0, dB = 0;
     const u128 ones = ~(u128)0;
-    for (int yy = y0 - 3; yy <= y0 + MORPH_RB + 2; ++yy) {
+#pragma unroll
+    for (int it = 0; it < MORPH_RB + 6; ++it) {
+        const int yy = y0 - 3 + it;
         const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
-        u128 hC0, hC1;
-        hsum3_replicate(load_win(src + (size_t)yc * g.WW, w, g.WW), q, hC0, hC1);
+        u128 hC0 = 0, hC1 = 0, mC = 0, dC = 0;
+        const u128 brow = load_win(src + (size_t)yc * g.WW, w, g.WW);
         const int ym = yy - 1;  // row whose median is complete now
-        u128 mC = count_ge5(hA0, hA1, hB0, hB1, hC0, hC1) & q.valid;
-        if (ym < 0 || ym >= g.H) mC = 0;  // outside the image: never wins the dilate
         const int yd = yy - 2;
-        u128 dC = (hor_or3(mA) | hor_or3(mB) | hor_or3(mC)) & q.valid;
+        // sparse images: when the new row and the whole pipeline are empty the stencils produce zeros
+        if ((brow | hA0 | hA1 | hB0 | hB1 | mA | mB) != 0) {
+            hsum3_replicate(brow, q, hC0, hC1);
+            mC = count_ge5(hA0, hA1, hB0, hB1, hC0, hC1) & q.valid;
+            if (ym < 0 || ym >= g.H) mC = 0;  // outside the image: never wins the dilate
+            dC = (hor_or3(mA) | hor_or3(mB) | hor_or3(mC)) & q.valid;
+        }
         const bool dC_in = yd >= 0 && yd < g.H;
         u128 eC = dC_in ? hor_and3_open(dC, q) : ones;  // rows outside the image never win the erode
         const int ya = yy - 3;
@@ -359,28 +595,14 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
     }
 }
 
-// a8 (temporal part): alive = NOT( act lit in all of the last len = min(n, t) frames )
-// (Detector.py:236-240: sum of the last len binaries <= (len-1)*255).
-__global__ void __launch_bounds__(256) k_dy_alive(const u64* __restrict__ act_ring, u64* __restrict__ alive, PassGeom g) {
-    const int i = blockIdx.y;
-    const int words = g.H * g.WW;
-    const int gw = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gw >= words) return;
-    const long long t = g.t_base + 1 + i;
-    const int len = window_len(g, i);
-    u64 all = ~0ull;
-    for (int j = 0; j < len; ++j) all &= act_ring[(size_t)((t - 1 - j) % g.R) * words + gw];
-    const int w = gw % g.WW;
-    const int rem = g.W - 64 * w;
-    const u64 vm = rem >= 64 ? ~0ull : ((1ull << rem) - 1);
-    alive[(size_t)i * words + gw] = ~all & vm;
-}
-
-// a8 (spatial part) + a9 count: dst = act & erode3x3(alive); per-row and per-frame popcounts; Hough working copy.
-__global__ void __launch_bounds__(256) k_dy_apply(const u64* __restrict__ act_ring, const u64* __restrict__ alive,
-                                                  u64* __restrict__ dst_bits, u64* __restrict__ work_bits,
-                                                  int* __restrict__ rowcount, int* __restrict__ litcount, PassGeom g,
-                                                  int use_dy) {
+// a8 + a9 count.  Dynamic mask (Detector.py:234-242): a pixel is "alive" unless it was lit in ALL of the last
+// len = min(n, t) binaries (sum of the last len binaries <= (len-1)*255);  dst = act & erode3x3(alive).
+// Only words with lit pixels need the mask, and those are rare, so alive is evaluated on the fly from the ring of
+// binaries for the 3x3 word neighbourhood instead of being materialised for the whole frame.
+// Also: per-row and per-frame popcounts.
+__global__ void __launch_bounds__(256) k_dy_apply(const u64* __restrict__ act_ring, u64* __restrict__ dst_bits,
+                                                  int* __restrict__ rowcount,
+                                                  int* __restrict__ litcount, PassGeom g, int use_dy) {
     const int i = blockIdx.y;
     const int words = g.H * g.WW;
     const int gw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,17 +612,19 @@ __global__ void __launch_bounds__(256) k_dy_apply(const u64* __restrict__ act_ri
     u64 out = act_ring[(size_t)((t - 1) % g.R) * words + gw];
     if (use_dy && out) {
         const Win q = make_win(w, g.W);
-        const u64* al = alive + (size_t)i * words;
+        const int len = window_len(g, i);
         u128 e = ~(u128)0;
         for (int dy = -1; dy <= 1; ++dy) {
             const int yy = y + dy;
             if (yy < 0 || yy >= g.H) continue;
-            e &= hor_and3_open(load_win(al + (size_t)yy * g.WW, w, g.WW), q);
+            u128 all = ~(u128)0;
+            for (int j = 0; j < len; ++j)
+                all &= load_win(act_ring + (size_t)((t - 1 - j) % g.R) * words + (size_t)yy * g.WW, w, g.WW);
+            e &= hor_and3_open(~all & q.valid, q);
         }
         out &= (u64)((e & q.valid) >> 3);
     }
     dst_bits[(size_t)i * words + gw] = out;
-    work_bits[(size_t)i * words + gw] = out;
     if (out) {
         const int c = __popcll(out);
         atomicAdd(&rowcount[i * g.H + y], c);
@@ -450,7 +674,7 @@ __global__ void __launch_bounds__(256) k_classic_diff(const uint8_t* const* __re
 }
 
 __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__ planes, u64* __restrict__ dst_bits,
-                                                         u64* __restrict__ work_bits, int* __restrict__ rowcount,
+                                                         int* __restrict__ rowcount,
                                                          int* __restrict__ litcount, PassGeom g) {
     const int i = blockIdx.y;
     const int words = g.H * g.WW;
@@ -480,7 +704,6 @@ __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__
         out = (u64)((acc & q.valid) >> 3);
     }
     dst_bits[(size_t)i * words + gw] = out;
-    work_bits[(size_t)i * words + gw] = out;
     if (out) {
         const int c = __popcll(out);
         atomicAdd(&rowcount[i * g.H + y], c);
@@ -856,6 +1079,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     }
     const size_t words = (size_t)P.H * P.WW;
     const u64* dst = P.dst_bits + (size_t)i * words;
+    u64* wrk = P.work_bits + (size_t)i * words;
     unsigned* nzo = P.nz_orig + (size_t)i * P.nz_cap;
     // row-major list of set pixels: wave scan over the per-row counts, rows emit their own bits
     int total = 0;
@@ -872,6 +1096,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
             int pos = total + incl - c;
             for (int w = 0; w < P.WW; ++w) {
                 u64 word = dst[(size_t)y * P.WW + w];
+                wrk[(size_t)y * P.WW + w] = word;  // working copy: only rows with lit pixels (the rest stays zero)
                 while (word) {
                     const int bpos = __builtin_ctzll(word);
                     word &= word - 1;
@@ -964,6 +1189,12 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
                 }
             }
         }
+    }
+    // the working mask is all-zero between passes: clear the rows that were copied in
+    for (int yb = 0; yb < P.H; yb += 64) {
+        const int y = yb + lane;
+        if (y < P.H && P.rowcount[i * P.H + y] > 0)
+            for (int w = 0; w < P.WW; ++w) wrk[(size_t)y * P.WW + w] = 0;
     }
     if (P.dbg && lane == 0) {
         long long* d = P.dbg + (size_t)i * 8;

@@ -291,3 +291,33 @@ def test_hough_windows_too_big_for_lds_fall_back():
     for k in range(300):
         img[300 + k:303 + k, 700 + k:703 + k] = 220
     run_pair([base, img, base], n, mask, cfg, check_act=False)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16])
+def test_m3_wide_load_window_kernels(n):
+    """Widths that are multiples of 64 take the wide-load window kernels (16 px/lane for n <= 8, 8 px/lane for
+    n <= 16); height chosen so the last wave is partly out of range."""
+    shape = (37, 192)
+    mask = np.ones(shape, np.uint8)
+    frames = busy_frames(300 + n, 3 * n + 20, shape)
+    total = run_pair(frames, n, mask, binary_cfg(adaptive=False, init_value=9), batch=len(frames), max_batch=len(frames))
+    assert total > 0
+    s = SkyStream(*shape, n, speed=4, streak_period=9, streak_life=6)
+    run_pair([s.next() for _ in range(2 * n + 24)], n, mask, binary_cfg(), batch=17, max_batch=17)
+
+
+def test_m3_byte_kernel_equals_wide(monkeypatch):
+    shape, n = (50, 256), 8
+    mask = np.ones(shape, np.uint8)
+    frames = np.stack(busy_frames(56, 50, shape))
+    cfg = binary_cfg(adaptive=False, init_value=9)
+    a = M3Detector(1, n, mask, 10, cfg, None)
+    ra, ia = a.detect_batch(frames)
+    a.close()
+    monkeypatch.setenv("MDH_FORCE_BYTES", "1")
+    b = M3Detector(1, n, mask, 10, cfg, None)
+    rb, ib = b.detect_batch(frames)
+    b.close()
+    assert np.array_equal(ia, ib)
+    for (l1, p1), (l2, p2) in zip(ra, rb):
+        assert np.array_equal(np.asarray(l1).reshape(-1, 4), np.asarray(l2).reshape(-1, 4)) and np.array_equal(p1, p2)
