@@ -50,6 +50,8 @@ def lib():
         L.om3_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double),
                               C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.om3_num_threads.restype = C.c_int
+        L.om3_set_threads.argtypes = [C.c_int]
+        L.om3_set_threads.restype = None
         _lib = L
     return _lib
 

@@ -414,6 +414,14 @@ void om3_get(const om3* c, uint8_t* dst, uint8_t* act, int* bi_threshold, double
     if (sigma) *sigma = c->sigma;
 }
 
+void om3_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int om3_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
