@@ -34,7 +34,7 @@ static void set_err(const std::string& s) { g_err = s; }
 
 enum KernelKind { KK_NOISE_SUMS = 0, KK_NOISE_FINAL, KK_STACK_THR, KK_MORPH, KK_DY_ALIVE, KK_DY_APPLY, KK_HOUGH, KK_CLASSIC };
 static const char* kKernelNames[MDH_NUM_KERNELS] = {"noise_sums", "noise_finalize", "stack_threshold", "morph_close",
-                                                    "dy_alive",   "dy_apply",       "hough_ppht",      "classic"};
+                                                    "dy_alive",   "dy_sparse",       "hough_ppht",      "classic"};
 
 struct ProfSpan {
     int kind;
@@ -65,9 +65,14 @@ struct mdh_ctx {
     int* d_thr = nullptr;
     u64 *d_bbits = nullptr, *d_act = nullptr, *d_dst = nullptr, *d_work = nullptr, *d_planes = nullptr;
     int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr;
-    unsigned char* d_bandflag = nullptr;  // [K][bands][WW]: the (band, word column) block of b holds a set bit
+    int* d_bbox = nullptr;   // [K][4]: bounding box of the lit pixels of each frame
+    hipStream_t stream2 = nullptr;  // second stream for the big-LDS Hough launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
+    unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;  // words of act with lit pixels (sparse dynamic-mask pass)
     int* d_accum = nullptr;
     unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
+    int* h_bbox_init = nullptr;
     int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
     double *d_gap = nullptr, *h_gap = nullptr;
     float* d_trig = nullptr;
@@ -114,16 +119,19 @@ static void free_all(mdh_ctx* c) {
     void* dev[] = {c->d_ring,  c->d_zero,     c->d_ptrtab,   c->d_jobs,  c->d_sums,    c->d_state, c->d_jobres,   c->d_fscal, c->d_thr,
                    c->d_bbits, c->d_act,      c->d_dst,   c->d_work,    c->d_planes,  c->d_rowcount,
                    c->d_litcount, c->d_accum, c->d_nz_orig,  c->d_nz_work, c->d_lines, c->d_nraw,    c->d_gap,   c->d_trig,
-                   c->d_expand, c->d_hdbg, c->d_bandflag};
+                   c->d_expand, c->d_hdbg, c->d_bandflag, c->d_bbox, c->d_nzlist, c->d_nzcount};
     for (void* p : dev)
         if (p) hipFree(p);
-    void* host[] = {c->h_ptrtab, c->h_jobs, c->h_fscal, c->h_litcount, c->h_lines, c->h_nraw, c->h_gap};
+    void* host[] = {c->h_ptrtab, c->h_jobs, c->h_fscal, c->h_litcount, c->h_lines, c->h_nraw, c->h_gap, c->h_bbox_init};
     for (void* p : host)
         if (p) hipHostFree(p);
     for (auto& s : c->spans) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -131,6 +139,9 @@ static void free_all(mdh_ctx* c) {
 static int create_impl(mdh_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     const size_t K = c->Kmax, HW = c->HW, words = c->words;
     int rc;
 #define TRY(x) if ((rc = (x)) != MDH_OK) return rc
@@ -153,7 +164,15 @@ static int create_impl(mdh_ctx* c) {
     if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
     TRY(dev_alloc(c->d_rowcount, K * c->H));
     TRY(dev_alloc(c->d_bandflag, K * (size_t)((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW));
+    TRY(dev_alloc(c->d_nzlist, K * words, false));
+    TRY(dev_alloc(c->d_nzcount, 1));
     TRY(dev_alloc(c->d_litcount, K));
+    TRY(dev_alloc(c->d_bbox, 4 * K));
+    TRY(host_alloc(c->h_bbox_init, 4 * K));
+    for (size_t k = 0; k < K; ++k) {
+        c->h_bbox_init[4 * k + 0] = 0x7FFFFFFF; c->h_bbox_init[4 * k + 1] = -1;
+        c->h_bbox_init[4 * k + 2] = 0x7FFFFFFF; c->h_bbox_init[4 * k + 3] = -1;
+    }
     TRY(host_alloc(c->h_litcount, K));
     TRY(dev_alloc(c->d_accum, K * (size_t)NUM_ANGLE * c->numrho));
     TRY(dev_alloc(c->d_nz_orig, K * HW, false));
@@ -168,6 +187,8 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_expand, HW));
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
 #undef TRY
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (8192 + 61440 / 2 + 64) * (int)sizeof(unsigned)));
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
     const float theta = (float)(3.14159265358979323846 / 180.0);
@@ -464,7 +485,9 @@ static int run_detect(mdh_ctx* c, int K) {
     const int words = (int)c->words;
     HIPCHK(hipMemsetAsync(c->d_rowcount, 0, sizeof(int) * (size_t)K * c->H, c->stream));
     HIPCHK(hipMemsetAsync(c->d_litcount, 0, sizeof(int) * K, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, (size_t)K * ((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_bbox, c->h_bbox_init, sizeof(int) * 4 * K, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * (size_t)K * ((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_nzcount, 0, sizeof(unsigned), c->stream));
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR);
         launch_stack_threshold(c, g);
@@ -472,17 +495,17 @@ static int run_detect(mdh_ctx* c, int K) {
         const int nb = (c->H + MORPH_RB - 1) / MORPH_RB;
         span_begin(c, KK_MORPH);
         hipLaunchKernelGGL(k_morph_close, dim3((nb * c->WW + 255) / 256, K), dim3(256), 0, c->stream, c->d_bbits, c->d_bandflag,
-                           c->d_act, g);
+                           c->d_act, c->d_dst, c->d_nzlist, c->d_nzcount, g);
         span_end(c);
         span_begin(c, KK_DY_APPLY);
-        hipLaunchKernelGGL(k_dy_apply, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_act, c->d_dst,
-                           c->d_rowcount, c->d_litcount, g, c->cfg.dy_mask);
+        hipLaunchKernelGGL(k_dy_sparse, dim3(256), dim3(256), 0, c->stream, c->d_act, c->d_dst, c->d_nzlist, c->d_nzcount,
+                           c->d_rowcount, c->d_litcount, c->d_bbox, g, c->cfg.dy_mask);
         span_end(c);
     } else {
         span_begin(c, KK_CLASSIC);
         hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, c->d_planes, g);
         hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_planes, c->d_dst,
-                           c->d_rowcount, c->d_litcount, g);
+                           c->d_rowcount, c->d_litcount, c->d_bbox, g);
         span_end(c);
     }
     HoughParams P;
@@ -498,8 +521,20 @@ static int run_detect(mdh_ctx* c, int K) {
     P.dst_bits = c->d_dst; P.work_bits = c->d_work; P.rowcount = c->d_rowcount; P.litcount = c->d_litcount;
     P.accum = c->d_accum; P.nz_orig = c->d_nz_orig; P.nz_work = c->d_nz_work; P.nz_cap = (long long)c->HW;
     P.out_lines = c->d_lines; P.out_nraw = c->d_nraw; P.out_gap = c->d_gap; P.trig = c->d_trig;
+    // Two launches that run side by side on two streams: a small-LDS one (2 frames per CU) takes the frames whose
+    // point list and accumulator windows fit it, a big-LDS one (1 frame per CU) takes the rest.  Both evaluate the
+    // same fit test from the per-frame lit count and bounding box, so they do not depend on each other.
     span_begin(c, KK_HOUGH);
-    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), 0, c->stream, P);
+    P.bbox = c->d_bbox;
+    P.small_list = 4096; P.small_cells = 32000;
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
+    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->stream2, P);
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
+    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->stream, P);
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     span_end(c);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_fscal, c->d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, c->stream));

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
 // Generic-n version: one lane per pixel, n byte loads per pixel (the "algorithmic" (n+1) reads of SURVEY 8d).
 __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* const* __restrict__ ptrtab,
                                                                  const int* __restrict__ thr_tab, u64* __restrict__ bbits,
-                                                                 unsigned char* __restrict__ bandflag, PassGeom g) {
+                                                                 unsigned* __restrict__ blockcnt, PassGeom g) {
     const int i = blockIdx.y;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* 
     const u64 m = __ballot(b);
     if (lane == 0) {
         bbits[((size_t)i * g.H + y) * g.WW + w] = m;
-        if (m) bandflag[((size_t)i * ((g.H + MORPH_RB - 1) / MORPH_RB) + y / MORPH_RB) * g.WW + w] = 1;
+        if (m) atomicAdd(&blockcnt[((size_t)i * ((g.H + MORPH_RB - 1) / MORPH_RB) + y / MORPH_RB) * g.WW + w], (unsigned)__popcll(m));
     }
 }
 
@@ -243,7 +243,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <int N>
 __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const* __restrict__ ptrtab,
                                                             const int* __restrict__ thr_tab, u64* __restrict__ bbits,
-                                                            unsigned char* __restrict__ bandflag, PassGeom g, int Tc) {
+                                                            unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
     constexpr int U = N < 8 ? N : 8;  // frames fetched per load burst
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
                         if (lane < 4 && gw0 + lane < words) {
                             const u64 v = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
                             bbits[(size_t)i * words + gw0 + lane] = v;
-                            if (v) bandflag[(size_t)i * nbands * g.WW + (size_t)((gw0 + lane) / g.WW / MORPH_RB) * g.WW + (gw0 + lane) % g.WW] = 1;  // rare
+                            if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)((gw0 + lane) / g.WW / MORPH_RB) * g.WW + (gw0 + lane) % g.WW], (unsigned)__popcll(v));  // rare
                         }
                     }
                 }
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 template <int N, int PPL>
 __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, u64* __restrict__ bbits,
-                                                              unsigned char* __restrict__ bandflag, PassGeom g, int Tc) {
+                                                              unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
     constexpr int RW = PPL / 2;   // packed pair registers per window entry
     constexpr int DW = PPL / 4;   // dwords per load
     constexpr int LPW = 64 / PPL; // lanes per 64-pixel word
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                         for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
                         if (q == 0 && gw < words) {
                             bbits[(size_t)i * words + gw] = v;
-                            if (v) bandflag[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW] = 1;  // rare
+                            if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
                         }
                     }
                 }
@@ -534,8 +534,9 @@ __device__ __forceinline__ u128 hor_and3_open(u128 d, const Win& q) {
 // a5 + a6 + a7: act = MORPH_CLOSE( median3(diff) > T ) computed from b = (diff > T):
 //   median3(diff) > T  <=>  at least 5 of the 9 (border-replicated) neighbours have diff > T.
 // One thread owns one word column and a band of RB rows and slides down it with 3-row pipelines.
-__global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbits, const unsigned char* __restrict__ bandflag,
-                                                     u64* __restrict__ act_ring, PassGeom g) {
+__global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbits, const unsigned* __restrict__ blockcnt,
+                                                     u64* __restrict__ act_ring, u64* __restrict__ dst_bits,
+                                                     unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
     const int i = blockIdx.y;
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,20 +547,27 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
     const u64* src = bbits + (size_t)i * g.H * g.WW;
     const long long t = g.t_base + 1 + i;
     u64* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
-    // the stencils reach 3 rows and 3 columns: if the 3x3 neighbourhood of (band, word column) blocks of b holds no
-    // set bit, the output block is all zero
+    // A pixel survives the median only with >= 5 set samples in its 3x3 window, and every stencil reaches at most
+    // 3 rows / 3 columns, so if the 3x3 neighbourhood of (8-row band, word column) blocks of b holds fewer than 5
+    // set bits (border replication can count a sample twice per axis) the whole output block is zero.
+    u64* dzero = dst_bits + (size_t)i * g.H * g.WW;
     {
-        unsigned any = 0;
+        unsigned total = 0;
         for (int db = -1; db <= 1; ++db) {
             const int bb = band + db;
             if (bb < 0 || bb >= nb) continue;
-            const unsigned char* f = bandflag + ((size_t)i * nb + bb) * g.WW;
-            any |= f[w];
-            if (w > 0) any |= f[w - 1];
-            if (w + 1 < g.WW) any |= f[w + 1];
+            const unsigned* f = blockcnt + ((size_t)i * nb + bb) * g.WW;
+            total += f[w];
+            if (w > 0) total += f[w - 1];
+            if (w + 1 < g.WW) total += f[w + 1];
         }
-        if (!any) {
-            for (int ya = y0; ya < y0 + MORPH_RB && ya < g.H; ++ya) dst[(size_t)ya * g.WW + w] = 0;
+        const unsigned my = (y0 - 3 < 0 || y0 + MORPH_RB + 2 > g.H - 1) ? 2u : 1u;
+        const unsigned mx = (w == 0 || 64 * (w + 1) + 3 > g.W - 1) ? 2u : 1u;
+        if (total * my * mx < 5u) {
+            for (int ya = y0; ya < y0 + MORPH_RB && ya < g.H; ++ya) {
+                dst[(size_t)ya * g.WW + w] = 0;
+                dzero[(size_t)ya * g.WW + w] = 0;
+            }
             return;
         }
     }
@@ -586,8 +594,13 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
         u128 eC = dC_in ? hor_and3_open(dC, q) : ones;  // rows outside the image never win the erode
         const int ya = yy - 3;
         if (ya >= y0 && ya < g.H) {
-            const u128 a = dA & dB & eC & q.valid;
-            dst[(size_t)ya * g.WW + w] = (u64)(a >> 3);
+            const u64 a = (u64)((dA & dB & eC & q.valid) >> 3);
+            dst[(size_t)ya * g.WW + w] = a;
+            // words without lit pixels are final (dst = 0); the others go to the sparse dynamic-mask pass
+            if (a)
+                nzlist[atomicAdd(nzcount, 1u)] = (unsigned)((size_t)i * g.H * g.WW + (size_t)ya * g.WW + w);
+            else
+                dzero[(size_t)ya * g.WW + w] = 0;
         }
         hA0 = hB0; hA1 = hB1; hB0 = hC0; hB1 = hC1;
         mA = mB; mB = mC;
@@ -600,35 +613,43 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
 // Only words with lit pixels need the mask, and those are rare, so alive is evaluated on the fly from the ring of
 // binaries for the 3x3 word neighbourhood instead of being materialised for the whole frame.
 // Also: per-row and per-frame popcounts.
-__global__ void __launch_bounds__(256) k_dy_apply(const u64* __restrict__ act_ring, u64* __restrict__ dst_bits,
-                                                  int* __restrict__ rowcount,
-                                                  int* __restrict__ litcount, PassGeom g, int use_dy) {
-    const int i = blockIdx.y;
+__global__ void __launch_bounds__(256) k_dy_sparse(const u64* __restrict__ act_ring, u64* __restrict__ dst_bits,
+                                                   const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount,
+                                                   int* __restrict__ rowcount, int* __restrict__ litcount,
+                                                   int* __restrict__ bbox, PassGeom g, int use_dy) {
     const int words = g.H * g.WW;
-    const int gw = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gw >= words) return;
-    const int y = gw / g.WW, w = gw - y * g.WW;
-    const long long t = g.t_base + 1 + i;
-    u64 out = act_ring[(size_t)((t - 1) % g.R) * words + gw];
-    if (use_dy && out) {
-        const Win q = make_win(w, g.W);
-        const int len = window_len(g, i);
-        u128 e = ~(u128)0;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= g.H) continue;
-            u128 all = ~(u128)0;
-            for (int j = 0; j < len; ++j)
-                all &= load_win(act_ring + (size_t)((t - 1 - j) % g.R) * words + (size_t)yy * g.WW, w, g.WW);
-            e &= hor_and3_open(~all & q.valid, q);
+    const unsigned total = *nzcount;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned idx = nzlist[e];
+        const int i = idx / words, gw = idx - i * words;
+        const int y = gw / g.WW, w = gw - y * g.WW;
+        const long long t = g.t_base + 1 + i;
+        u64 out = act_ring[(size_t)((t - 1) % g.R) * words + gw];
+        if (use_dy) {
+            const Win q = make_win(w, g.W);
+            const int len = window_len(g, i);
+            u128 e3 = ~(u128)0;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= g.H) continue;
+                u128 all = ~(u128)0;
+                for (int j = 0; j < len; ++j)
+                    all &= load_win(act_ring + (size_t)((t - 1 - j) % g.R) * words + (size_t)yy * g.WW, w, g.WW);
+                e3 &= hor_and3_open(~all & q.valid, q);
+            }
+            out &= (u64)((e3 & q.valid) >> 3);
         }
-        out &= (u64)((e & q.valid) >> 3);
-    }
-    dst_bits[(size_t)i * words + gw] = out;
-    if (out) {
-        const int c = __popcll(out);
-        atomicAdd(&rowcount[i * g.H + y], c);
-        atomicAdd(&litcount[i], c);
+        dst_bits[(size_t)i * words + gw] = out;
+        if (out) {
+            const int c = __popcll(out);
+            atomicAdd(&rowcount[i * g.H + y], c);
+            atomicAdd(&litcount[i], c);
+            // bounding box of the lit pixels of the frame: {min x, max x, min y, max y}
+            atomicMin(&bbox[4 * i + 0], w * 64 + __builtin_ctzll(out));
+            atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(out));
+            atomicMin(&bbox[4 * i + 2], y);
+            atomicMax(&bbox[4 * i + 3], y);
+        }
     }
 }
 
@@ -674,8 +695,8 @@ __global__ void __launch_bounds__(256) k_classic_diff(const uint8_t* const* __re
 }
 
 __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__ planes, u64* __restrict__ dst_bits,
-                                                         int* __restrict__ rowcount,
-                                                         int* __restrict__ litcount, PassGeom g) {
+                                                         int* __restrict__ rowcount, int* __restrict__ litcount,
+                                                         int* __restrict__ bbox, PassGeom g) {
     const int i = blockIdx.y;
     const int words = g.H * g.WW;
     const int gw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -708,6 +729,11 @@ __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__
         const int c = __popcll(out);
         atomicAdd(&rowcount[i * g.H + y], c);
         atomicAdd(&litcount[i], c);
+        // bounding box of the lit pixels of the frame: {min x, max x, min y, max y}
+        atomicMin(&bbox[4 * i + 0], w * 64 + __builtin_ctzll(out));
+        atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(out));
+        atomicMin(&bbox[4 * i + 2], y);
+        atomicMax(&bbox[4 * i + 3], y);
     }
 }
 
@@ -737,9 +763,13 @@ struct HoughParams {
     double* out_gap;       // [K]
     const float* trig;     // [180][2] (cos, sin) as float32 of the float64 value
     long long* dbg;        // optional [K][8] cycle stamps (MDH_HOUGH_DEBUG=1), else null
+    int list_cap;          // LDS point-list capacity of this launch (dwords)
+    int cell_cap;          // LDS accumulator capacity of this launch (16-bit cells, even)
+    int tier;              // 0: small-LDS launch, takes the frames that fit it; 1: big-LDS launch, takes the others; -1: all
+    int small_list, small_cells;  // capacities of the small-LDS launch (the tier decision both launches make)
+    const int* bbox;       // [K][4] {min x, max x, min y, max y} of the lit pixels
 };
 
-#define HOUGH_LDS_PTS 8192
 
 __device__ __forceinline__ u64 ld_l2(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
@@ -763,11 +793,13 @@ struct Ppht {
     float tc[3], ts[3];  // this lane's 3 angles
     int line_gap, frame, found, lane;
     int groups, lines;  // statistics (debug)
+    long long t_shuffle, t_mask, t_vote, t_key, t_line;  // cycle totals per section (debug)
     // LDS-resident part of the accumulator: for angle n the rho bins [lo, hi] live in 16-bit LDS cells starting at
     // `off` (two cells per dword, each biased by CELL_BIAS so that +-1 on one half never carries into the other);
     // bins outside the window stay in the global accumulator.
     unsigned* cells;
-    int lo[3], hi[3], off[3];
+    int dummy_base;  // 64 spare dwords behind the cells: one private dummy target per lane
+    int lo[3], hi[3], off[3], span[3];  // span = hi - lo (-1: no window for this angle)
     bool touched_global;
 };
 #define CELL_BIAS 0x4000
@@ -781,19 +813,24 @@ __device__ __forceinline__ bool work_bit(const Ppht& C, int x, int y) {
 // line pixels that never voted), hence the bias.
 #define KEY_BIAS (1 << 22)
 __device__ __forceinline__ int key_value(unsigned key) { return (int)(key >> 8) - KEY_BIAS; }
+// Branch-free in the common case: every lane issues its LDS atomic (lanes without a valid angle or with a bin
+// outside the window hit a private dummy cell), and the global-accumulator path is entered only when some lane
+// really is outside its window (wave-uniform test).
 __device__ __forceinline__ void vote_issue(Ppht& C, int x, int y, int (&old)[3]) {
+    const float fx = (float)x, fy = (float)y;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int n = C.lane + 64 * q;
-        old[q] = -1;
-        if (n < NUM_ANGLE) {
-            const int r = rho_bin(x, y, C.tc[q], C.ts[q], C.P.half);
-            if (r >= C.lo[q] && r <= C.hi[q]) {
-                const int c = C.off[q] + r - C.lo[q];
-                const int sh = (c & 1) * 16;
-                const unsigned o = atomicAdd(&C.cells[c >> 1], 1u << sh);
-                old[q] = (int)((o >> sh) & 0xFFFFu) - CELL_BIAS;
-            } else {
+        const int r = __float2int_rn(__fadd_rn(__fmul_rn(fx, C.tc[q]), __fmul_rn(fy, C.ts[q]))) + C.P.half;
+        const unsigned d = (unsigned)(r - C.lo[q]);
+        const bool inwin = C.span[q] >= 0 && d <= (unsigned)C.span[q];  // span = hi - lo, or -1 for "no window / no angle"
+        const int c = C.off[q] + (int)d;
+        const int sh = (c & 1) * 16;
+        const unsigned o = atomicAdd(&C.cells[inwin ? (c >> 1) : C.dummy_base + C.lane], inwin ? (1u << sh) : 0u);
+        old[q] = inwin ? (int)((o >> sh) & 0xFFFFu) - CELL_BIAS : -KEY_BIAS - 1;
+        const bool outside = !inwin && n < NUM_ANGLE;
+        if (__any(outside)) {
+            if (outside) {
                 old[q] = atomicAdd(&C.acc[(size_t)n * C.P.numrho + r], 1);
                 C.touched_global = true;
             }
@@ -804,24 +841,24 @@ __device__ __forceinline__ unsigned vote_key(const Ppht& C, const int (&old)[3])
     unsigned key = 0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const int n = C.lane + 64 * q;
-        if (n < NUM_ANGLE) {
-            const unsigned k = ((unsigned)(old[q] + 1 + KEY_BIAS) << 8) | (unsigned)(255 - n);
-            key = k > key ? k : key;
-        }
+        const unsigned k = ((unsigned)(old[q] + 1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.lane + 64 * q));
+        key = k > key ? k : key;
     }
     return key;
 }
 __device__ __forceinline__ void unvote(Ppht& C, int x, int y) {
+    const float fx = (float)x, fy = (float)y;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int n = C.lane + 64 * q;
-        if (n < NUM_ANGLE) {
-            const int r = rho_bin(x, y, C.tc[q], C.ts[q], C.P.half);
-            if (r >= C.lo[q] && r <= C.hi[q]) {
-                const int c = C.off[q] + r - C.lo[q];
-                atomicSub(&C.cells[c >> 1], 1u << ((c & 1) * 16));
-            } else {
+        const int r = __float2int_rn(__fadd_rn(__fmul_rn(fx, C.tc[q]), __fmul_rn(fy, C.ts[q]))) + C.P.half;
+        const unsigned d = (unsigned)(r - C.lo[q]);
+        const bool inwin = C.span[q] >= 0 && d <= (unsigned)C.span[q];
+        const int c = C.off[q] + (int)d;
+        atomicSub(&C.cells[inwin ? (c >> 1) : C.dummy_base + C.lane], inwin ? (1u << ((c & 1) * 16)) : 0u);
+        const bool outside = !inwin && n < NUM_ANGLE;
+        if (__any(outside)) {
+            if (outside) {
                 atomicSub(&C.acc[(size_t)n * C.P.numrho + r], 1);
                 C.touched_global = true;
             }
@@ -862,16 +899,27 @@ __device__ void ppht_line(Ppht& C, int x, int y, int bn) {
             bool lit = false;
             if (inside) lit = work_bit(C, j1, i1);
             const u64 mi = __ballot(inside), ml = __ballot(lit);
-            for (int bb = 0; bb < 64; ++bb) {
-                if (!((mi >> bb) & 1)) { done = true; break; }
-                if ((ml >> bb) & 1) {
+            // scan the 64 steps run by run (lit runs reset the gap, dark runs extend it) instead of bit by bit
+            const int n_in = mi == ~0ull ? 64 : __builtin_ctzll(~mi);  // steps before the image border
+            int pos = 0;
+            while (pos < n_in) {
+                const u64 rest = ml >> pos;
+                if (rest & 1) {
+                    const u64 inv = ~rest;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    run = min(run, n_in - pos);
+                    pos += run;
+                    last_lit = s0 + pos - 1;
                     gap = 0;
-                    last_lit = s0 + bb;
-                } else if (++gap > C.line_gap) {
-                    done = true;
-                    break;
+                } else {
+                    int run = rest ? __builtin_ctzll(rest) : 64;
+                    run = min(run, n_in - pos);
+                    if (gap + run > C.line_gap) { done = true; break; }
+                    gap += run;
+                    pos += run;
                 }
             }
+            if (!done && n_in < 64) done = true;  // left the image
         }
         end_step[k] = last_lit;
         const int X = x0 + dx * last_lit, Y = y0 + dy * last_lit;
@@ -913,6 +961,14 @@ __device__ void ppht_line(Ppht& C, int x, int y, int bn) {
     }
 }
 
+// minimum over lanes 0..15 (one DPP row), broadcast: 4 row_shr steps leave it in lane 15
+__device__ __forceinline__ unsigned row16_min_lane15(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
 __device__ __forceinline__ u64 rng_step(u64 s) { return (u64)(unsigned)s * 4164903690ull + (s >> 32); }
 
 // Serial replay (any list size; the list lives in global memory when it does not fit in LDS).
@@ -958,6 +1014,7 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
     u64 state = 0xFFFFFFFFFFFFFFFFull;
     int count = N;
     while (count > 0) {
+        const long long ta = clock64();
         int gn = count < PPHT_G ? count : PPHT_G;
         u64 st = state, my_state = 0;
         unsigned my_rnd = 0;
@@ -981,7 +1038,7 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
             const int v = __builtin_amdgcn_readlane(my_idx, j);
             if (in_grp && j < lane && v == my_idx) lim = lane < lim ? lane : lim;
         }
-        const int g = min(gn, (int)__builtin_amdgcn_wave_reduce_min_u32((unsigned)lim, 0));
+        const int g = min(gn, (int)row16_min_lane15((unsigned)lim));
         unsigned my_pt = 0;
         if (g == 0) {  // the first draw removes the last element itself: ordinary serial step
             state = rng_step(state);
@@ -1007,13 +1064,17 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
         }
         count -= gn;
         ++C.groups;
+        C.t_shuffle += clock64() - ta;
         u64 pending = (1ull << gn) - 1;
         const int px = my_pt & 0xFFFF, py = my_pt >> 16;
         while (pending) {
+            const long long tb = clock64();
             bool alive = false;
             if ((pending >> lane) & 1) alive = work_bit(C, px, py);
             const u64 am = __ballot(alive);
+            C.t_mask += clock64() - tb;
             if (!am) break;
+            const long long tc0 = clock64();
             int old[PPHT_G][3];
 #pragma unroll
             for (int k = 0; k < PPHT_G; ++k) {
@@ -1022,6 +1083,8 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
                     vote_issue(C, pt & 0xFFFF, pt >> 16, old[k]);
                 }
             }
+            const long long td = clock64();
+            C.t_vote += td - tc0;
             int trig = -1;
             unsigned trig_key = 0;
 #pragma unroll
@@ -1034,7 +1097,9 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
                     }
                 }
             }
+            C.t_key += clock64() - td;
             if (trig < 0) break;
+            const long long te = clock64();
             // points after the trigger voted too early: take those votes back, they are re-examined below
             const u64 later = am & ~((2ull << trig) - 1);
 #pragma unroll
@@ -1050,15 +1115,17 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
             for (int k = 0; k < PPHT_G; ++k)
                 if (k == trig) tp = __builtin_amdgcn_readlane(my_pt, k);
             ppht_line(C, tp & 0xFFFF, tp >> 16, 255 - (int)(best & 0xFF));
+            C.t_line += clock64() - te;
             pending = later;
         }
     }
 }
 
-#define HOUGH_LDS_CELLS 61440  // 16-bit accumulator cells in LDS (120 KiB)
 __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
-    __shared__ unsigned lds_list[HOUGH_LDS_PTS];
-    __shared__ unsigned lds_cells[HOUGH_LDS_CELLS / 2];
+    // dynamic LDS: [ point list: list_cap dwords | accumulator cells: cell_cap/2 dwords | 64 dummy dwords ]
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    unsigned* lds_list = lds_dyn;
+    unsigned* lds_cells = lds_dyn + P.list_cap;
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = P.litcount[i];
@@ -1074,8 +1141,40 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     const int line_gap = (int)rint(gap);
     if (lane == 0) P.out_gap[i] = gap;
     if (N == 0) {
-        if (lane == 0) P.out_nraw[i] = 0;
+        if (lane == 0 && P.tier <= 0) P.out_nraw[i] = 0;
         return;
+    }
+    // Accumulator windows: rho is monotone in x and in y for a fixed angle (rounded float products and sum), so over
+    // the bounding box of the lit pixels its extremes are at the corners.  Window sizes decide which launch owns
+    // the frame (both launches evaluate the same test) and whether the accumulator lives in LDS at all.
+    int w_lo[3] = {0, 0, 0}, w_span[3] = {-1, -1, -1}, w_off[3] = {0, 0, 0};
+    int cells_needed = 0;
+    {
+        const int bx0 = P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = lane + 64 * q;
+            int size = 0;
+            if (n < NUM_ANGLE) {
+                const float c = P.trig[2 * n], sn = P.trig[2 * n + 1];
+                const int r00 = rho_bin(bx0, by0, c, sn, P.half), r10 = rho_bin(bx1, by0, c, sn, P.half);
+                const int r01 = rho_bin(bx0, by1, c, sn, P.half), r11 = rho_bin(bx1, by1, c, sn, P.half);
+                w_lo[q] = min(min(r00, r10), min(r01, r11));
+                size = max(max(r00, r10), max(r01, r11)) - w_lo[q] + 1;
+            }
+            int incl = size;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tt = __shfl_up(incl, d);
+                if (lane >= d) incl += tt;
+            }
+            w_off[q] = cells_needed + incl - size;
+            w_span[q] = size - 1;
+            cells_needed += __shfl(incl, 63);
+        }
+    }
+    if (P.tier >= 0) {
+        const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
+        if ((P.tier == 0) != fits_small) return;  // the other launch owns this frame
     }
     const size_t words = (size_t)P.H * P.WW;
     const u64* dst = P.dst_bits + (size_t)i * words;
@@ -1083,7 +1182,6 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     unsigned* nzo = P.nz_orig + (size_t)i * P.nz_cap;
     // row-major list of set pixels: wave scan over the per-row counts, rows emit their own bits
     int total = 0;
-    int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;  // bounding box of the lit pixels
     for (int yb = 0; yb < P.H; yb += 64) {
         const int y = yb + lane;
         const int c = y < P.H ? P.rowcount[i * P.H + y] : 0;
@@ -1101,12 +1199,8 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
                     const int bpos = __builtin_ctzll(word);
                     word &= word - 1;
                     nzo[pos++] = ((unsigned)y << 16) | (unsigned)(w * 64 + bpos);
-                    bx0 = min(bx0, w * 64 + bpos);
-                    bx1 = max(bx1, w * 64 + bpos);
                 }
             }
-            by0 = min(by0, y);
-            by1 = max(by1, y);
         }
         total += __shfl(incl, 63);
     }
@@ -1114,52 +1208,25 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long c1 = clock64();
     Ppht C{P, P.work_bits + (size_t)i * words, (unsigned*)(P.work_bits + (size_t)i * words),
-           P.accum + (size_t)i * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0,
-           lds_cells, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, false};
+           P.accum + (size_t)i * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0, 0, 0, 0, 0, 0,
+           lds_cells, P.cell_cap / 2, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, {-1, -1, -1}, false};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int n = lane + 64 * q;
         C.tc[q] = n < NUM_ANGLE ? P.trig[2 * n] : 0.f;
         C.ts[q] = n < NUM_ANGLE ? P.trig[2 * n + 1] : 0.f;
     }
-    // Accumulator windows: rho is monotone in x and in y for a fixed angle (rounded float products and sum), so over
-    // the bounding box its extremes are at the corners.  If all 180 windows fit, every vote of every pixel is an LDS
-    // atomic; otherwise the whole frame uses the global accumulator.
-    if (!P.no_lds_acc && N <= HOUGH_LDS_PTS) {
-        for (int o = 32; o > 0; o >>= 1) {
-            bx0 = min(bx0, __shfl_xor(bx0, o));
-            bx1 = max(bx1, __shfl_xor(bx1, o));
-            by0 = min(by0, __shfl_xor(by0, o));
-            by1 = max(by1, __shfl_xor(by1, o));
-        }
-        int size[3], base = 0;
+    if (!P.no_lds_acc && N <= P.list_cap && cells_needed <= P.cell_cap) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int n = lane + 64 * q;
-            size[q] = 0;
-            if (n < NUM_ANGLE) {
-                const int r00 = rho_bin(bx0, by0, C.tc[q], C.ts[q], P.half), r10 = rho_bin(bx1, by0, C.tc[q], C.ts[q], P.half);
-                const int r01 = rho_bin(bx0, by1, C.tc[q], C.ts[q], P.half), r11 = rho_bin(bx1, by1, C.tc[q], C.ts[q], P.half);
-                C.lo[q] = min(min(r00, r10), min(r01, r11));
-                C.hi[q] = max(max(r00, r10), max(r01, r11));
-                size[q] = C.hi[q] - C.lo[q] + 1;
-            }
-            int incl = size[q];
-            for (int d = 1; d < 64; d <<= 1) {
-                const int tt = __shfl_up(incl, d);
-                if (lane >= d) incl += tt;
-            }
-            C.off[q] = base + incl - size[q];
-            base += __shfl(incl, 63);
+            C.lo[q] = w_lo[q];
+            C.span[q] = w_span[q];
+            C.hi[q] = w_lo[q] + w_span[q];
+            C.off[q] = w_off[q];
         }
-        if (base <= HOUGH_LDS_CELLS) {
-            for (int p = lane; p < (base + 1) / 2; p += 64) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { C.lo[q] = 0; C.hi[q] = -1; }
-        }
+        for (int p = lane; p < (cells_needed + 1) / 2; p += 64) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
     }
-    if (N <= HOUGH_LDS_PTS) {
+    if (N <= P.list_cap) {
         for (int p = lane; p < N; p += 64) lds_list[p] = ld_l2(&nzo[p]);
         __syncthreads();
         if (P.serial)
@@ -1185,7 +1252,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
                 const int n = lane + 64 * q;
                 if (n < NUM_ANGLE) {
                     const int r = rho_bin(x, y, C.tc[q], C.ts[q], P.half);
-                    if (r < C.lo[q] || r > C.hi[q]) acc[(size_t)n * P.numrho + r] = 0;
+                    if (C.span[q] < 0 || (unsigned)(r - C.lo[q]) > (unsigned)C.span[q]) acc[(size_t)n * P.numrho + r] = 0;
                 }
             }
         }
@@ -1198,6 +1265,6 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     }
     if (P.dbg && lane == 0) {
         long long* d = P.dbg + (size_t)i * 8;
-        d[0] = N; d[1] = c1 - c0; d[2] = c2 - c1; d[3] = clock64() - c2; d[4] = C.found; d[5] = C.groups; d[6] = C.lines; d[7] = c0;
+        d[0] = N; d[1] = c1 - c0; d[2] = c2 - c1; d[3] = C.t_shuffle; d[4] = C.t_mask; d[5] = C.t_vote; d[6] = C.t_key; d[7] = C.t_line;
     }
 }
