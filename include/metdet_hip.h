@@ -114,6 +114,21 @@ int mdh_profile_enable(mdh_ctx* ctx, int on);
 int mdh_profile_read(mdh_ctx* ctx, double* ms, int64_t* launches, int reset);
 const char* mdh_kernel_name(int k);
 
+/* Loader-side preprocessing in front of the detector:
+ *   Transform.exec_transform = cv2.resize(INTER_LINEAR) -> cv2.cvtColor(BGR2GRAY) -> img * mask   imgproc.py:82-101, 129-139
+ *   MergeFunction.max over exp_frame consecutive processed frames                                utils.py:202-204
+ * bgr: exp_frame x src_h x src_w x 3 u8 (host or device); out: dst_h x dst_w u8 (host or device).
+ * mask01 (dst_h x dst_w of {0,1}, as fileio.load_mask returns) may be NULL. */
+typedef struct mdh_pre mdh_pre;
+mdh_pre* mdh_pre_create(int device, int src_h, int src_w, int dst_h, int dst_w, const uint8_t* mask01);
+int mdh_pre_run(mdh_pre* pre, const uint8_t* bgr, int exp_frame, int src_on_device, uint8_t* out, int out_on_device);
+void mdh_pre_destroy(mdh_pre* pre);
+
+/* stacker.max_stacker / MaxImgContainer (stacker.py:43-49, 197-213): elementwise max over K frames of frame_bytes
+ * bytes each (any channel layout). */
+int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint8_t* out,
+                  int out_on_device);
+
 /* Frames consumed so far (SlidingWindow.timer). */
 int64_t mdh_frames_seen(const mdh_ctx* ctx);
 

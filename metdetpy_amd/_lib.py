@@ -40,7 +40,8 @@ assert FRAME_INFO_DTYPE.itemsize == C.sizeof(MdhFrameInfo)
 EXPORTS = [
     "mdh_create", "mdh_destroy", "mdh_last_error", "mdh_update", "mdh_detect", "mdh_process_batch", "mdh_get_binary",
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
-    "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen"
+    "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
+    "mdh_max_stack"
 ]
 
 _lib = None
@@ -80,6 +81,12 @@ def load():
     L.mdh_kernel_name.restype = C.c_char_p
     L.mdh_frames_seen.argtypes = [vp]
     L.mdh_frames_seen.restype = i64
+    L.mdh_pre_create.argtypes = [i32, i32, i32, i32, i32, vp]
+    L.mdh_pre_create.restype = vp
+    L.mdh_pre_run.argtypes = [vp, vp, i32, i32, vp, i32]
+    L.mdh_pre_destroy.argtypes = [vp]
+    L.mdh_pre_destroy.restype = None
+    L.mdh_max_stack.argtypes = [i32, vp, i32, u64, i32, vp, i32]
     _lib = L
     return L
 

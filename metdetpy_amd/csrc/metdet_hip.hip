@@ -8,6 +8,7 @@
 // Everything that touches pixels runs on the device; the running scalars (snr, threshold) live on the device
 // too, so a pass of K frames is queued without any host round trip.
 #include "metdet_kernels.hpp"
+#include "metdet_pre.hpp"
 
 #include "../../include/metdet_hip.h"
 
@@ -753,5 +754,145 @@ extern "C" int mdh_device_upload(mdh_ctx* c, void* dst, const void* src, uint64_
     if (!c || !dst || !src) return MDH_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MDH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ preprocessing
+struct mdh_pre {
+    int device = 0;
+    PreGeom g{};
+    hipStream_t stream = nullptr;
+    int *d_xi = nullptr, *d_yi = nullptr;
+    short *d_xw = nullptr, *d_yw = nullptr;
+    uint8_t *d_mask = nullptr, *d_src = nullptr, *d_out = nullptr;
+    size_t src_cap = 0;
+};
+
+// OpenCV resize(INTER_LINEAR) coefficient tables: fx = (float)((d+0.5)*scale-0.5), clamp, weights cvRound(w*2048)
+static void linear_table(int dst_n, int src_n, std::vector<int>& idx, std::vector<short>& w) {
+    idx.resize(dst_n);
+    w.resize(2 * (size_t)dst_n);
+    const double scale = (double)src_n / dst_n;
+    for (int d = 0; d < dst_n; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src_n - 1) { s = src_n - 1; f = 0.f; }
+        idx[d] = s;
+        w[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+        w[2 * d + 1] = (short)lrintf(f * 2048.f);
+    }
+}
+
+extern "C" void mdh_pre_destroy(mdh_pre* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    void* dev[] = {p->d_xi, p->d_yi, p->d_xw, p->d_yw, p->d_mask, p->d_src, p->d_out};
+    for (void* q : dev)
+        if (q) hipFree(q);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+static int pre_init(mdh_pre* p, const uint8_t* mask01) {
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    std::vector<int> xi, yi;
+    std::vector<short> xw, yw;
+    linear_table(p->g.dw, p->g.sw, xi, xw);
+    linear_table(p->g.dh, p->g.sh, yi, yw);
+    int rc;
+    if ((rc = dev_alloc(p->d_xi, xi.size(), false)) || (rc = dev_alloc(p->d_yi, yi.size(), false)) ||
+        (rc = dev_alloc(p->d_xw, xw.size(), false)) || (rc = dev_alloc(p->d_yw, yw.size(), false)) ||
+        (rc = dev_alloc(p->d_out, (size_t)p->g.dh * p->g.dw, false)))
+        return rc;
+    HIPCHK(hipMemcpy(p->d_xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_xw, xw.data(), xw.size() * sizeof(short), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_yw, yw.data(), yw.size() * sizeof(short), hipMemcpyHostToDevice));
+    if (mask01) {
+        if ((rc = dev_alloc(p->d_mask, (size_t)p->g.dh * p->g.dw, false))) return rc;
+        HIPCHK(hipMemcpy(p->d_mask, mask01, (size_t)p->g.dh * p->g.dw, hipMemcpyHostToDevice));
+    }
+    return MDH_OK;
+}
+
+extern "C" mdh_pre* mdh_pre_create(int device, int src_h, int src_w, int dst_h, int dst_w, const uint8_t* mask01) {
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) {
+        set_err("mdh_pre_create: bad geometry");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_err("mdh_pre_create: no such HIP device (there is no CPU fallback)");
+        return nullptr;
+    }
+    mdh_pre* p = new mdh_pre();
+    p->device = device;
+    p->g = PreGeom{src_h, src_w, dst_h, dst_w};
+    if (pre_init(p, mask01) != MDH_OK) {
+        std::string keep = g_err;
+        mdh_pre_destroy(p);
+        set_err(keep);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" int mdh_pre_run(mdh_pre* p, const uint8_t* bgr, int exp_frame, int src_on_device, uint8_t* out, int out_on_device) {
+    if (!p || !bgr || !out || exp_frame < 1) { set_err("mdh_pre_run: bad argument"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(p->device));
+    const size_t frame = (size_t)p->g.sh * p->g.sw * 3, need = frame * exp_frame;
+    const uint8_t* src = bgr;
+    if (!src_on_device) {
+        if (p->src_cap < need) {
+            if (p->d_src) HIPCHK(hipFree(p->d_src));
+            p->d_src = nullptr;
+            HIPCHK(hipMalloc((void**)&p->d_src, need));
+            p->src_cap = need;
+        }
+        HIPCHK(hipMemcpyAsync(p->d_src, bgr, need, hipMemcpyHostToDevice, p->stream));
+        src = p->d_src;
+    }
+    uint8_t* dst = out_on_device ? out : p->d_out;
+    const int px = p->g.dh * p->g.dw;
+    hipLaunchKernelGGL(k_preprocess, dim3((px + 255) / 256), dim3(256), 0, p->stream, src, exp_frame, p->g, p->d_xi, p->d_xw,
+                       p->d_yi, p->d_yw, p->d_mask, dst);
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, p->d_out, (size_t)px, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return MDH_OK;
+}
+
+extern "C" int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint8_t* out,
+                             int out_on_device) {
+    if (!frames || !out || K < 1 || frame_bytes == 0) { set_err("mdh_max_stack: bad argument"); return MDH_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_err("mdh_max_stack: no such HIP device (there is no CPU fallback)");
+        return MDH_E_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    const uint8_t* src = frames;
+    if (!on_device) {
+        HIPCHK(hipMalloc((void**)&d_in, (size_t)K * frame_bytes));
+        HIPCHK(hipMemcpy(d_in, frames, (size_t)K * frame_bytes, hipMemcpyHostToDevice));
+        src = d_in;
+    }
+    uint8_t* dst = out;
+    if (!out_on_device) {
+        HIPCHK(hipMalloc((void**)&d_out, frame_bytes));
+        dst = d_out;
+    }
+    const size_t threads = std::max<size_t>(frame_bytes / 16, 16);
+    hipLaunchKernelGGL(k_max_stack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, src, K, (size_t)frame_bytes, dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    if (!out_on_device) HIPCHK(hipMemcpy(out, d_out, frame_bytes, hipMemcpyDeviceToHost));
+    if (d_in) hipFree(d_in);
+    if (d_out) hipFree(d_out);
     return MDH_OK;
 }

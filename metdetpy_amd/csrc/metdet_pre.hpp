@@ -1,0 +1,80 @@
+// metdet_pre.hpp -- loader-side preprocessing in front of the detector:
+//   Transform.exec_transform  resize(INTER_LINEAR) -> BGR2GRAY -> * mask     imgproc.py:82-101, 129-139
+//   MergeFunction.max         elementwise max over exp_frame processed frames utils.py:202-204
+//   MaxImgContainer           running max over a clip (max_stacker)          stacker.py:43-49, 197-213
+// The OpenCV fixed-point paths are restated (PARITY UNPINNED): 11-bit separable bilinear
+// ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2 and Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct PreGeom {
+    int sh, sw, dh, dw;
+};
+
+// One thread per output pixel; the e loop is the exposure merge.
+__global__ void __launch_bounds__(256) k_preprocess(const uint8_t* __restrict__ src, int exp_frame, PreGeom g,
+                                                    const int* __restrict__ xi, const short* __restrict__ xw,
+                                                    const int* __restrict__ yi, const short* __restrict__ yw,
+                                                    const uint8_t* __restrict__ mask01, uint8_t* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.dh * g.dw) return;
+    const int dy = p / g.dw, dx = p - dy * g.dw;
+    const int x0 = xi[dx], x1 = min(x0 + 1, g.sw - 1);
+    const int y0 = yi[dy], y1 = min(y0 + 1, g.sh - 1);
+    const int a0 = xw[2 * dx], a1 = xw[2 * dx + 1];
+    const int b0 = yw[2 * dy], b1 = yw[2 * dy + 1];
+    const int m = mask01 ? mask01[p] : 1;
+    const size_t frame = (size_t)g.sh * g.sw * 3;
+    int best = 0;
+    for (int e = 0; e < exp_frame; ++e) {
+        const uint8_t* f = src + (size_t)e * frame;
+        const uint8_t* r0 = f + (size_t)y0 * g.sw * 3;
+        const uint8_t* r1 = f + (size_t)y1 * g.sw * 3;
+        int ch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int s0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+            const int s1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+            int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+            ch[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        const int gray = ((ch[0] * 1868 + ch[1] * 9617 + ch[2] * 4899 + 8192) >> 14) * m;
+        best = max(best, gray & 0xFF);
+    }
+    out[p] = (uint8_t)best;
+}
+
+// acc = max(acc, frame) over K frames of `bytes` bytes each; 16 bytes per lane (requires bytes % 16 == 0 for the
+// vector body, the tail goes byte-wise).
+__global__ void __launch_bounds__(256) k_max_stack(const uint8_t* __restrict__ frames, int K, size_t bytes,
+                                                   uint8_t* __restrict__ out) {
+    const size_t nvec = bytes / 16;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nvec) {
+        uint4 acc = ((const uint4*)frames)[tid];
+        for (int k = 1; k < K; ++k) {
+            const uint4 v = ((const uint4*)(frames + (size_t)k * bytes))[tid];
+            const unsigned a[4] = {acc.x, acc.y, acc.z, acc.w}, b[4] = {v.x, v.y, v.z, v.w};
+            unsigned r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // per-byte unsigned max on packed bytes via two 16-bit-lane passes
+                const unsigned ae = a[j] & 0x00FF00FFu, be = b[j] & 0x00FF00FFu;
+                const unsigned ao = (a[j] >> 8) & 0x00FF00FFu, bo = (b[j] >> 8) & 0x00FF00FFu;
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const us2 me = __builtin_elementwise_max(__builtin_bit_cast(us2, ae), __builtin_bit_cast(us2, be));
+                const us2 mo = __builtin_elementwise_max(__builtin_bit_cast(us2, ao), __builtin_bit_cast(us2, bo));
+                r[j] = __builtin_bit_cast(unsigned, me) | (__builtin_bit_cast(unsigned, mo) << 8);
+            }
+            acc = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        ((uint4*)out)[tid] = acc;
+    }
+    if (tid < bytes % 16) {
+        const size_t p = nvec * 16 + tid;
+        uint8_t m = frames[p];
+        for (int k = 1; k < K; ++k) m = max(m, frames[(size_t)k * bytes + p]);
+        out[p] = m;
+    }
+}
