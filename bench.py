@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one native pass (mdh_process_batch) over a batch of `--batch` consecutive frames of a seeded synthetic
+One "step" = one native pass (mdh_submit_batch / mdh_collect_batch, two passes in flight) over a batch of `--batch` consecutive frames of a seeded synthetic
 night-sky stream that is already resident in HBM (a pool of `--batch` frames per GPU, cycled): update + detect incl.
 Hough and NMS, results on the host.  N > 1: one process per GPU (torchrun), one independent stream per GPU
 (BASELINE config C4), no data-path collective; RCCL only gathers the per-rank detection counts at the end.
@@ -131,31 +131,42 @@ def main():
     nms = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
     prob = np.zeros((B, _lib.MDH_MAX_LINES), np.float64)
 
-    def step():
-        ctx.process_batch_into(pool, B, True, info, raw, nms, prob)
+    tally = [0, 0, 0]
+
+    def collect():
+        ctx.collect_into(info, raw, nms, prob)
+        tally[0] += int(info["n_raw"].sum())
+        tally[1] += int(info["n_nms"].sum())
+        tally[2] += int(info["lit_count"].sum())
+
+    def run(nsteps):
+        """nsteps passes with two in flight: pass s+1 is queued before pass s is collected, so the pixel stages of
+        one pass overlap the Hough stage of the previous one.  Every pass is fully collected before run() returns."""
+        for s_ in range(nsteps):
+            ctx.submit(pool, B, True)
+            if s_ > 0:
+                collect()
+        collect()
 
     def fence():
-        # the library synchronises its own stream inside every call; the barrier aligns the ranks
+        # the library has no work in flight between run() calls; the barrier aligns the ranks
         if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    if a.warmup:
+        run(a.warmup)
     if not a.no_profile:
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
+    tally[:] = [0, 0, 0]
     fence()
     t0 = time.perf_counter()
-    lit = segs = kept = 0
-    for _ in range(a.steps):
-        step()
-        segs += int(info["n_raw"].sum())
-        kept += int(info["n_nms"].sum())
-        lit += int(info["lit_count"].sum())
+    run(a.steps)
     fence()
+    segs, kept, lit = tally
     dt = time.perf_counter() - t0
     prof = ctx.profile_read(reset=True) if not a.no_profile else {}
     ctx.profile_enable(False)

@@ -41,7 +41,7 @@ EXPORTS = [
     "mdh_create", "mdh_destroy", "mdh_last_error", "mdh_update", "mdh_detect", "mdh_process_batch", "mdh_get_binary",
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
-    "mdh_max_stack"
+    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight"
 ]
 
 _lib = None
@@ -69,6 +69,9 @@ def load():
     L.mdh_update.argtypes = [vp, vp]
     L.mdh_detect.argtypes = [vp, vp, vp, vp, vp]
     L.mdh_process_batch.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    L.mdh_submit_batch.argtypes = [vp, vp, i32, i32]
+    L.mdh_collect_batch.argtypes = [vp, vp, vp, vp, vp]
+    L.mdh_in_flight.argtypes = [vp]
     L.mdh_get_binary.argtypes = [vp, i32, i32, vp]
     L.mdh_lineset_nms.argtypes = [vp, i32, vp, vp]
     L.mdh_device_alloc.argtypes = [vp, u64]
@@ -174,6 +177,24 @@ class Context:
                                        raw.ctypes.data if raw is not None else None,
                                        nms.ctypes.data if nms is not None else None,
                                        prob.ctypes.data if prob is not None else None), "mdh_process_batch")
+
+    def submit(self, ptr, K, on_device):
+        """Queue a pass of K <= max_batch frames and return at once (at most two passes may be in flight).  The
+        frames must stay valid until the pass has been collected."""
+        check(self.L.mdh_submit_batch(self.handle, int(ptr), int(K), int(bool(on_device))), "mdh_submit_batch")
+
+    def collect_into(self, info, raw, nms, prob) -> int:
+        """Wait for the oldest pass in flight and fetch its results; returns its frame count."""
+        rc = self.L.mdh_collect_batch(self.handle, info.ctypes.data, raw.ctypes.data if raw is not None else None,
+                                      nms.ctypes.data if nms is not None else None,
+                                      prob.ctypes.data if prob is not None else None)
+        if rc < 0:
+            check(rc, "mdh_collect_batch")
+        return rc
+
+    @property
+    def in_flight(self) -> int:
+        return self.L.mdh_in_flight(self.handle)
 
     def get_binary(self, index=-1, stage=0):
         out = np.empty((self.H, self.W), np.uint8)

@@ -1,5 +1,5 @@
 // metdet_hip.hip -- host side of libmetdet_hip.so: the C-ABI of include/metdet_hip.h over the gfx950
-// kernels in metdet_kernels.hpp.  No torch, no Triton, no CUDA-compat layer; one HIP stream per context.
+// kernels in metdet_kernels.hpp.  No torch, no Triton, no CUDA-compat layer.
 //
 // Host logic mirrored from the reference (all data-independent, so it stays on the host):
 //   * when the noise sigma is due          SNR_SW.update            Detector.py:81-91
@@ -7,6 +7,12 @@
 //   * lineset_nms                          utils.py:780-839
 // Everything that touches pixels runs on the device; the running scalars (snr, threshold) live on the device
 // too, so a pass of K frames is queued without any host round trip.
+//
+// Streams.  A pass = pixel stages (noise, window/threshold, morphology, dynamic mask) on the MAIN stream, then the
+// Hough stage on two HOUGH streams (small-LDS and big-LDS launches side by side).  Up to two passes are in flight:
+// the pixel stages of pass p+1 (HBM-bound) overlap the Hough stage of pass p (LDS / latency-bound).  Buffers that
+// cross the pixel -> Hough boundary and the result mirrors exist twice ("slots"); state that is carried from frame
+// to frame (frame ring, ring of binaries, running scalars) is only touched on the main stream, in stream order.
 #include "metdet_kernels.hpp"
 #include "metdet_pre.hpp"
 
@@ -35,11 +41,30 @@ static void set_err(const std::string& s) { g_err = s; }
 
 enum KernelKind { KK_NOISE_SUMS = 0, KK_NOISE_FINAL, KK_STACK_THR, KK_MORPH, KK_DY_ALIVE, KK_DY_APPLY, KK_HOUGH, KK_CLASSIC };
 static const char* kKernelNames[MDH_NUM_KERNELS] = {"noise_sums", "noise_finalize", "stack_threshold", "morph_close",
-                                                    "dy_alive",   "dy_sparse",       "hough_ppht",      "classic"};
+                                                    "dy_alive",   "dy_sparse",      "hough_ppht",      "classic"};
 
 struct ProfSpan {
     int kind;
     hipEvent_t a, b;
+};
+
+#define NSLOT 2
+
+// Everything that crosses the pixel-stage -> Hough boundary or is mirrored to the host, per in-flight pass.
+struct Slot {
+    const uint8_t** h_ptrtab = nullptr;  // pinned
+    NoiseJob* h_jobs = nullptr;          // pinned
+    u64* d_dst = nullptr;
+    int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr, *d_bbox = nullptr;
+    FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
+    int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
+    double *d_gap = nullptr, *h_gap = nullptr;
+    hipEvent_t ev_pix = nullptr, ev_done = nullptr;
+    std::vector<ProfSpan> spans;
+    // the pass occupying the slot
+    bool busy = false, used = false;
+    int K = 0;
+    int64_t t_base = 0;
 };
 
 struct mdh_ctx {
@@ -47,51 +72,54 @@ struct mdh_ctx {
     int H = 0, W = 0, WW = 0, n = 0, R = 0, Kmax = 0;
     size_t HW = 0, words = 0;
     mdh_cfg cfg{};
-    hipStream_t stream = nullptr;
-    int64_t t = 0;  // frames consumed (SlidingWindow.timer)
+    hipStream_t stream = nullptr;                   // main: pixel stages, state
+    hipStream_t hstream[2] = {nullptr, nullptr};    // Hough: [0] small-LDS launch + result copies, [1] big-LDS launch
+    hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
+    hipEvent_t ev_big = nullptr;
+    int64_t t = 0;  // frames submitted (SlidingWindow.timer)
     // EMA schedule (host mirror of utils.py:334-368)
     double ema_m0 = 0, ema_warm = 0;
     int64_t ema_t = 0;
     double coef_a = 0, coef_b = 0;
     int numrho = 0;
-    // device buffers
+    // device buffers used on the main stream only
     uint8_t* d_ring = nullptr;
     uint8_t* d_zero = nullptr;
     const uint8_t** d_ptrtab = nullptr;
-    const uint8_t** h_ptrtab = nullptr;
-    NoiseJob *d_jobs = nullptr, *h_jobs = nullptr;
+    const uint8_t** h_ptrtab = nullptr;  // = slot[cur].h_ptrtab while a pass is being queued
+    NoiseJob* d_jobs = nullptr;
     long long* d_sums = nullptr;
     ScalarState *d_state = nullptr, *d_jobres = nullptr;
-    FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
     int* d_thr = nullptr;
-    u64 *d_bbits = nullptr, *d_act = nullptr, *d_dst = nullptr, *d_work = nullptr, *d_planes = nullptr;
-    int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr;
-    int* d_bbox = nullptr;   // [K][4]: bounding box of the lit pixels of each frame
-    hipStream_t stream2 = nullptr;  // second stream for the big-LDS Hough launch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    u64 *d_bbits = nullptr, *d_act = nullptr, *d_planes = nullptr;
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;  // words of act with lit pixels (sparse dynamic-mask pass)
+    int* h_bbox_init = nullptr;
+    // Hough-private buffers (Hough stages of consecutive passes run one after the other)
+    u64* d_work = nullptr;
     int* d_accum = nullptr;
     unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
-    int* h_bbox_init = nullptr;
-    int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
-    double *d_gap = nullptr, *h_gap = nullptr;
     float* d_trig = nullptr;
-    uint8_t* d_expand = nullptr;
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
+    uint8_t* d_expand = nullptr;
+    Slot slot[NSLOT];
+    int next_slot = 0;       // slot the next submitted pass takes
+    int oldest = 0;          // slot of the oldest pass not yet collected
+    int in_flight = 0;
+    int last_hough_slot = -1;  // slot whose Hough stage was queued last
     std::vector<const uint8_t*> hist;  // device pointers of the last n-1 frames, oldest first
-    // pass bookkeeping
-    bool pending = false;      // mdh_update done, mdh_detect not yet
-    int last_K = 0;            // frames of the most recent pass
-    int64_t last_t_base = 0;
-    // profiling
-    bool force_generic = false;  // MDH_FORCE_GENERIC=1: use the n-reads kernel (A/B and parity testing)
-    bool force_bytes = false;    // MDH_FORCE_BYTES=1: never use the wide-load window kernel
-    bool force_ppl8 = false;     // MDH_FORCE_PPL8=1: 8 pixels per lane even when 16 would do
-    bool hough_serial = false;   // MDH_HOUGH_SERIAL=1: one-point-at-a-time PPHT replay
+    // update()/detect() protocol
+    bool pending = false;
+    int last_slot = -1;        // slot of the most recently collected pass (mdh_get_binary)
+    // switches
+    bool force_generic = false;     // MDH_FORCE_GENERIC=1: use the n-reads kernel (A/B and parity testing)
+    bool force_bytes = false;       // MDH_FORCE_BYTES=1: never use the wide-load window kernel
+    bool force_ppl8 = false;        // MDH_FORCE_PPL8=1: 8 pixels per lane even when 16 would do
+    bool hough_serial = false;      // MDH_HOUGH_SERIAL=1: one-point-at-a-time PPHT replay
     bool hough_global_acc = false;  // MDH_HOUGH_GLOBAL_ACC=1: never use the LDS accumulator windows
+    // profiling
     bool prof = false;
-    std::vector<ProfSpan> spans;
+    std::vector<ProfSpan>* cur_spans = nullptr;
     double prof_ms[MDH_NUM_KERNELS] = {0};
     int64_t prof_n[MDH_NUM_KERNELS] = {0};
 };
@@ -99,6 +127,7 @@ struct mdh_ctx {
 extern "C" const char* mdh_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KERNELS) ? kKernelNames[k] : ""; }
 extern "C" int64_t mdh_frames_seen(const mdh_ctx* c) { return c ? c->t : -1; }
+extern "C" int mdh_in_flight(const mdh_ctx* c) { return c ? c->in_flight : -1; }
 
 template <typename T>
 static int dev_alloc(T*& p, size_t count, bool zero = true) {
@@ -116,77 +145,90 @@ static int host_alloc(T*& p, size_t count) {
 static void free_all(mdh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    void* dev[] = {c->d_ring,  c->d_zero,     c->d_ptrtab,   c->d_jobs,  c->d_sums,    c->d_state, c->d_jobres,   c->d_fscal, c->d_thr,
-                   c->d_bbits, c->d_act,      c->d_dst,   c->d_work,    c->d_planes,  c->d_rowcount,
-                   c->d_litcount, c->d_accum, c->d_nz_orig,  c->d_nz_work, c->d_lines, c->d_nraw,    c->d_gap,   c->d_trig,
-                   c->d_expand, c->d_hdbg, c->d_bandflag, c->d_bbox, c->d_nzlist, c->d_nzcount};
+    hipDeviceSynchronize();
+    void* dev[] = {c->d_ring, c->d_zero, c->d_ptrtab, c->d_jobs, c->d_sums, c->d_state, c->d_jobres, c->d_thr, c->d_bbits,
+                   c->d_act, c->d_planes, c->d_bandflag, c->d_nzlist, c->d_nzcount, c->d_work, c->d_accum, c->d_nz_orig,
+                   c->d_nz_work, c->d_trig, c->d_hdbg, c->d_expand};
     for (void* p : dev)
         if (p) hipFree(p);
-    void* host[] = {c->h_ptrtab, c->h_jobs, c->h_fscal, c->h_litcount, c->h_lines, c->h_nraw, c->h_gap, c->h_bbox_init};
-    for (void* p : host)
-        if (p) hipHostFree(p);
-    for (auto& s : c->spans) {
-        hipEventDestroy(s.a);
-        hipEventDestroy(s.b);
+    if (c->h_bbox_init) hipHostFree(c->h_bbox_init);
+    for (Slot& s : c->slot) {
+        void* sdev[] = {s.d_dst, s.d_rowcount, s.d_litcount, s.d_bbox, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap};
+        for (void* p : sdev)
+            if (p) hipFree(p);
+        void* shost[] = {s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
+        for (void* p : shost)
+            if (p) hipHostFree(p);
+        if (s.ev_pix) hipEventDestroy(s.ev_pix);
+        if (s.ev_done) hipEventDestroy(s.ev_done);
+        for (auto& sp : s.spans) {
+            hipEventDestroy(sp.a);
+            hipEventDestroy(sp.b);
+        }
     }
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->stream2) hipStreamDestroy(c->stream2);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->ev_big) hipEventDestroy(c->ev_big);
+    hipStream_t st[] = {c->stream, c->hstream[0], c->hstream[1], c->cstream};
+    for (hipStream_t q : st)
+        if (q) hipStreamDestroy(q);
     delete c;
 }
 
 static int create_impl(mdh_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->hstream[1], hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_big, hipEventDisableTiming));
     const size_t K = c->Kmax, HW = c->HW, words = c->words;
+    const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     int rc;
 #define TRY(x) if ((rc = (x)) != MDH_OK) return rc
     TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
     TRY(dev_alloc(c->d_zero, HW));
     TRY(dev_alloc(c->d_ptrtab, c->n - 1 + K));
-    TRY(host_alloc(c->h_ptrtab, c->n - 1 + K));
     TRY(dev_alloc(c->d_jobs, K));
-    TRY(host_alloc(c->h_jobs, K));
     TRY(dev_alloc(c->d_sums, 2 * K));
     TRY(dev_alloc(c->d_state, 1));
     TRY(dev_alloc(c->d_jobres, K + 1));
-    TRY(dev_alloc(c->d_fscal, K));
-    TRY(host_alloc(c->h_fscal, K));
     TRY(dev_alloc(c->d_thr, K));
     TRY(dev_alloc(c->d_bbits, K * words));
     TRY(dev_alloc(c->d_act, (size_t)c->R * words));
-    TRY(dev_alloc(c->d_dst, K * words));
-    TRY(dev_alloc(c->d_work, K * words));
     if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
-    TRY(dev_alloc(c->d_rowcount, K * c->H));
-    TRY(dev_alloc(c->d_bandflag, K * (size_t)((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW));
+    TRY(dev_alloc(c->d_bandflag, K * nb * c->WW));
     TRY(dev_alloc(c->d_nzlist, K * words, false));
     TRY(dev_alloc(c->d_nzcount, 1));
-    TRY(dev_alloc(c->d_litcount, K));
-    TRY(dev_alloc(c->d_bbox, 4 * K));
+    TRY(dev_alloc(c->d_work, K * words));
+    TRY(dev_alloc(c->d_accum, K * (size_t)NUM_ANGLE * c->numrho));
+    TRY(dev_alloc(c->d_nz_orig, K * HW, false));
+    TRY(dev_alloc(c->d_nz_work, K * HW, false));
+    TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
+    TRY(dev_alloc(c->d_expand, HW));
+    if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
     TRY(host_alloc(c->h_bbox_init, 4 * K));
     for (size_t k = 0; k < K; ++k) {
         c->h_bbox_init[4 * k + 0] = 0x7FFFFFFF; c->h_bbox_init[4 * k + 1] = -1;
         c->h_bbox_init[4 * k + 2] = 0x7FFFFFFF; c->h_bbox_init[4 * k + 3] = -1;
     }
-    TRY(host_alloc(c->h_litcount, K));
-    TRY(dev_alloc(c->d_accum, K * (size_t)NUM_ANGLE * c->numrho));
-    TRY(dev_alloc(c->d_nz_orig, K * HW, false));
-    TRY(dev_alloc(c->d_nz_work, K * HW, false));
-    TRY(dev_alloc(c->d_lines, K * (size_t)MAX_LINES * 4));
-    TRY(host_alloc(c->h_lines, K * (size_t)MAX_LINES * 4));
-    TRY(dev_alloc(c->d_nraw, K));
-    TRY(host_alloc(c->h_nraw, K));
-    TRY(dev_alloc(c->d_gap, K));
-    TRY(host_alloc(c->h_gap, K));
-    TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
-    TRY(dev_alloc(c->d_expand, HW));
-    if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
+    for (Slot& s : c->slot) {
+        TRY(host_alloc(s.h_ptrtab, c->n - 1 + K));
+        TRY(host_alloc(s.h_jobs, K));
+        TRY(dev_alloc(s.d_dst, K * words));
+        TRY(dev_alloc(s.d_rowcount, K * c->H));
+        TRY(dev_alloc(s.d_litcount, K));
+        TRY(host_alloc(s.h_litcount, K));
+        TRY(dev_alloc(s.d_bbox, 4 * K));
+        TRY(dev_alloc(s.d_fscal, K));
+        TRY(host_alloc(s.h_fscal, K));
+        TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
+        TRY(host_alloc(s.h_lines, K * (size_t)MAX_LINES * 4));
+        TRY(dev_alloc(s.d_nraw, K));
+        TRY(host_alloc(s.h_nraw, K));
+        TRY(dev_alloc(s.d_gap, K));
+        TRY(host_alloc(s.h_gap, K));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_pix, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    }
 #undef TRY
     HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (8192 + 61440 / 2 + 64) * (int)sizeof(unsigned)));
@@ -211,6 +253,11 @@ static int create_impl(mdh_ctx* c) {
     c->ema_t = 0;
     c->hist.assign(c->n - 1, c->d_zero);
     return MDH_OK;
+}
+
+static bool env_on(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] == '1';
 }
 
 extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh_cfg* cfg) {
@@ -253,22 +300,18 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->WW = (W + 63) / 64;
     c->n = n_window;
     c->Kmax = cfg->max_batch > 0 ? cfg->max_batch : 64;
-    c->R = c->n - 1 + c->Kmax;
+    // the frame / binary rings must hold the history plus two passes in flight
+    c->R = c->n - 1 + NSLOT * c->Kmax;
     if (c->R < c->n) c->R = c->n;
     c->HW = (size_t)H * W;
     c->words = (size_t)H * c->WW;
     c->cfg = *cfg;
     c->numrho = (W + H) * 2 + 1;
-    const char* fg = getenv("MDH_FORCE_GENERIC");
-    c->force_generic = fg && fg[0] == '1';
-    const char* fb = getenv("MDH_FORCE_BYTES");
-    c->force_bytes = fb && fb[0] == '1';
-    const char* f8 = getenv("MDH_FORCE_PPL8");
-    c->force_ppl8 = f8 && f8[0] == '1';
-    const char* hs = getenv("MDH_HOUGH_SERIAL");
-    c->hough_serial = hs && hs[0] == '1';
-    const char* hg = getenv("MDH_HOUGH_GLOBAL_ACC");
-    c->hough_global_acc = hg && hg[0] == '1';
+    c->force_generic = env_on("MDH_FORCE_GENERIC");
+    c->force_bytes = env_on("MDH_FORCE_BYTES");
+    c->force_ppl8 = env_on("MDH_FORCE_PPL8");
+    c->hough_serial = env_on("MDH_HOUGH_SERIAL");
+    c->hough_global_acc = env_on("MDH_HOUGH_GLOBAL_ACC");
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
         free_all(c);
@@ -281,21 +324,21 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
 extern "C" void mdh_destroy(mdh_ctx* c) { free_all(c); }
 
 // ------------------------------------------------------------------------------------------------ profiling
-static inline void span_begin(mdh_ctx* c, int kind) {
+static inline void span_begin(mdh_ctx* c, int kind, hipStream_t st) {
     if (!c->prof) return;
     ProfSpan s;
     s.kind = kind;
     hipEventCreate(&s.a);
     hipEventCreate(&s.b);
-    hipEventRecord(s.a, c->stream);
-    c->spans.push_back(s);
+    hipEventRecord(s.a, st);
+    c->cur_spans->push_back(s);
 }
-static inline void span_end(mdh_ctx* c) {
+static inline void span_end(mdh_ctx* c, hipStream_t st) {
     if (!c->prof) return;
-    hipEventRecord(c->spans.back().b, c->stream);
+    hipEventRecord(c->cur_spans->back().b, st);
 }
-static void spans_collect(mdh_ctx* c) {
-    for (auto& s : c->spans) {
+static void spans_collect(mdh_ctx* c, Slot& sl) {
+    for (auto& s : sl.spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             c->prof_ms[s.kind] += ms;
@@ -304,7 +347,7 @@ static void spans_collect(mdh_ctx* c) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
-    c->spans.clear();
+    sl.spans.clear();
 }
 extern "C" int mdh_profile_enable(mdh_ctx* c, int on) {
     if (!c) return MDH_E_ARG;
@@ -332,24 +375,21 @@ static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
 }
 
 // Stage K frames (absolute timers t_base+1 .. t_base+K): build the pointer table [hist (n-1) | pass frames (K)].
-static int stage_frames(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
-    const int64_t t_base = c->t;
+static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int on_device) {
+    const int64_t t_base = sl.t_base;
+    c->h_ptrtab = sl.h_ptrtab;
     for (int e = 0; e < c->n - 1; ++e) c->h_ptrtab[e] = c->hist[e];
     for (int i = 0; i < K; ++i) {
-        const int64_t slot = (t_base + i) % c->R;
-        if (on_device) {
-            c->h_ptrtab[c->n - 1 + i] = frames + (size_t)i * c->HW;
-        } else {
-            c->h_ptrtab[c->n - 1 + i] = c->d_ring + (size_t)slot * c->HW;
-        }
+        const int64_t rs = (t_base + i) % c->R;
+        c->h_ptrtab[c->n - 1 + i] = on_device ? frames + (size_t)i * c->HW : c->d_ring + (size_t)rs * c->HW;
     }
     if (!on_device) {
         // contiguous host frames -> ring slots (t_base + i) % R : at most two runs
         int i = 0;
         while (i < K) {
-            const int64_t slot = (t_base + i) % c->R;
-            const int run = (int)std::min<int64_t>(K - i, c->R - slot);
-            HIPCHK(hipMemcpyAsync(c->d_ring + (size_t)slot * c->HW, frames + (size_t)i * c->HW, (size_t)run * c->HW,
+            const int64_t rs = (t_base + i) % c->R;
+            const int run = (int)std::min<int64_t>(K - i, c->R - rs);
+            HIPCHK(hipMemcpyAsync(c->d_ring + (size_t)rs * c->HW, frames + (size_t)i * c->HW, (size_t)run * c->HW,
                                   hipMemcpyHostToDevice, c->stream));
             i += run;
         }
@@ -423,8 +463,8 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
 }
 
 // LineDetector.update for the K staged frames: noise sums where due, then the scalar chain.
-static int run_noise(mdh_ctx* c, int K) {
-    const int64_t t_base = c->t;
+static int run_noise(mdh_ctx* c, Slot& sl, int K) {
+    const int64_t t_base = sl.t_base;
     const int n = c->n;
     const int64_t std_interval = (int64_t)c->cfg.interval * n;  // Detector.py:63
     int nj = 0;
@@ -445,7 +485,7 @@ static int run_noise(mdh_ctx* c, int K) {
             }
         }
         c->ema_t += 1;
-        NoiseJob& j = c->h_jobs[nj++];
+        NoiseJob& j = sl.h_jobs[nj++];
         j.frame = i;
         j.k_used = k_used;
         j.m_cur = m;
@@ -455,11 +495,11 @@ static int run_noise(mdh_ctx* c, int K) {
     const int rh = r[2] - r[0], rw = r[3] - r[1];
     PassGeom g = geom(c, K, t_base);
     if (nj) {
-        HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_jobs, sl.h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->stream));
         bool aligned4 = (c->W % 4) == 0;
         for (int e = 0; e < c->n - 1 + K && aligned4; ++e) aligned4 = ((uintptr_t)c->h_ptrtab[e] & 3) == 0;
-        span_begin(c, KK_NOISE_SUMS);
+        span_begin(c, KK_NOISE_SUMS, c->stream);
         if (aligned4) {
             const int xa = r[1] & ~3;
             const int nx4 = (r[1] + rw - xa + 3) >> 2;
@@ -469,46 +509,48 @@ static int run_noise(mdh_ctx* c, int K) {
             hipLaunchKernelGGL(k_noise_sums_bytes, dim3((rh * rw + 255) / 256, nj), dim3(256), 0, c->stream, c->d_ptrtab,
                                c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
         }
-        span_end(c);
+        span_end(c, c->stream);
     }
-    span_begin(c, KK_NOISE_FINAL);
+    span_begin(c, KK_NOISE_FINAL, c->stream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->stream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
-                       c->d_fscal, c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
-    span_end(c);
+                       sl.d_fscal, c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
+    span_end(c, c->stream);
     HIPCHK(hipGetLastError());
     return MDH_OK;
 }
 
-// {M3,Classic}Detector.detect for the K staged frames, up to the raw Hough segments; results land in pinned memory.
-static int run_detect(mdh_ctx* c, int K) {
-    const int64_t t_base = c->t;
+// {M3,Classic}Detector.detect for the K staged frames: pixel stages on the main stream, Hough on the Hough streams.
+static int run_detect(mdh_ctx* c, Slot& sl, int K) {
+    const int64_t t_base = sl.t_base;
     PassGeom g = geom(c, K, t_base);
     const int words = (int)c->words;
-    HIPCHK(hipMemsetAsync(c->d_rowcount, 0, sizeof(int) * (size_t)K * c->H, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_litcount, 0, sizeof(int) * K, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_bbox, c->h_bbox_init, sizeof(int) * 4 * K, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * (size_t)K * ((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW, c->stream));
+    const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
+    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * (size_t)K * c->H, c->stream));
+    HIPCHK(hipMemsetAsync(sl.d_litcount, 0, sizeof(int) * K, c->stream));
+    HIPCHK(hipMemcpyAsync(sl.d_bbox, c->h_bbox_init, sizeof(int) * 4 * K, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * (size_t)K * nb * c->WW, c->stream));
     HIPCHK(hipMemsetAsync(c->d_nzcount, 0, sizeof(unsigned), c->stream));
     if (c->cfg.detector == MDH_DET_M3) {
-        span_begin(c, KK_STACK_THR);
+        span_begin(c, KK_STACK_THR, c->stream);
         launch_stack_threshold(c, g);
-        span_end(c);
-        const int nb = (c->H + MORPH_RB - 1) / MORPH_RB;
-        span_begin(c, KK_MORPH);
-        hipLaunchKernelGGL(k_morph_close, dim3((nb * c->WW + 255) / 256, K), dim3(256), 0, c->stream, c->d_bbits, c->d_bandflag,
-                           c->d_act, c->d_dst, c->d_nzlist, c->d_nzcount, g);
-        span_end(c);
-        span_begin(c, KK_DY_APPLY);
-        hipLaunchKernelGGL(k_dy_sparse, dim3(256), dim3(256), 0, c->stream, c->d_act, c->d_dst, c->d_nzlist, c->d_nzcount,
-                           c->d_rowcount, c->d_litcount, c->d_bbox, g, c->cfg.dy_mask);
-        span_end(c);
+        span_end(c, c->stream);
+        span_begin(c, KK_MORPH, c->stream);
+        hipLaunchKernelGGL(k_morph_close, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, c->stream, c->d_bbits,
+                           c->d_bandflag, c->d_act, sl.d_dst, c->d_nzlist, c->d_nzcount, g);
+        span_end(c, c->stream);
+        span_begin(c, KK_DY_APPLY, c->stream);
+        hipLaunchKernelGGL(k_dy_sparse, dim3(256), dim3(256), 0, c->stream, c->d_act, sl.d_dst, c->d_nzlist, c->d_nzcount,
+                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
+        span_end(c, c->stream);
     } else {
-        span_begin(c, KK_CLASSIC);
+        span_begin(c, KK_CLASSIC, c->stream);
         hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, c->d_planes, g);
-        hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_planes, c->d_dst,
-                           c->d_rowcount, c->d_litcount, c->d_bbox, g);
-        span_end(c);
+        hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_planes, sl.d_dst,
+                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
+        span_end(c, c->stream);
     }
+    HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(sl.ev_pix, c->stream));
     HoughParams P;
     P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
     P.threshold = c->cfg.hough_threshold;
@@ -519,35 +561,39 @@ static int run_detect(mdh_ctx* c, int K) {
     P.no_lds_acc = c->hough_global_acc;
     P.dbg = c->d_hdbg;
     P.mask_area = c->cfg.mask_area;
-    P.dst_bits = c->d_dst; P.work_bits = c->d_work; P.rowcount = c->d_rowcount; P.litcount = c->d_litcount;
+    P.dst_bits = sl.d_dst; P.work_bits = c->d_work; P.rowcount = sl.d_rowcount; P.litcount = sl.d_litcount;
     P.accum = c->d_accum; P.nz_orig = c->d_nz_orig; P.nz_work = c->d_nz_work; P.nz_cap = (long long)c->HW;
-    P.out_lines = c->d_lines; P.out_nraw = c->d_nraw; P.out_gap = c->d_gap; P.trig = c->d_trig;
-    // Two launches that run side by side on two streams: a small-LDS one (2 frames per CU) takes the frames whose
-    // point list and accumulator windows fit it, a big-LDS one (1 frame per CU) takes the rest.  Both evaluate the
-    // same fit test from the per-frame lit count and bounding box, so they do not depend on each other.
-    span_begin(c, KK_HOUGH);
-    P.bbox = c->d_bbox;
+    P.out_lines = sl.d_lines; P.out_nraw = sl.d_nraw; P.out_gap = sl.d_gap; P.trig = c->d_trig;
+    P.bbox = sl.d_bbox;
     P.small_list = 4096; P.small_cells = 32000;
-    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    // Hough: a small-LDS launch (2 frames per CU) takes the frames whose point list and accumulator windows fit it, a
+    // big-LDS launch (1 frame per CU) takes the rest; both evaluate the same fit test from the lit count and bounding
+    // box, so they run side by side.  They start once this pass's pixel stages are done and the previous pass's Hough
+    // stage has released the shared accumulators / point lists.
+    for (int h = 0; h < 2; ++h) {
+        HIPCHK(hipStreamWaitEvent(c->hstream[h], sl.ev_pix, 0));
+        if (c->last_hough_slot >= 0) HIPCHK(hipStreamWaitEvent(c->hstream[h], c->slot[c->last_hough_slot].ev_done, 0));
+    }
+    span_begin(c, KK_HOUGH, c->hstream[0]);
     P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
-    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->stream2, P);
-    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[1], P);
+    HIPCHK(hipEventRecord(c->ev_big, c->hstream[1]));
     P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
-    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->stream, P);
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    span_end(c);
+    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[0], P);
+    HIPCHK(hipStreamWaitEvent(c->hstream[0], c->ev_big, 0));
+    span_end(c, c->hstream[0]);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_fscal, c->d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_nraw, c->d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_litcount, c->d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_gap, c->d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(sl.h_nraw, sl.d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, c->hstream[0]));
+    HIPCHK(hipMemcpyAsync(sl.h_litcount, sl.d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, c->hstream[0]));
+    HIPCHK(hipMemcpyAsync(sl.h_gap, sl.d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, c->hstream[0]));
+    HIPCHK(hipEventRecord(sl.ev_done, c->hstream[0]));
+    c->last_hough_slot = (int)(&sl - c->slot);
     return MDH_OK;
 }
 
-// After a pass: remember where the last n-1 frames live (copying caller-owned device frames into the ring).
-static int retire_frames(mdh_ctx* c, int K, int on_device) {
-    const int64_t t_base = c->t;
+// After a pass is queued: remember where the last n-1 frames live (copying caller-owned device frames into the ring).
+static int retire_frames(mdh_ctx* c, Slot& sl, int K, int on_device) {
+    const int64_t t_base = sl.t_base;
     const int keep = c->n - 1;
     std::vector<const uint8_t*> nh(keep);
     for (int e = 0; e < keep; ++e) {
@@ -557,10 +603,10 @@ static int retire_frames(mdh_ctx* c, int K, int on_device) {
             nh[e] = c->hist[src];
         } else {
             const int i = src - keep;
-            uint8_t* slot = c->d_ring + (size_t)((t_base + i) % c->R) * c->HW;
+            uint8_t* rs = c->d_ring + (size_t)((t_base + i) % c->R) * c->HW;
             if (on_device)
-                HIPCHK(hipMemcpyAsync(slot, c->h_ptrtab[keep + i], c->HW, hipMemcpyDeviceToDevice, c->stream));
-            nh[e] = slot;
+                HIPCHK(hipMemcpyAsync(rs, sl.h_ptrtab[keep + i], c->HW, hipMemcpyDeviceToDevice, c->stream));
+            nh[e] = rs;
         }
     }
     c->hist.swap(nh);
@@ -610,25 +656,62 @@ extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, 
     return kept;
 }
 
-// Wait for the pass and hand results to the caller.
-static int finish_pass(mdh_ctx* c, int K, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    spans_collect(c);
-    // second, strided copy: only as many segments per frame as the fullest frame of the pass holds
+// Take the next slot for a pass of K frames.  The slot's previous pass must have been collected.
+static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
+    if (K < 1 || K > c->Kmax) { set_err("pass size must be 1..max_batch"); return MDH_E_ARG; }
+    if (c->in_flight >= NSLOT) { set_err("two passes are already in flight: collect one first"); return MDH_E_STATE; }
+    Slot& sl = c->slot[c->next_slot];
+    if (sl.busy) { set_err("internal: slot still busy"); return MDH_E_STATE; }
+    // the main stream may not overwrite this slot's buffers before the Hough stage that last read them is done
+    if (sl.used) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    sl.K = K;
+    sl.t_base = c->t;
+    c->cur_spans = &sl.spans;
+    out = &sl;
+    return MDH_OK;
+}
+static void slot_commit(mdh_ctx* c, Slot& sl) {
+    sl.busy = true;
+    sl.used = true;
+    c->t += sl.K;
+    c->next_slot = (c->next_slot + 1) % NSLOT;
+    c->in_flight += 1;
+}
+
+static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
+    Slot* sl = nullptr;
+    int rc;
+    if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
+    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return rc;
+    if ((rc = run_noise(c, *sl, K)) != MDH_OK) return rc;
+    if ((rc = run_detect(c, *sl, K)) != MDH_OK) return rc;
+    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return rc;
+    slot_commit(c, *sl);
+    return MDH_OK;
+}
+
+// Wait for the oldest pass in flight and hand its results to the caller.
+static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline, int* K_out) {
+    if (c->in_flight <= 0) { set_err("no pass in flight"); return MDH_E_STATE; }
+    Slot& sl = c->slot[c->oldest];
+    const int K = sl.K;
+    HIPCHK(hipEventSynchronize(sl.ev_done));
+    spans_collect(c, sl);
+    // strided copy of the segments: only as many per frame as the fullest frame of the pass holds
     int most = 0;
-    for (int i = 0; i < K; ++i) most = std::max(most, std::min(c->h_nraw[i], MAX_LINES));
+    for (int i = 0; i < K; ++i) most = std::max(most, std::min(sl.h_nraw[i], MAX_LINES));
     if (most > 0) {
         const size_t pitch = sizeof(int) * 4 * MAX_LINES;
-        HIPCHK(hipMemcpy2DAsync(c->h_lines, pitch, c->d_lines, pitch, sizeof(int) * 4 * (size_t)most, K, hipMemcpyDeviceToHost,
-                                c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy2DAsync(sl.h_lines, pitch, sl.d_lines, pitch, sizeof(int) * 4 * (size_t)most, K, hipMemcpyDeviceToHost,
+                                c->cstream));
+        HIPCHK(hipStreamSynchronize(c->cstream));
     }
     std::vector<int32_t> tmp_l(4 * MAX_LINES);
     std::vector<double> tmp_p(MAX_LINES);
     for (int i = 0; i < K; ++i) {
-        const int n_raw = c->h_nraw[i];
+        const int n_raw = sl.h_nraw[i];
         const int stored = std::min(n_raw, MAX_LINES);
-        const int32_t* L = c->h_lines + (size_t)i * MAX_LINES * 4;
+        const int32_t* L = sl.h_lines + (size_t)i * MAX_LINES * 4;
         if (raw_lines) memcpy(raw_lines + (size_t)i * MAX_LINES * 4, L, sizeof(int32_t) * 4 * stored);
         int n_nms = 0;
         if (n_raw > 0 && n_raw <= 500) {  // NUM_LINES_TOOMUCH (Detector.py:30, 358-360)
@@ -639,25 +722,48 @@ static int finish_pass(mdh_ctx* c, int K, mdh_frame_info* info, int32_t* raw_lin
             mdh_frame_info& o = info[i];
             o.n_raw = n_raw;
             o.n_nms = n_nms;
-            o.lit_count = c->h_litcount[i];
-            o.bi_threshold = c->h_fscal[i].thr;
-            o.bi_threshold_float = c->h_fscal[i].thr_f;
-            o.snr = c->h_fscal[i].snr;
-            o.sigma = c->h_fscal[i].sigma;
-            o.dst_sum = (double)c->h_litcount[i] / c->cfg.mask_area * 100;  // Detector.py:342
-            o.hough_gap = c->h_gap[i];
+            o.lit_count = sl.h_litcount[i];
+            o.bi_threshold = sl.h_fscal[i].thr;
+            o.bi_threshold_float = sl.h_fscal[i].thr_f;
+            o.snr = sl.h_fscal[i].snr;
+            o.sigma = sl.h_fscal[i].sigma;
+            o.dst_sum = (double)sl.h_litcount[i] / c->cfg.mask_area * 100;  // Detector.py:342
+            o.hough_gap = sl.h_gap[i];
         }
     }
+    sl.busy = false;
+    c->last_slot = c->oldest;
+    c->oldest = (c->oldest + 1) % NSLOT;
+    c->in_flight -= 1;
+    if (K_out) *K_out = K;
     return MDH_OK;
+}
+
+extern "C" int mdh_submit_batch(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
+    if (!c || !frames) { set_err("mdh_submit_batch: null argument"); return MDH_E_ARG; }
+    if (c->pending) { set_err("mdh_submit_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    return submit_pass(c, frames, K, on_device);
+}
+
+extern "C" int mdh_collect_batch(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
+    if (!c) { set_err("mdh_collect_batch: null context"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    int K = 0;
+    const int rc = collect_pass(c, info, raw_lines, nms_lines, nonline, &K);
+    return rc == MDH_OK ? K : rc;
 }
 
 extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if (!c || !frame) { set_err("mdh_update: null argument"); return MDH_E_ARG; }
     if (c->pending) { set_err("mdh_update: previous frame not yet consumed by mdh_detect"); return MDH_E_STATE; }
+    if (c->in_flight) { set_err("mdh_update: collect the submitted passes first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    Slot* sl = nullptr;
     int rc;
-    if ((rc = stage_frames(c, frame, 1, 0)) != MDH_OK) return rc;
-    if ((rc = run_noise(c, 1)) != MDH_OK) return rc;
+    if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
+    if ((rc = stage_frames(c, *sl, frame, 1, 0)) != MDH_OK) return rc;
+    if ((rc = run_noise(c, *sl, 1)) != MDH_OK) return rc;
     // the caller may reuse `frame` after return (the reference copies it, utils.py:280)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->pending = true;
@@ -668,54 +774,54 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
     if (!c) { set_err("mdh_detect: null context"); return MDH_E_ARG; }
     if (!c->pending) { set_err("mdh_detect: call mdh_update first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    Slot& sl = c->slot[c->next_slot];
     int rc;
-    if ((rc = run_detect(c, 1)) != MDH_OK) return rc;
-    if ((rc = retire_frames(c, 1, 0)) != MDH_OK) return rc;
-    if ((rc = finish_pass(c, 1, info, raw_lines, nms_lines, nonline)) != MDH_OK) return rc;
-    c->last_K = 1;
-    c->last_t_base = c->t;
-    c->t += 1;
+    if ((rc = run_detect(c, sl, 1)) != MDH_OK) return rc;
+    if ((rc = retire_frames(c, sl, 1, 0)) != MDH_OK) return rc;
+    slot_commit(c, sl);
     c->pending = false;
-    return MDH_OK;
+    return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
 }
 
 extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int on_device, mdh_frame_info* info,
                                  int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
     if (!c || !frames || K < 0) { set_err("mdh_process_batch: bad argument"); return MDH_E_ARG; }
     if (c->pending) { set_err("mdh_process_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
+    if (c->in_flight) { set_err("mdh_process_batch: collect the submitted passes first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    int done = 0;
-    while (done < K) {
-        const int k = std::min(K - done, c->Kmax);
-        const uint8_t* f = frames + (size_t)done * c->HW;
+    // chunks of at most max_batch frames, two in flight: chunk j+1 is queued before chunk j is collected
+    int submitted = 0, collected = 0;
+    while (collected < K) {
         int rc;
-        if ((rc = stage_frames(c, f, k, on_device)) != MDH_OK) return rc;
-        if ((rc = run_noise(c, k)) != MDH_OK) return rc;
-        if ((rc = run_detect(c, k)) != MDH_OK) return rc;
-        if ((rc = retire_frames(c, k, on_device)) != MDH_OK) return rc;
-        if ((rc = finish_pass(c, k, info ? info + done : nullptr, raw_lines ? raw_lines + (size_t)done * MAX_LINES * 4 : nullptr,
-                              nms_lines ? nms_lines + (size_t)done * MAX_LINES * 4 : nullptr,
-                              nonline ? nonline + (size_t)done * MAX_LINES : nullptr)) != MDH_OK)
+        while (submitted < K && c->in_flight < NSLOT) {
+            const int k = std::min(K - submitted, c->Kmax);
+            if ((rc = submit_pass(c, frames + (size_t)submitted * c->HW, k, on_device)) != MDH_OK) return rc;
+            submitted += k;
+        }
+        int k = 0;
+        if ((rc = collect_pass(c, info ? info + collected : nullptr,
+                               raw_lines ? raw_lines + (size_t)collected * MAX_LINES * 4 : nullptr,
+                               nms_lines ? nms_lines + (size_t)collected * MAX_LINES * 4 : nullptr,
+                               nonline ? nonline + (size_t)collected * MAX_LINES : nullptr, &k)) != MDH_OK)
             return rc;
-        c->last_K = k;
-        c->last_t_base = c->t;
-        c->t += k;
-        done += k;
+        collected += k;
     }
     return MDH_OK;
 }
 
 extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {
     if (!c || !out) { set_err("mdh_get_binary: null argument"); return MDH_E_ARG; }
-    if (c->last_K <= 0) { set_err("mdh_get_binary: no pass has run yet"); return MDH_E_STATE; }
-    if (index < 0) index = c->last_K - 1;
-    if (index >= c->last_K) { set_err("mdh_get_binary: index beyond the last pass"); return MDH_E_ARG; }
+    if (c->last_slot < 0) { set_err("mdh_get_binary: no pass has been collected yet"); return MDH_E_STATE; }
+    if (c->in_flight) { set_err("mdh_get_binary: collect the submitted passes first"); return MDH_E_STATE; }
+    const Slot& sl = c->slot[c->last_slot];
+    if (index < 0) index = sl.K - 1;
+    if (index >= sl.K) { set_err("mdh_get_binary: index beyond the last pass"); return MDH_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
     const u64* bits;
     if (stage == 0) {
-        bits = c->d_dst + (size_t)index * c->words;
+        bits = sl.d_dst + (size_t)index * c->words;
     } else if (stage == 1 && c->cfg.detector == MDH_DET_M3) {
-        const int64_t t = c->last_t_base + 1 + index;
+        const int64_t t = sl.t_base + 1 + index;
         bits = c->d_act + (size_t)((t - 1) % c->R) * c->words;
     } else {
         set_err("mdh_get_binary: unknown stage");
@@ -730,6 +836,7 @@ extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {
 
 extern "C" int mdh_debug_hough(mdh_ctx* c, long long* out, int K) {
     if (!c || !c->d_hdbg || K > c->Kmax) return MDH_E_ARG;
+    HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, c->d_hdbg, sizeof(long long) * 8 * K, hipMemcpyDeviceToHost));
     return MDH_OK;
 }
@@ -746,7 +853,7 @@ extern "C" void* mdh_device_alloc(mdh_ctx* c, uint64_t bytes) {
 extern "C" int mdh_device_free(mdh_ctx* c, void* p) {
     if (!c) return MDH_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipFree(p));
     return MDH_OK;
 }

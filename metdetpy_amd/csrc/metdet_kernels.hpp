@@ -386,8 +386,10 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
             p[r].u = __builtin_amdgcn_perm(d[r / 4 + DW / 2], d[r / 4], sel);
         }
     };
+    constexpr int GS = 4;                  // window slots per max group
+    constexpr int NG = (N + GS - 1) / GS;  // groups
     PK win[N][RW];
-    u16x2 sum[RW];
+    u16x2 sum[RW], gmax[NG][RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) sum[r] = (u16x2){0, 0};
 #pragma unroll
@@ -398,6 +400,16 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) win[N - 1][r].u = 0;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            u16x2 m = win[gi * GS][r].v;
+#pragma unroll
+            for (int k = gi * GS + 1; k < (gi + 1) * GS && k < N; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
+            gmax[gi][r] = m;
+        }
+    }
     const int e_max = g.K + N - 2;
     // Bursts of U frames; the loads of burst b+1 are issued before burst b is consumed (double buffering), so a
     // wave always has loads in flight while it computes.
@@ -427,34 +439,30 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                         const int i = i0 + s;
                         const unsigned short T = (unsigned short)thr_tab[i];
                         const unsigned short len = (unsigned short)window_len(g, i);
-                        const u16x2 Tv = {T, T}, Lv = {len, len}, one = {1, 1};
+                        const u16x2 Tv = {T, T}, Lv = {len, len};
                         unsigned acc = 0;
-                        u16x2 mx[RW], top = {0, 0};
+                        const int grp = slot / GS;  // the group of 4 window slots the new frame falls into (static after unrolling)
 #pragma unroll
                         for (int r = 0; r < RW; ++r) {
                             sum[r] += a[r].v - win[slot][r].v;
                             win[slot][r] = a[r];
-                            u16x2 m = win[0][r].v;
+                            // two-level max: only the group that changed is re-reduced, then the NG group maxima
+                            u16x2 m = win[grp * GS][r].v;
 #pragma unroll
-                            for (int k = 1; k < N; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
-                            mx[r] = m;
-                            top = __builtin_elementwise_max(top, m);
-                        }
-                        // b needs max > T; on a quiet sky no pixel of the whole wave gets there, so the multiply /
-                        // compare / bit-pack chain is skipped wave-uniformly
-                        PK tp;
-                        tp.v = __builtin_elementwise_sub_sat(top, Tv);
-                        if (__any(tp.u != 0)) {
+                            for (int k = grp * GS + 1; k < (grp + 1) * GS && k < N; ++k)
+                                m = __builtin_elementwise_max(m, win[k][r].v);
+                            gmax[grp][r] = m;
+                            m = gmax[0][r];
 #pragma unroll
-                            for (int r = 0; r < RW; ++r) {
-                                PK z;  // 1 per half where  sum < (max - T) * len
-                                z.v = __builtin_elementwise_min(
-                                    __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(mx[r], Tv) * Lv, sum[r]), one);
-                                acc |= z.u << r;
-                            }
+                            for (int k = 1; k < NG; ++k) m = __builtin_elementwise_max(m, gmax[k][r]);
+                            // sum < (max - T) * len  <=>  bit 15 of the 16-bit difference (all terms < 2^15 for n <= 128)
+                            PK d;
+                            d.v = sum[r] - __builtin_elementwise_sub_sat(m, Tv) * Lv;
+                            acc = (acc >> 1) | (d.u & 0x80008000u);
                         }
-                        // bits 0..RW-1 = pixels 0..RW-1, bits 16..16+RW-1 = pixels RW..PPL-1
-                        const unsigned bits = (acc & ((1u << RW) - 1)) | ((acc >> (16 - RW)) & (((1u << RW) - 1) << RW));
+                        // reg r landed on bit 8+r-(8-RW) ... after RW shifts: low half bits (16-RW)..15 = pixels 0..RW-1,
+                        // high half bits (32-RW)..31 = pixels RW..PPL-1
+                        const unsigned bits = ((acc >> (16 - RW)) & ((1u << RW) - 1)) | ((acc >> (32 - 2 * RW)) & (((1u << RW) - 1) << RW));
                         u64 v = (u64)bits << (q * PPL);
 #pragma unroll
                         for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);

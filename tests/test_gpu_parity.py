@@ -321,3 +321,42 @@ def test_m3_byte_kernel_equals_wide(monkeypatch):
     assert np.array_equal(ia, ib)
     for (l1, p1), (l2, p2) in zip(ra, rb):
         assert np.array_equal(np.asarray(l1).reshape(-1, 4), np.asarray(l2).reshape(-1, 4)) and np.array_equal(p1, p2)
+
+
+def test_submit_collect_pipeline_equals_process_batch():
+    """Two passes in flight (pixel stages of pass p+1 overlap the Hough stage of pass p): same results, same order."""
+    shape, n = (90, 192), 6
+    mask = np.ones(shape, np.uint8)
+    frames = np.stack(busy_frames(77, 60, shape))
+    cfg = binary_cfg(adaptive=False, init_value=9)
+    a = M3Detector(1, n, mask, 10, cfg, None, max_batch=16)
+    want, winfo = a.detect_batch(frames)          # internally chunks of 16, pipelined
+    a.close()
+    b = M3Detector(1, n, mask, 10, cfg, None, max_batch=16)
+    ctx = b._ctx
+    from metdetpy_amd import _lib
+    got = []
+    chunks = [frames[i:i + 16] for i in range(0, 60, 16)]
+    bufs = [np.ascontiguousarray(c) for c in chunks]
+    out = lambda k: (np.zeros(k, _lib.FRAME_INFO_DTYPE), np.zeros((k, 512, 4), np.int32), np.zeros((k, 512, 4), np.int32),
+                     np.zeros((k, 512), np.float64))
+    pending = []
+    for buf in bufs:
+        if ctx.in_flight == 2:
+            o = out(len(pending[0])); ctx.collect_into(*o); got.append(o); pending.pop(0)
+        ctx.submit(buf.ctypes.data, len(buf), False)
+        pending.append(buf)
+    while pending:
+        o = out(len(pending[0])); ctx.collect_into(*o); got.append(o); pending.pop(0)
+    info = np.concatenate([g[0] for g in got])
+    assert np.array_equal(info, winfo)
+    k = 0
+    for g in got:
+        for i in range(len(g[0])):
+            nn = int(g[0][i]["n_nms"])
+            assert np.array_equal(g[2][i][:nn], np.asarray(want[k][0]).reshape(-1, 4))
+            k += 1
+    from metdetpy_amd._lib import MetDetHipError
+    with pytest.raises(MetDetHipError):
+        ctx.collect_into(*out(1))                 # nothing in flight
+    b.close()
