@@ -46,6 +46,8 @@ def parse():
                     "batch repeats them (generation is NumPy on the host and would otherwise dominate the run time)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--parity-frames", type=int, default=64, help="frames of the stream compared against the CPU oracle "
+                    "after the timed region (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     return ap.parse_args()
 
@@ -92,6 +94,39 @@ def cpu_baseline(frames, n, mask, seconds):
     return dict(value=done / dt, unit="frames/s", cores=threads, kind="port",
                 sample=f"{done} frames of the same stream after {warm} warm-up frames, oracle/metdet_oracle.c "
                        f"(gcc -O3 -fopenmp, {threads} threads), host cpu_count={os.cpu_count()}")
+
+
+def parity_check(frames, n, mask, local, count):
+    """Detection parity vs the CPU reference restatement (the metric's second half): a fresh GPU detector and the C
+    port of the oracle see the first `count` frames of the stream; thresholds, lit counts, raw Hough segments (in
+    discovery order) and NMS output must be identical."""
+    from metdetpy_amd import M3Detector
+    from metdetpy_amd.utils import select_std_roi
+    from oracle import c_oracle as co
+    count = min(count, len(frames))
+    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=count)
+    info, raw, nms, prob = det._ctx.process_batch(np.ascontiguousarray(frames[:count]))
+    det.close()
+    co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
+    orc = co.CM3(n, mask, select_std_roi(mask, 0.1))
+    bad, segs = [], 0
+    for i in range(count):
+        orc.update(frames[i])
+        o_raw = orc.detect()
+        thr = orc.state()[0]
+        ok = (int(info[i]["bi_threshold"]) == thr and int(info[i]["lit_count"]) == orc.lit_count
+              and int(info[i]["n_raw"]) == orc.lines_num
+              and np.array_equal(raw[i][:min(orc.lines_num, 512)], o_raw[:512]))
+        if ok and 0 < orc.lines_num <= 500:
+            o_nms, o_prob = co.lineset_nms(o_raw)
+            k = int(info[i]["n_nms"])
+            ok = k == len(o_nms) and np.array_equal(nms[i][:k], o_nms) and np.array_equal(prob[i][:k], o_prob)
+        segs += orc.lines_num
+        if not ok:
+            bad.append(i)
+    return {"frames_checked": count, "raw_segments_checked": segs, "mismatching_frames": bad,
+            "verdict": "identical" if not bad else "MISMATCH",
+            "checked": "bi_threshold, lit_count, raw Hough segments (order included), lineset_nms output vs oracle/metdet_oracle.c"}
 
 
 def main():
@@ -220,6 +255,8 @@ def main():
             out["kernels_ms_per_step"] = {k: v[0] / a.steps for k, v in prof.items() if v[1]}
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, n, mask, a.cpu_seconds)
+        if world == 1 and a.parity_frames > 0:
+            out["parity"] = parity_check(frames, n, mask, local, a.parity_frames)
         print(json.dumps(out), flush=True)
     ctx.device_free(pool)
     det.close()
