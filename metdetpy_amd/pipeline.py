@@ -1,0 +1,86 @@
+"""Stream driver: what `MetDetPy.detect_video`'s main loop does between the loader and the MDRF result
+(MetDetPy.py:183-250), for frames that are already grayscale at runtime size: detector (batched native passes) ->
+MeteorCollector -> list of SingleMDRecord.  Decoding, exposure estimation, the visualiser and the YOLO re-check are
+outside this path."""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import numpy as np
+
+from .collector import MeteorCollector
+from .detector import M3Detector
+from .metstruct import BinaryCfg, CollectorCfg, RuntimeParams
+from .utils import VERSION, get_num_class
+
+
+def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: BinaryCfg, collector_cfg: CollectorCfg,
+                  rt: RuntimeParams, *, window_sec: float = 1.0, batch: int = 64, device: int = 0, logger=None,
+                  detector_cls=M3Detector, start_frame: int = 0):
+    """Feed `frames` (each (H,W) uint8, one per exposure frame) through the detector and the collector exactly in the
+    order the reference's loop does: collector.update(i, lines, cates) when the frame has lines, or on every
+    eq_int_fps-th iteration (MetDetPy.py:200-202); collector.clear() at the end (MetDetPy.py:237).
+    Returns (records, per_frame_info)."""
+    det = detector_cls(window_sec, rt.eq_fps, mask, get_num_class(), detector_cfg, logger, device=device, max_batch=batch)
+    col = MeteorCollector(collector_cfg, rt, None, logger)
+    infos = []
+    it = 0
+    buf = []
+
+    def flush():
+        nonlocal it
+        if not buf:
+            return
+        results, info = det.detect_batch(np.stack(buf))
+        for (lines, cates) in results:
+            i = start_frame + it * rt.exp_frame
+            if len(lines) or (it % rt.eq_int_fps == 0):
+                col.update(i, lines=lines, cates=cates)
+            it += 1
+        infos.append(info)
+        buf.clear()
+
+    for f in frames:
+        buf.append(f)
+        if len(buf) == batch:
+            flush()
+    flush()
+    col.clear()
+    det.close()
+    return col.met_exporter.meteor_list, (np.concatenate(infos) if infos else np.zeros(0))
+
+
+def to_mdrf(records, video_size, rt: RuntimeParams, desc: Optional[str] = None) -> dict:
+    """The `results` part of an MDRF document (metstruct.py:428-441) as plain dicts."""
+    return {"version": VERSION, "type": "prediction", "anno_size": list(video_size),
+            "basic_info": {"resolution": list(rt.raw_size), "runtime_resolution": list(rt.runtime_size), "fps": rt.fps,
+                           "exp_time": rt.exp_time, "desc": desc},
+            "results": [r.to_dict() for r in records]}
+
+
+def calculate_time_iou(a, b) -> float:
+    """evaluate.py:119-139 on [start_frame, last_activate_frame]."""
+    if a.start_frame >= b.last_activate_frame or a.last_activate_frame <= b.start_frame:
+        return 0
+    t = sorted([a.start_frame, a.last_activate_frame, b.start_frame, b.last_activate_frame], reverse=True)
+    return (t[1] - t[2]) / (t[0] - t[3])
+
+
+def calculate_area_iou(b1, b2) -> float:
+    """utils.py:921-953 on Box(x1,y1,x2,y2)."""
+    if b1.x1 == b1.x2 == b2.x1 == b2.x2:
+        oy = sorted([b1.y1, b1.y2, b2.y1, b2.y2], reverse=True)
+        if b1.y1 == b2.y1 and b1.y2 == b2.y2:
+            return 1
+        return (oy[2] - oy[1]) / (oy[3] - oy[0])
+    if b1.y1 == b1.y2 == b2.y1 == b2.y2:
+        ox = sorted([b1.x1, b1.x2, b2.x1, b2.x2], reverse=True)
+        if b1.x1 == b2.x1 and b1.x2 == b2.x2:
+            return 1
+        return (ox[2] - ox[1]) / (ox[3] - ox[0])
+    if b1.x1 >= b2.x2 or b1.x2 <= b2.x1 or b1.y1 >= b2.y2 or b1.y2 <= b2.y1:
+        return 0
+    ix = sorted([b1.x1, b1.x2, b2.x1, b2.x2], reverse=True)[1:-1]
+    iy = sorted([b1.y1, b1.y2, b2.y1, b2.y2], reverse=True)[1:-1]
+    inter = (ix[1] - ix[0]) * (iy[1] - iy[0])
+    return inter / ((b1.x2 - b1.x1) * (b1.y2 - b1.y1) + (b2.x2 - b2.x1) * (b2.y2 - b2.y1) - inter)
