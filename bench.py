@@ -33,6 +33,8 @@ WORKLOADS = {
     "C2": dict(H=1080, W=1920, n=8, seed=20220413, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
     "C3": dict(H=2160, W=3840, n=16, seed=20220414, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
     "C1s": dict(H=540, W=960, n=8, seed=20220412, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
+    "C5": dict(H=4320, W=7680, n=8, seed=20220415, sensitivity="high",
+               desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
 }
 
 
@@ -52,10 +54,13 @@ def parse():
     return ap.parse_args()
 
 
+SENSITIVITY = "normal"
+
+
 def make_cfg():
     from metdetpy_amd import BinaryCfg, BinaryCoreCfg, DynamicCfg, HoughLineCfg
-    # config/m3det_normal.json detector block
-    return BinaryCfg(BinaryCoreCfg(True, 7, "normal", 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
+    # config/m3det_normal.json (or m3det_high.json) detector block
+    return BinaryCfg(BinaryCoreCfg(True, 7, SENSITIVITY, 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
 
 
 def load_mask(H, W):
@@ -74,7 +79,7 @@ def cpu_baseline(frames, n, mask, seconds):
     # the port scales to ~16 threads on the GPU box's host (83 fps at 1080p; 32 threads are slower: the frame-sized
     # loops are memory-bound and the PPHT is serial)
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
-    det = co.CM3(n, mask, roi)
+    det = co.CM3(n, mask, roi, sensitivity=SENSITIVITY)
     threads = int(co.lib().om3_num_threads())
     warm = min(2 * n, len(frames))
     for i in range(warm):
@@ -108,7 +113,7 @@ def parity_check(frames, n, mask, local, count):
     info, raw, nms, prob = det._ctx.process_batch(np.ascontiguousarray(frames[:count]))
     det.close()
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
-    orc = co.CM3(n, mask, select_std_roi(mask, 0.1))
+    orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY)
     bad, segs = [], 0
     for i in range(count):
         orc.update(frames[i])
@@ -142,6 +147,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     wl = WORKLOADS[a.workload]
     H, W, n = wl["H"], wl["W"], wl["n"]
+    global SENSITIVITY
+    SENSITIVITY = wl.get("sensitivity", "normal")
     from metdetpy_amd import M3Detector
     from metdetpy_amd import _lib
     from metdetpy_amd.synth import SkyStream
@@ -232,7 +239,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_normal detector cfg, {B} frames/step resident in HBM, "
+        "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_{SENSITIVITY} detector cfg, {B} frames/step resident in HBM, "
                                f"one independent stream per GPU", "frame": [W, H], "window": n, "frames_per_step": B,
                    "parallelism": f"streams x{world}"},
         "detections": {"raw_segments": tot[0], "nms_segments": tot[1], "lit_pixels": tot[2]},

@@ -137,6 +137,10 @@ void mdh_pre_destroy(mdh_pre* pre);
 int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint8_t* out,
                   int out_on_device);
 
+/* Debug: with MDH_HOUGH_DEBUG=1 in the environment at mdh_create, the Hough kernel records 8 cycle counters per frame
+ * of the last pass (lit pixels, list build, PPHT total, draws, mask checks, votes, trigger scan, line handling). */
+int mdh_debug_hough(mdh_ctx* ctx, long long* out, int K);
+
 /* Frames consumed so far (SlidingWindow.timer). */
 int64_t mdh_frames_seen(const mdh_ctx* ctx);
 

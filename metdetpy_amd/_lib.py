@@ -41,7 +41,7 @@ EXPORTS = [
     "mdh_create", "mdh_destroy", "mdh_last_error", "mdh_update", "mdh_detect", "mdh_process_batch", "mdh_get_binary",
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
-    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight"
+    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_debug_hough"
 ]
 
 _lib = None

@@ -15,7 +15,6 @@
 typedef unsigned long long u64;
 typedef unsigned __int128 u128;
 
-#define MDH_WAVE 64
 #define NUM_ANGLE 180
 #define MAX_LINES 512
 #define MORPH_RB 8  // rows per band of the morphology kernel (and granularity of the "band has set bits" flags)
@@ -801,7 +800,8 @@ struct Ppht {
     float tc[3], ts[3];  // this lane's 3 angles
     int line_gap, frame, found, lane;
     int groups, lines;  // statistics (debug)
-    long long t_shuffle, t_mask, t_vote, t_key, t_line;  // cycle totals per section (debug)
+    long long t_shuffle, t_mask, t_vote, t_key, t_line;  // cycle totals per section (only with MDH_HOUGH_DEBUG)
+    bool timing;
     // LDS-resident part of the accumulator: for angle n the rho bins [lo, hi] live in 16-bit LDS cells starting at
     // `off` (two cells per dword, each biased by CELL_BIAS so that +-1 on one half never carries into the other);
     // bins outside the window stay in the global accumulator.
@@ -1022,7 +1022,7 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
     u64 state = 0xFFFFFFFFFFFFFFFFull;
     int count = N;
     while (count > 0) {
-        const long long ta = clock64();
+        const long long ta = C.timing ? clock64() : 0;
         int gn = count < PPHT_G ? count : PPHT_G;
         u64 st = state, my_state = 0;
         unsigned my_rnd = 0;
@@ -1072,17 +1072,17 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
         }
         count -= gn;
         ++C.groups;
-        C.t_shuffle += clock64() - ta;
+        if (C.timing) C.t_shuffle += clock64() - ta;
         u64 pending = (1ull << gn) - 1;
         const int px = my_pt & 0xFFFF, py = my_pt >> 16;
         while (pending) {
-            const long long tb = clock64();
+            const long long tb = C.timing ? clock64() : 0;
             bool alive = false;
             if ((pending >> lane) & 1) alive = work_bit(C, px, py);
             const u64 am = __ballot(alive);
-            C.t_mask += clock64() - tb;
+            if (C.timing) C.t_mask += clock64() - tb;
             if (!am) break;
-            const long long tc0 = clock64();
+            const long long tc0 = C.timing ? clock64() : 0;
             int old[PPHT_G][3];
 #pragma unroll
             for (int k = 0; k < PPHT_G; ++k) {
@@ -1091,8 +1091,8 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
                     vote_issue(C, pt & 0xFFFF, pt >> 16, old[k]);
                 }
             }
-            const long long td = clock64();
-            C.t_vote += td - tc0;
+            const long long td = C.timing ? clock64() : 0;
+            if (C.timing) C.t_vote += td - tc0;
             int trig = -1;
             unsigned trig_key = 0;
 #pragma unroll
@@ -1105,9 +1105,9 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
                     }
                 }
             }
-            C.t_key += clock64() - td;
+            if (C.timing) C.t_key += clock64() - td;
             if (trig < 0) break;
-            const long long te = clock64();
+            const long long te = C.timing ? clock64() : 0;
             // points after the trigger voted too early: take those votes back, they are re-examined below
             const u64 later = am & ~((2ull << trig) - 1);
 #pragma unroll
@@ -1123,7 +1123,7 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
             for (int k = 0; k < PPHT_G; ++k)
                 if (k == trig) tp = __builtin_amdgcn_readlane(my_pt, k);
             ppht_line(C, tp & 0xFFFF, tp >> 16, 255 - (int)(best & 0xFF));
-            C.t_line += clock64() - te;
+            if (C.timing) C.t_line += clock64() - te;
             pending = later;
         }
     }
@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = P.litcount[i];
-    const long long c0 = clock64();
+    const long long c0 = P.dbg ? clock64() : 0;
     // maxLineGap (Detector.py:342-344) -> cvRound
     double gap = P.max_gap;
     if (!P.fixed_gap) {
@@ -1155,34 +1155,58 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     // Accumulator windows: rho is monotone in x and in y for a fixed angle (rounded float products and sum), so over
     // the bounding box of the lit pixels its extremes are at the corners.  Window sizes decide which launch owns
     // the frame (both launches evaluate the same test) and whether the accumulator lives in LDS at all.
-    int w_lo[3] = {0, 0, 0}, w_span[3] = {-1, -1, -1}, w_off[3] = {0, 0, 0};
+    int w_lo[3] = {0, 0, 0}, w_size[3] = {0, 0, 0}, w_span[3] = {-1, -1, -1}, w_off[3] = {0, 0, 0};
     int cells_needed = 0;
     {
         const int bx0 = P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int n = lane + 64 * q;
-            int size = 0;
             if (n < NUM_ANGLE) {
                 const float c = P.trig[2 * n], sn = P.trig[2 * n + 1];
                 const int r00 = rho_bin(bx0, by0, c, sn, P.half), r10 = rho_bin(bx1, by0, c, sn, P.half);
                 const int r01 = rho_bin(bx0, by1, c, sn, P.half), r11 = rho_bin(bx1, by1, c, sn, P.half);
                 w_lo[q] = min(min(r00, r10), min(r01, r11));
-                size = max(max(r00, r10), max(r01, r11)) - w_lo[q] + 1;
+                w_size[q] = max(max(r00, r10), max(r01, r11)) - w_lo[q] + 1;
             }
+            cells_needed += w_size[q];
+        }
+        for (int o = 32; o > 0; o >>= 1) cells_needed += __shfl_xor(cells_needed, o);
+    }
+    if (P.tier >= 0) {
+        const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
+        if ((P.tier == 0) != fits_small) return;  // the other launch owns this frame
+    }
+    // Which windows live in LDS: all of them if they fit; otherwise the smallest ones (the angles across the streak,
+    // where the votes pile up), found by bisecting the size limit; the remaining angles use the global accumulator.
+    {
+        int limit = 0x7FFFFFFF;
+        if (cells_needed > P.cell_cap) {
+            int lo = 0, hi = P.numrho;  // largest `limit` with sum(size <= limit) <= cell_cap
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                int sum = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sum += w_size[q] <= mid ? w_size[q] : 0;
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                if (sum <= P.cell_cap) lo = mid; else hi = mid - 1;
+            }
+            limit = lo;
+        }
+        int base = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int size = (w_size[q] > 0 && w_size[q] <= limit) ? w_size[q] : 0;
             int incl = size;
             for (int d = 1; d < 64; d <<= 1) {
                 const int tt = __shfl_up(incl, d);
                 if (lane >= d) incl += tt;
             }
-            w_off[q] = cells_needed + incl - size;
+            w_off[q] = base + incl - size;
             w_span[q] = size - 1;
-            cells_needed += __shfl(incl, 63);
+            base += __shfl(incl, 63);
         }
-    }
-    if (P.tier >= 0) {
-        const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
-        if ((P.tier == 0) != fits_small) return;  // the other launch owns this frame
+        cells_needed = base;  // cells actually placed in LDS
     }
     const size_t words = (size_t)P.H * P.WW;
     const u64* dst = P.dst_bits + (size_t)i * words;
@@ -1214,9 +1238,9 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     }
     __threadfence_block();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const long long c1 = clock64();
+    const long long c1 = P.dbg ? clock64() : 0;
     Ppht C{P, P.work_bits + (size_t)i * words, (unsigned*)(P.work_bits + (size_t)i * words),
-           P.accum + (size_t)i * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0, 0, 0, 0, 0, 0,
+           P.accum + (size_t)i * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0, 0, 0, 0, 0, 0, P.dbg != nullptr,
            lds_cells, P.cell_cap / 2, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, {-1, -1, -1}, false};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -1248,7 +1272,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
         ppht_serial<false>(C, N, nzw);
     }
     if (lane == 0) P.out_nraw[i] = C.found;
-    const long long c2 = clock64();
+    const long long c2 = P.dbg ? clock64() : 0;
     // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
     if (__any(C.touched_global)) {
         int* acc = P.accum + (size_t)i * NUM_ANGLE * P.numrho;

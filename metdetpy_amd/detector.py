@@ -157,9 +157,8 @@ class M3Detector(LineDetector):
 
     def _package(self, info, raw, nms, prob):
         n_raw, n_nms = int(info["n_raw"]), int(info["n_nms"])
-        if n_raw > NUM_LINES_TOOMUCH or n_raw == 0:
-            linesp_ext = np.array([]) if n_raw > NUM_LINES_TOOMUCH or n_raw == 0 else raw
-            return linesp_ext, np.array([]), np.zeros((0, self.num_cls))
+        if n_raw > NUM_LINES_TOOMUCH or n_raw == 0:  # nothing found, or the frame is discarded (Detector.py:358-360)
+            return np.array([]), np.array([]), np.zeros((0, self.num_cls))
         cls_pred = np.zeros((n_nms, self.num_cls))
         cls_pred[:, -1] = prob[:n_nms]
         cls_pred[:, 0] = 1 - prob[:n_nms]
