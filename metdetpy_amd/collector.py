@@ -195,13 +195,15 @@ class MeteorSeries:
         self.count += 1
 
     def may_in_series(self, pts, cur_frame):
+        """True when any new point lies within sqrt(max_acceptable_dist) of a point seen in the last max_acti_frame
+        frames (collector.py:357-369).  Same integer comparisons as the reference's double loop, vectorised."""
         recent = np.where(self.coord_list.frame_num >= cur_frame - self.max_acti_frame)[0]
-        first = len(self.coord_list.frame_num) if len(recent) == 0 else recent[0]
-        for p in pts:
-            for q in self.coord_list[first:]:
-                if pt_len_sqr(p, q) < self.max_acceptable_dist:
-                    return True
-        return False
+        if len(recent) == 0:
+            return False
+        old = self.coord_list.pts[recent[0]:]
+        new = np.asarray(pts)
+        d2 = (new[:, None, 1] - old[None, :, 1])**2 + (new[:, None, 0] - old[None, :, 0])**2
+        return bool(np.any(d2 < self.max_acceptable_dist))
 
 
 class _Joinable:
