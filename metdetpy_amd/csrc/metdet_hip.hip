@@ -94,7 +94,6 @@ struct mdh_ctx {
     u64 *d_bbits = nullptr, *d_act = nullptr, *d_planes = nullptr;
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;  // words of act with lit pixels (sparse dynamic-mask pass)
-    int* h_bbox_init = nullptr;
     // Hough-private buffers (Hough stages of consecutive passes run one after the other)
     u64* d_work = nullptr;
     int* d_accum = nullptr;
@@ -151,9 +150,8 @@ static void free_all(mdh_ctx* c) {
                    c->d_nz_work, c->d_trig, c->d_hdbg, c->d_expand};
     for (void* p : dev)
         if (p) hipFree(p);
-    if (c->h_bbox_init) hipHostFree(c->h_bbox_init);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_dst, s.d_rowcount, s.d_litcount, s.d_bbox, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap};
+        void* sdev[] = {s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap};
         for (void* p : sdev)
             if (p) hipFree(p);
         void* shost[] = {s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
@@ -205,19 +203,15 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
-    TRY(host_alloc(c->h_bbox_init, 4 * K));
-    for (size_t k = 0; k < K; ++k) {
-        c->h_bbox_init[4 * k + 0] = 0x7FFFFFFF; c->h_bbox_init[4 * k + 1] = -1;
-        c->h_bbox_init[4 * k + 2] = 0x7FFFFFFF; c->h_bbox_init[4 * k + 3] = -1;
-    }
     for (Slot& s : c->slot) {
         TRY(host_alloc(s.h_ptrtab, c->n - 1 + K));
         TRY(host_alloc(s.h_jobs, K));
         TRY(dev_alloc(s.d_dst, K * words));
-        TRY(dev_alloc(s.d_rowcount, K * c->H));
-        TRY(dev_alloc(s.d_litcount, K));
+        // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
+        TRY(dev_alloc(s.d_rowcount, K * c->H + 5 * K));
+        s.d_litcount = s.d_rowcount + K * c->H;
+        s.d_bbox = s.d_litcount + K;
         TRY(host_alloc(s.h_litcount, K));
-        TRY(dev_alloc(s.d_bbox, 4 * K));
         TRY(dev_alloc(s.d_fscal, K));
         TRY(host_alloc(s.h_fscal, K));
         TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
@@ -525,10 +519,8 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     PassGeom g = geom(c, K, t_base);
     const int words = (int)c->words;
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
-    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * (size_t)K * c->H, c->stream));
-    HIPCHK(hipMemsetAsync(sl.d_litcount, 0, sizeof(int) * K, c->stream));
-    HIPCHK(hipMemcpyAsync(sl.d_bbox, c->h_bbox_init, sizeof(int) * 4 * K, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * (size_t)K * nb * c->WW, c->stream));
+    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * ((size_t)K * nb * c->WW), c->stream));
     HIPCHK(hipMemsetAsync(c->d_nzcount, 0, sizeof(unsigned), c->stream));
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
@@ -596,6 +588,15 @@ static int retire_frames(mdh_ctx* c, Slot& sl, int K, int on_device) {
     const int64_t t_base = sl.t_base;
     const int keep = c->n - 1;
     std::vector<const uint8_t*> nh(keep);
+    int run_i = -1, run_len = 0;  // pending run of pass frames to copy (contiguous in the caller's buffer and in the ring)
+    auto flush = [&]() -> int {
+        if (run_len > 0) {
+            uint8_t* rs = c->d_ring + (size_t)((t_base + run_i) % c->R) * c->HW;
+            HIPCHK(hipMemcpyAsync(rs, sl.h_ptrtab[keep + run_i], (size_t)run_len * c->HW, hipMemcpyDeviceToDevice, c->stream));
+        }
+        run_len = 0;
+        return MDH_OK;
+    };
     for (int e = 0; e < keep; ++e) {
         // entry e of the new history = table entry K + e of this pass
         const int src = K + e;
@@ -603,12 +604,22 @@ static int retire_frames(mdh_ctx* c, Slot& sl, int K, int on_device) {
             nh[e] = c->hist[src];
         } else {
             const int i = src - keep;
-            uint8_t* rs = c->d_ring + (size_t)((t_base + i) % c->R) * c->HW;
-            if (on_device)
-                HIPCHK(hipMemcpyAsync(rs, sl.h_ptrtab[keep + i], c->HW, hipMemcpyDeviceToDevice, c->stream));
-            nh[e] = rs;
+            const int64_t ring_slot = (t_base + i) % c->R;
+            nh[e] = c->d_ring + (size_t)ring_slot * c->HW;
+            if (on_device) {
+                if (run_len > 0 && i == run_i + run_len && ring_slot != 0) {
+                    ++run_len;
+                } else {
+                    int rc = flush();
+                    if (rc != MDH_OK) return rc;
+                    run_i = i;
+                    run_len = 1;
+                }
+            }
         }
     }
+    int rc = flush();
+    if (rc != MDH_OK) return rc;
     c->hist.swap(nh);
     return MDH_OK;
 }

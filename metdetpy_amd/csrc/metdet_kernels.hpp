@@ -651,10 +651,11 @@ __global__ void __launch_bounds__(256) k_dy_sparse(const u64* __restrict__ act_r
             const int c = __popcll(out);
             atomicAdd(&rowcount[i * g.H + y], c);
             atomicAdd(&litcount[i], c);
-            // bounding box of the lit pixels of the frame: {min x, max x, min y, max y}
-            atomicMin(&bbox[4 * i + 0], w * 64 + __builtin_ctzll(out));
+            // bounding box of the lit pixels of the frame, kept as four running maxima so that a zero fill is the
+            // neutral start: {W-1 - min x, max x, H-1 - min y, max y}
+            atomicMax(&bbox[4 * i + 0], g.W - 1 - (w * 64 + __builtin_ctzll(out)));
             atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(out));
-            atomicMin(&bbox[4 * i + 2], y);
+            atomicMax(&bbox[4 * i + 2], g.H - 1 - y);
             atomicMax(&bbox[4 * i + 3], y);
         }
     }
@@ -736,10 +737,10 @@ __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__
         const int c = __popcll(out);
         atomicAdd(&rowcount[i * g.H + y], c);
         atomicAdd(&litcount[i], c);
-        // bounding box of the lit pixels of the frame: {min x, max x, min y, max y}
-        atomicMin(&bbox[4 * i + 0], w * 64 + __builtin_ctzll(out));
+        // bounding box of the lit pixels, as four running maxima: {W-1 - min x, max x, H-1 - min y, max y}
+        atomicMax(&bbox[4 * i + 0], g.W - 1 - (w * 64 + __builtin_ctzll(out)));
         atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(out));
-        atomicMin(&bbox[4 * i + 2], y);
+        atomicMax(&bbox[4 * i + 2], g.H - 1 - y);
         atomicMax(&bbox[4 * i + 3], y);
     }
 }
@@ -774,7 +775,7 @@ struct HoughParams {
     int cell_cap;          // LDS accumulator capacity of this launch (16-bit cells, even)
     int tier;              // 0: small-LDS launch, takes the frames that fit it; 1: big-LDS launch, takes the others; -1: all
     int small_list, small_cells;  // capacities of the small-LDS launch (the tier decision both launches make)
-    const int* bbox;       // [K][4] {min x, max x, min y, max y} of the lit pixels
+    const int* bbox;       // [K][4] {W-1 - min x, max x, H-1 - min y, max y} of the lit pixels
 };
 
 
@@ -1158,7 +1159,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     int w_lo[3] = {0, 0, 0}, w_size[3] = {0, 0, 0}, w_span[3] = {-1, -1, -1}, w_off[3] = {0, 0, 0};
     int cells_needed = 0;
     {
-        const int bx0 = P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
+        const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int n = lane + 64 * q;
