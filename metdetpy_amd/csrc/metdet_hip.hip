@@ -116,6 +116,7 @@ struct mdh_ctx {
     bool force_ppl8 = false;        // MDH_FORCE_PPL8=1: 8 pixels per lane even when 16 would do
     bool hough_serial = false;      // MDH_HOUGH_SERIAL=1: one-point-at-a-time PPHT replay
     bool hough_global_acc = false;  // MDH_HOUGH_GLOBAL_ACC=1: never use the LDS accumulator windows
+    bool hough_one_wave = false;    // MDH_HOUGH_ONE_WAVE=1: one wave per frame instead of a 256-thread workgroup
     // profiling
     bool prof = false;
     std::vector<ProfSpan>* cur_spans = nullptr;
@@ -226,6 +227,8 @@ static int create_impl(mdh_ctx* c) {
 #undef TRY
     HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (8192 + 61440 / 2 + 64) * (int)sizeof(unsigned)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht4, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (8192 + 61440 / 2 + HOUGH4_EXTRA_DWORDS) * (int)sizeof(unsigned)));
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
     const float theta = (float)(3.14159265358979323846 / 180.0);
@@ -306,6 +309,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->force_ppl8 = env_on("MDH_FORCE_PPL8");
     c->hough_serial = env_on("MDH_HOUGH_SERIAL");
     c->hough_global_acc = env_on("MDH_HOUGH_GLOBAL_ACC");
+    c->hough_one_wave = env_on("MDH_HOUGH_ONE_WAVE") || c->hough_serial;
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
         free_all(c);
@@ -557,7 +561,7 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     P.accum = c->d_accum; P.nz_orig = c->d_nz_orig; P.nz_work = c->d_nz_work; P.nz_cap = (long long)c->HW;
     P.out_lines = sl.d_lines; P.out_nraw = sl.d_nraw; P.out_gap = sl.d_gap; P.trig = c->d_trig;
     P.bbox = sl.d_bbox;
-    P.small_list = 4096; P.small_cells = 32000;
+    P.big_list = 8192;
     // Hough: a small-LDS launch (2 frames per CU) takes the frames whose point list and accumulator windows fit it, a
     // big-LDS launch (1 frame per CU) takes the rest; both evaluate the same fit test from the lit count and bounding
     // box, so they run side by side.  They start once this pass's pixel stages are done and the previous pass's Hough
@@ -567,11 +571,26 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
         if (c->last_hough_slot >= 0) HIPCHK(hipStreamWaitEvent(c->hstream[h], c->slot[c->last_hough_slot].ev_done, 0));
     }
     span_begin(c, KK_HOUGH, c->hstream[0]);
-    P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
-    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[1], P);
-    HIPCHK(hipEventRecord(c->ev_big, c->hstream[1]));
-    P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
-    hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[0], P);
+    if (c->hough_one_wave) {
+        P.small_list = 4096; P.small_cells = 32000;
+        P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
+        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[1], P);
+        HIPCHK(hipEventRecord(c->ev_big, c->hstream[1]));
+        P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
+        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[0], P);
+    } else {
+        // four waves per frame; frames with more than big_list lit pixels go to the one-wave kernel's global-list path
+        P.small_list = 4096; P.small_cells = 31000;
+        P.tier = 1; P.list_cap = P.big_list; P.cell_cap = 61440;
+        hipLaunchKernelGGL(k_hough_ppht4, dim3(K), dim3(256), (P.list_cap + P.cell_cap / 2 + HOUGH4_EXTRA_DWORDS) * sizeof(unsigned),
+                           c->hstream[1], P);
+        P.tier = 2; P.list_cap = 0; P.cell_cap = 0;  // global point list, global accumulator, 64 dummy dwords of LDS
+        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (64 + 64) * sizeof(unsigned), c->hstream[1], P);
+        HIPCHK(hipEventRecord(c->ev_big, c->hstream[1]));
+        P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
+        hipLaunchKernelGGL(k_hough_ppht4, dim3(K), dim3(256), (P.list_cap + P.cell_cap / 2 + HOUGH4_EXTRA_DWORDS) * sizeof(unsigned),
+                           c->hstream[0], P);
+    }
     HIPCHK(hipStreamWaitEvent(c->hstream[0], c->ev_big, 0));
     span_end(c, c->hstream[0]);
     HIPCHK(hipGetLastError());

@@ -773,8 +773,10 @@ struct HoughParams {
     long long* dbg;        // optional [K][8] cycle stamps (MDH_HOUGH_DEBUG=1), else null
     int list_cap;          // LDS point-list capacity of this launch (dwords)
     int cell_cap;          // LDS accumulator capacity of this launch (16-bit cells, even)
-    int tier;              // 0: small-LDS launch, takes the frames that fit it; 1: big-LDS launch, takes the others; -1: all
+    int tier;              // 0: small-LDS launch, takes the frames that fit it; 1: big-LDS launch, takes the others;
+                           // 2 (one-wave kernel only): just the frames with more points than big_list; -1: all
     int small_list, small_cells;  // capacities of the small-LDS launch (the tier decision both launches make)
+    int big_list;          // point-list capacity of the big-LDS launch; frames beyond it use the one-wave global-list path
     const int* bbox;       // [K][4] {W-1 - min x, max x, H-1 - min y, max y} of the lit pixels
 };
 
@@ -1174,7 +1176,9 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
         }
         for (int o = 32; o > 0; o >>= 1) cells_needed += __shfl_xor(cells_needed, o);
     }
-    if (P.tier >= 0) {
+    if (P.tier == 2) {
+        if (N <= P.big_list) return;  // handled by the four-wave launches
+    } else if (P.tier >= 0) {
         const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
         if ((P.tier == 0) != fits_small) return;  // the other launch owns this frame
     }
@@ -1300,4 +1304,429 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
         long long* d = P.dbg + (size_t)i * 8;
         d[0] = N; d[1] = c1 - c0; d[2] = c2 - c1; d[3] = C.t_shuffle; d[4] = C.t_mask; d[5] = C.t_vote; d[6] = C.t_key; d[7] = C.t_line;
     }
+}
+
+// ================================================================================================
+// Four-wave PPHT: the same exact replay, but one 256-thread workgroup per frame.  Thread t owns angle t (180 of
+// the 256 lanes), so a vote / un-vote is ONE rho + ONE LDS atomic per lane and the four SIMDs of the CU work on the
+// same point.  Everything that decides control flow (draws, swap-removes, mask bits, trigger) is computed identically
+// by every wave from the same data; what must happen once (list writes, mask clears, output) is done by wave 0; the
+// per-point "did any angle reach the threshold" and the arg-max cross the waves through a small LDS mailbox.
+// Barriers per group of <= 16 points: two (list reads | list writes + votes | decision).
+struct Ppht4 {
+    const HoughParams& P;
+    u64* work;
+    unsigned* work32;
+    int* acc;
+    float tc, ts;        // this thread's angle
+    int n;               // angle index (= thread id); n >= 180: no angle
+    int lo, span, off;   // its LDS window (span < 0: none)
+    int line_gap, frame, found, lane, wave;
+    unsigned* cells;
+    int dummy_base;
+    unsigned* mbox;      // [0..7] hit masks [parity][wave], [8..11] keys, [12..15] flags
+    bool touched_global;
+};
+
+__device__ __forceinline__ bool work_bit4(const Ppht4& C, int x, int y) {
+    return (ld_l2(&C.work[(size_t)y * C.P.WW + (x >> 6)]) >> (x & 63)) & 1;
+}
+
+__device__ __forceinline__ int vote4(Ppht4& C, int x, int y) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts))) + C.P.half;
+    const unsigned d = (unsigned)(r - C.lo);
+    const bool inwin = C.span >= 0 && d <= (unsigned)C.span;
+    const int c = C.off + (int)d;
+    const int sh = (c & 1) * 16;
+    const unsigned o = atomicAdd(&C.cells[inwin ? (c >> 1) : C.dummy_base + (int)threadIdx.x], inwin ? (1u << sh) : 0u);
+    int old = inwin ? (int)((o >> sh) & 0xFFFFu) - CELL_BIAS : -KEY_BIAS - 1;
+    const bool outside = !inwin && C.n < NUM_ANGLE;
+    if (__any(outside)) {
+        if (outside) {
+            old = atomicAdd(&C.acc[(size_t)C.n * C.P.numrho + r], 1);
+            C.touched_global = true;
+        }
+    }
+    return old;
+}
+__device__ __forceinline__ void unvote4(Ppht4& C, int x, int y) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts))) + C.P.half;
+    const unsigned d = (unsigned)(r - C.lo);
+    const bool inwin = C.span >= 0 && d <= (unsigned)C.span;
+    const int c = C.off + (int)d;
+    atomicSub(&C.cells[inwin ? (c >> 1) : C.dummy_base + (int)threadIdx.x], inwin ? (1u << ((c & 1) * 16)) : 0u);
+    const bool outside = !inwin && C.n < NUM_ANGLE;
+    if (__any(outside)) {
+        if (outside) {
+            atomicSub(&C.acc[(size_t)C.n * C.P.numrho + r], 1);
+            C.touched_global = true;
+        }
+    }
+}
+__device__ __forceinline__ unsigned key4(const Ppht4& C, int old) {
+    return ((unsigned)(old + 1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.n < 256 ? C.n : 255));
+}
+
+// Line extraction, identical in every wave; wave 0 clears the mask bits.  Ends with a barrier, so mask reads that
+// follow see the clears.
+__device__ void ppht4_line(Ppht4& C, int x, int y, int bn) {
+    const HoughParams& P = C.P;
+    const int lane = C.lane;
+    const float a = -P.trig[2 * bn + 1], b = P.trig[2 * bn];
+    int x0 = x, y0 = y, dx0, dy0;
+    bool xflag;
+    if (fabsf(a) > fabsf(b)) {
+        xflag = true;
+        dx0 = a > 0 ? 1 : -1;
+        dy0 = __float2int_rn(__fdiv_rn(__fmul_rn(b, 65536.f), fabsf(a)));
+        y0 = (y0 << 16) + 32768;
+    } else {
+        xflag = false;
+        dy0 = b > 0 ? 1 : -1;
+        dx0 = __float2int_rn(__fdiv_rn(__fmul_rn(a, 65536.f), fabsf(b)));
+        x0 = (x0 << 16) + 32768;
+    }
+    int end_step[2], end_x[2], end_y[2];
+    for (int k = 0; k < 2; ++k) {
+        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+        int gap = 0, last_lit = 0;
+        bool done = false;
+        for (int s0 = 0; !done; s0 += 64) {
+            const int s = s0 + lane;
+            const int X = x0 + dx * s, Y = y0 + dy * s;
+            const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
+            const bool inside = j1 >= 0 && j1 < P.W && i1 >= 0 && i1 < P.H;
+            bool lit = false;
+            if (inside) lit = work_bit4(C, j1, i1);
+            const u64 mi = __ballot(inside), ml = __ballot(lit);
+            const int n_in = mi == ~0ull ? 64 : __builtin_ctzll(~mi);
+            int pos = 0;
+            while (pos < n_in) {
+                const u64 rest = ml >> pos;
+                if (rest & 1) {
+                    const u64 inv = ~rest;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    run = min(run, n_in - pos);
+                    pos += run;
+                    last_lit = s0 + pos - 1;
+                    gap = 0;
+                } else {
+                    int run = rest ? __builtin_ctzll(rest) : 64;
+                    run = min(run, n_in - pos);
+                    if (gap + run > C.line_gap) { done = true; break; }
+                    gap += run;
+                    pos += run;
+                }
+            }
+            if (!done && n_in < 64) done = true;
+        }
+        end_step[k] = last_lit;
+        const int X = x0 + dx * last_lit, Y = y0 + dy * last_lit;
+        end_x[k] = xflag ? X : X >> 16;
+        end_y[k] = xflag ? Y >> 16 : Y;
+    }
+    const bool good = abs(end_x[1] - end_x[0]) >= P.line_length || abs(end_y[1] - end_y[0]) >= P.line_length;
+    for (int k = 0; k < 2; ++k) {
+        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+        for (int s0 = 0; s0 <= end_step[k]; s0 += 64) {
+            const int s = s0 + lane;
+            bool was = false;
+            int j1 = 0, i1 = 0;
+            if (s <= end_step[k]) {
+                const int X = x0 + dx * s, Y = y0 + dy * s;
+                j1 = xflag ? X : X >> 16;
+                i1 = xflag ? Y >> 16 : Y;
+                was = work_bit4(C, j1, i1);
+            }
+            u64 ms = __ballot(was);   // the same in every wave: nobody has cleared these pixels yet
+            __syncthreads();          // every wave has read the chunk
+            if (C.wave == 0 && was)
+                atomicAnd(&C.work32[((size_t)i1 * P.WW + (j1 >> 6)) * 2 + ((j1 >> 5) & 1)], ~(1u << (j1 & 31)));
+            if (good) {
+                while (ms) {
+                    const int bb = __builtin_ctzll(ms);
+                    ms &= ms - 1;
+                    const int sb = s0 + bb;
+                    const int X = x0 + dx * sb, Y = y0 + dy * sb;
+                    unvote4(C, xflag ? X : X >> 16, xflag ? Y >> 16 : Y);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the clears of this direction are done before anybody reads the mask again
+    }
+    if (good) {
+        if (C.found < MAX_LINES && threadIdx.x == 0) {
+            int* o = P.out_lines + ((size_t)C.frame * MAX_LINES + C.found) * 4;
+            o[0] = end_x[0]; o[1] = end_y[0]; o[2] = end_x[1]; o[3] = end_y[1];
+        }
+        ++C.found;
+    }
+}
+
+__device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
+    const int lane = C.lane;
+    u64 state = 0xFFFFFFFFFFFFFFFFull;
+    int count = N;
+    unsigned round = 0;
+    while (count > 0) {
+        int gn = count < PPHT_G ? count : PPHT_G;
+        u64 st = state, my_state = 0;
+        unsigned my_rnd = 0;
+#pragma unroll
+        for (int k = 0; k < PPHT_G; ++k) {
+            if (k < gn) {
+                st = rng_step(st);
+                if (lane == k) {
+                    my_rnd = (unsigned)st;
+                    my_state = st;
+                }
+            }
+        }
+        const bool in_grp = lane < gn;
+        const int my_idx = in_grp ? (int)(my_rnd % (unsigned)(count - lane)) : -1 - lane;
+        int lim = in_grp ? count - 1 - my_idx : PPHT_G;
+#pragma unroll
+        for (int j = 0; j < PPHT_G - 1; ++j) {
+            const int v = __builtin_amdgcn_readlane(my_idx, j);
+            if (in_grp && j < lane && v == my_idx) lim = lane < lim ? lane : lim;
+        }
+        const int g = min(gn, (int)row16_min_lane15((unsigned)lim));
+        unsigned my_pt = 0, wr_val = 0;
+        int wr_idx = -1;
+        if (g == 0) {  // the first draw removes the last element itself: ordinary serial step
+            state = rng_step(state);
+            const int idx = (int)((unsigned)state % (unsigned)count);
+            my_pt = list[idx];
+            wr_val = list[count - 1];
+            if (lane == 0) wr_idx = idx;
+            gn = 1;
+        } else {
+            if (lane < g) {
+                my_pt = list[my_idx];
+                wr_val = list[count - 1 - lane];
+                wr_idx = my_idx;
+            }
+            gn = g;
+#pragma unroll
+            for (int k = 0; k < PPHT_G; ++k)
+                if (k == g - 1)
+                    state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), k) << 32) |
+                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, k);
+        }
+        __syncthreads();  // every wave holds the drawn points; the list may change now
+        if (C.wave == 0 && wr_idx >= 0) list[wr_idx] = wr_val;
+        count -= gn;
+        u64 pending = (1ull << gn) - 1;
+        const int px = my_pt & 0xFFFF, py = my_pt >> 16;
+        while (true) {
+            bool alive = false;
+            if ((pending >> lane) & 1) alive = work_bit4(C, px, py);
+            const u64 am = __ballot(alive);
+            unsigned hits = 0;
+            unsigned keys[PPHT_G];
+            if (am) {
+                int old[PPHT_G];
+#pragma unroll
+                for (int k = 0; k < PPHT_G; ++k) {
+                    if ((am >> k) & 1) {
+                        const unsigned pt = __builtin_amdgcn_readlane(my_pt, k);
+                        old[k] = vote4(C, pt & 0xFFFF, pt >> 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PPHT_G; ++k) {
+                    keys[k] = 0;
+                    if ((am >> k) & 1) {
+                        keys[k] = key4(C, old[k]);
+                        if (__any(key_value(keys[k]) >= C.P.threshold)) hits |= 1u << k;
+                    }
+                }
+            }
+            if (lane == 0) C.mbox[(round & 1) * 4 + C.wave] = hits;
+            __syncthreads();  // also: the list writes above are visible to the next group's reads
+            const unsigned H = C.mbox[(round & 1) * 4] | C.mbox[(round & 1) * 4 + 1] | C.mbox[(round & 1) * 4 + 2] |
+                               C.mbox[(round & 1) * 4 + 3];
+            ++round;
+            if (!H) break;
+            const int trig = __builtin_ctz(H);
+            // points after the trigger voted too early: take those votes back, they are re-examined below
+            const u64 later = am & ~((2ull << trig) - 1);
+#pragma unroll
+            for (int k = 1; k < PPHT_G; ++k) {
+                if ((later >> k) & 1) {
+                    const unsigned pt = __builtin_amdgcn_readlane(my_pt, k);
+                    unvote4(C, pt & 0xFFFF, pt >> 16);
+                }
+            }
+            unsigned kt = 0, tp = 0;
+#pragma unroll
+            for (int k = 0; k < PPHT_G; ++k) {
+                if (k == trig) {
+                    kt = keys[k];
+                    tp = __builtin_amdgcn_readlane(my_pt, k);
+                }
+            }
+            const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(kt, 0);
+            if (lane == 0) C.mbox[8 + C.wave] = wmax;
+            __syncthreads();
+            const unsigned best = max(max(C.mbox[8], C.mbox[9]), max(C.mbox[10], C.mbox[11]));
+            ppht4_line(C, tp & 0xFFFF, tp >> 16, 255 - (int)(best & 0xFF));  // ends with a barrier
+            pending = later;
+            if (!pending) break;
+        }
+    }
+}
+
+// LDS: [ point list: list_cap | cells: cell_cap/2 | 256 dummy | 16 mailbox | 180*3 window table ]  (dwords)
+#define HOUGH4_EXTRA_DWORDS (256 + 16 + 3 * NUM_ANGLE)
+__global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    unsigned* lds_list = lds_dyn;
+    unsigned* lds_cells = lds_dyn + P.list_cap;
+    unsigned* mbox = lds_cells + P.cell_cap / 2 + 256;
+    int* wtab = (int*)(mbox + 16);
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = P.litcount[i];
+    double gap = P.max_gap;
+    if (!P.fixed_gap) {
+        const double dst_sum = (double)N / P.mask_area * 100;
+        double gg = 1 - dst_sum / 0.05;
+        if (gg < 0) gg = 0;
+        gap = gg * P.max_gap;
+    }
+    const int line_gap = (int)rint(gap);
+    if (tid == 0 && P.tier == 0) P.out_gap[i] = gap;
+    if (N == 0) {
+        if (tid == 0 && P.tier == 0) P.out_nraw[i] = 0;
+        return;
+    }
+    if (N > P.big_list) return;  // more points than any LDS list holds: the one-wave kernel's global-list path
+    // ---- wave 0: accumulator windows from the bounding box (see k_hough_ppht), published through LDS ----
+    if (wave == 0) {
+        int w_lo[3] = {0, 0, 0}, w_size[3] = {0, 0, 0};
+        int cells_needed = 0;
+        const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = lane + 64 * q;
+            if (n < NUM_ANGLE) {
+                const float c = P.trig[2 * n], sn = P.trig[2 * n + 1];
+                const int r00 = rho_bin(bx0, by0, c, sn, P.half), r10 = rho_bin(bx1, by0, c, sn, P.half);
+                const int r01 = rho_bin(bx0, by1, c, sn, P.half), r11 = rho_bin(bx1, by1, c, sn, P.half);
+                w_lo[q] = min(min(r00, r10), min(r01, r11));
+                w_size[q] = max(max(r00, r10), max(r01, r11)) - w_lo[q] + 1;
+            }
+            cells_needed += w_size[q];
+        }
+        for (int o = 32; o > 0; o >>= 1) cells_needed += __shfl_xor(cells_needed, o);
+        const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
+        const bool mine = P.tier < 0 || ((P.tier == 0) == fits_small);
+        int limit = 0x7FFFFFFF;
+        if (mine && cells_needed > P.cell_cap) {
+            int lo = 0, hi = P.numrho;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                int sum = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sum += w_size[q] <= mid ? w_size[q] : 0;
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                if (sum <= P.cell_cap) lo = mid; else hi = mid - 1;
+            }
+            limit = lo;
+        }
+        int base = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = lane + 64 * q;
+            const int size = (w_size[q] > 0 && w_size[q] <= limit && !P.no_lds_acc) ? w_size[q] : 0;
+            int incl = size;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tt = __shfl_up(incl, d);
+                if (lane >= d) incl += tt;
+            }
+            if (n < NUM_ANGLE) {
+                wtab[3 * n + 0] = w_lo[q];
+                wtab[3 * n + 1] = size - 1;
+                wtab[3 * n + 2] = base + incl - size;
+            }
+            base += __shfl(incl, 63);
+        }
+        if (lane == 0) {
+            mbox[12] = mine ? 1u : 0u;
+            mbox[13] = (unsigned)base;
+        }
+    }
+    __syncthreads();
+    if (!mbox[12]) return;  // the other launch owns this frame
+    const int cells_used = (int)mbox[13];
+    const size_t words = (size_t)P.H * P.WW;
+    const u64* dst = P.dst_bits + (size_t)i * words;
+    u64* wrk = P.work_bits + (size_t)i * words;
+    unsigned* nzo = P.nz_orig + (size_t)i * P.nz_cap;
+    // ---- wave 0: row-major point list + working copy of the lit rows; the others initialise the cells ----
+    if (wave == 0) {
+        int total = 0;
+        for (int yb = 0; yb < P.H; yb += 64) {
+            const int y = yb + lane;
+            const int c = y < P.H ? P.rowcount[i * P.H + y] : 0;
+            int incl = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tt = __shfl_up(incl, d);
+                if (lane >= d) incl += tt;
+            }
+            if (c > 0) {
+                int pos = total + incl - c;
+                for (int w = 0; w < P.WW; ++w) {
+                    u64 word = dst[(size_t)y * P.WW + w];
+                    wrk[(size_t)y * P.WW + w] = word;
+                    while (word) {
+                        const int bpos = __builtin_ctzll(word);
+                        word &= word - 1;
+                        const unsigned pt = ((unsigned)y << 16) | (unsigned)(w * 64 + bpos);
+                        nzo[pos] = pt;
+                        lds_list[pos] = pt;
+                        ++pos;
+                    }
+                }
+            }
+            total += __shfl(incl, 63);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        for (int p = tid - 64; p < (cells_used + 1) / 2; p += 192) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
+    }
+    Ppht4 C{P, wrk, (unsigned*)wrk, P.accum + (size_t)i * NUM_ANGLE * P.numrho, 0.f, 0.f, tid, 0, -1, 0,
+            line_gap, i, 0, lane, wave, lds_cells, P.cell_cap / 2, mbox, false};
+    if (tid < NUM_ANGLE) {
+        C.tc = P.trig[2 * tid];
+        C.ts = P.trig[2 * tid + 1];
+    }
+    __syncthreads();
+    if (tid < NUM_ANGLE) {
+        C.lo = wtab[3 * tid];
+        C.span = wtab[3 * tid + 1];
+        C.off = wtab[3 * tid + 2];
+    }
+    ppht4_grouped(C, N, lds_list);
+    if (tid == 0) P.out_nraw[i] = C.found;
+    // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
+    const unsigned long long any_global = __ballot(C.touched_global);
+    if (lane == 0) mbox[12 + wave] = any_global ? 1u : 0u;  // (mbox[12], [13] are no longer needed)
+    __syncthreads();
+    if (mbox[12] | mbox[13] | mbox[14] | mbox[15]) {
+        for (int p = 0; p < N; ++p) {
+            const unsigned pt = ld_l2(&nzo[p]);
+            const int x = pt & 0xFFFF, y = pt >> 16;
+            if (tid < NUM_ANGLE) {
+                const int r = rho_bin(x, y, C.tc, C.ts, P.half);
+                if (C.span < 0 || (unsigned)(r - C.lo) > (unsigned)C.span) C.acc[(size_t)tid * P.numrho + r] = 0;
+            }
+        }
+    }
+    // the working mask is all-zero between passes: clear the rows that were copied in
+    for (int y = tid; y < P.H; y += 256)
+        if (P.rowcount[i * P.H + y] > 0)
+            for (int w = 0; w < P.WW; ++w) wrk[(size_t)y * P.WW + w] = 0;
 }

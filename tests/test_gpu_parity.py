@@ -360,3 +360,12 @@ def test_submit_collect_pipeline_equals_process_batch():
     with pytest.raises(MetDetHipError):
         ctx.collect_into(*out(1))                 # nothing in flight
     b.close()
+
+
+def test_hough_one_wave_kernel_still_exact(monkeypatch):
+    """MDH_HOUGH_ONE_WAVE=1 selects the one-wave-per-frame kernel (the default is a 256-thread workgroup)."""
+    monkeypatch.setenv("MDH_HOUGH_ONE_WAVE", "1")
+    shape, n = (135, 240), 8
+    mask = np.ones(shape, np.uint8)
+    total = run_pair(busy_frames(17, 24, shape), n, mask, binary_cfg(adaptive=False, init_value=9), batch=24, max_batch=24)
+    assert total > 0
