@@ -52,6 +52,8 @@ def lib():
         L.om3_num_threads.restype = C.c_int
         L.om3_set_threads.argtypes = [C.c_int]
         L.om3_set_threads.restype = None
+        # small frames and hundreds of host cores do not mix: cap the OpenMP team (bench.py raises it explicitly)
+        L.om3_set_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
         _lib = L
     return _lib
 

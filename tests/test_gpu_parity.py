@@ -369,3 +369,49 @@ def test_hough_one_wave_kernel_still_exact(monkeypatch):
     mask = np.ones(shape, np.uint8)
     total = run_pair(busy_frames(17, 24, shape), n, mask, binary_cfg(adaptive=False, init_value=9), batch=24, max_batch=24)
     assert total > 0
+
+
+def test_m3_long_stream_mixed_protocols():
+    """1500 frames through one detector, mixing the per-frame protocol, small and large batches and the
+    submit/collect pipeline: ring wrap-around, sigma schedule (every interval*n frames), EMA warm-up end and the
+    binary ring all have to stay in step with the oracle."""
+    H, W, n = 96, 192, 8
+    mask = np.ones((H, W), np.uint8)
+    cfg = binary_cfg()
+    s = SkyStream(H, W, 99, speed=3, streak_period=40, streak_life=10)
+    frames = np.stack([s.next() for _ in range(1500)])
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=48)
+    cc = co.CM3(n, mask, det.stack.std_roi)
+    got_lines = []
+    infos = []
+    pos = 0
+    plan = [("single", 5), ("batch", 13), ("single", 3), ("batch", 200), ("batch", 1), ("batch", 48), ("single", 2),
+            ("batch", 97), ("batch", 1131)]
+    assert sum(k for _, k in plan) == 1500
+    for kind, k in plan:
+        chunk = frames[pos:pos + k]
+        if kind == "single":
+            for f in chunk:
+                det.update(f)
+                det.detect()
+                infos.append(det._ctx._info1[0].copy())
+                got_lines.append(det.linesp_ext.reshape(-1, 4).copy())
+        else:
+            info, raw, nms, prob = det._ctx.process_batch(chunk)
+            for i in range(k):
+                infos.append(info[i].copy())
+                nr = int(info[i]["n_raw"])
+                got_lines.append(raw[i][:nr].copy() if nr <= 500 else raw[i][:0].copy())
+        pos += k
+    total = 0
+    for t in range(1500):
+        cc.update(frames[t])
+        o_raw = cc.detect()
+        thr, thr_f, snr, _ = cc.state()
+        assert int(infos[t]["bi_threshold"]) == thr, t
+        assert float(infos[t]["snr"]) == pytest.approx(snr, rel=1e-12), t
+        assert int(infos[t]["lit_count"]) == cc.lit_count, t
+        assert np.array_equal(got_lines[t], o_raw.reshape(-1, 4)), t
+        total += len(o_raw)
+    assert total > 50
+    det.close()
