@@ -96,7 +96,7 @@ int mdh_process_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device,
 
 /* Asynchronous form of mdh_process_batch for K <= cfg.max_batch: mdh_submit_batch queues the pass and returns at
  * once; mdh_collect_batch waits for the OLDEST queued pass and returns its frame count (> 0) or a negative error.
- * At most two passes may be in flight; the pixel stages of the second overlap the Hough stage of the first.
+ * At most three passes may be in flight; the pixel stages of a later pass overlap the Hough stage of an earlier one.
  * `frames` must stay valid (and, for device memory, unmodified) until its pass has been collected. */
 int mdh_submit_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device);
 int mdh_collect_batch(mdh_ctx* ctx, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmetdet_hip.so")
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
+MAX_IN_FLIGHT = 3
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 SENSITIVITY_ID = {"low": 0, "normal": 1, "high": 2}
 
@@ -179,7 +180,7 @@ class Context:
                                        prob.ctypes.data if prob is not None else None), "mdh_process_batch")
 
     def submit(self, ptr, K, on_device):
-        """Queue a pass of K <= max_batch frames and return at once (at most two passes may be in flight).  The
+        """Queue a pass of K <= max_batch frames and return at once (at most MAX_IN_FLIGHT passes may be queued).  The
         frames must stay valid until the pass has been collected."""
         check(self.L.mdh_submit_batch(self.handle, int(ptr), int(K), int(bool(on_device))), "mdh_submit_batch")
 

@@ -48,7 +48,7 @@ struct ProfSpan {
     hipEvent_t a, b;
 };
 
-#define NSLOT 2
+#define NSLOT 3
 
 // Everything that crosses the pixel-stage -> Hough boundary or is mirrored to the host, per in-flight pass.
 struct Slot {
@@ -297,7 +297,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->WW = (W + 63) / 64;
     c->n = n_window;
     c->Kmax = cfg->max_batch > 0 ? cfg->max_batch : 64;
-    // the frame / binary rings must hold the history plus two passes in flight
+    // the frame / binary rings must hold the history plus NSLOT passes in flight
     c->R = c->n - 1 + NSLOT * c->Kmax;
     if (c->R < c->n) c->R = c->n;
     c->HW = (size_t)H * W;
@@ -689,7 +689,7 @@ extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, 
 // Take the next slot for a pass of K frames.  The slot's previous pass must have been collected.
 static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     if (K < 1 || K > c->Kmax) { set_err("pass size must be 1..max_batch"); return MDH_E_ARG; }
-    if (c->in_flight >= NSLOT) { set_err("two passes are already in flight: collect one first"); return MDH_E_STATE; }
+    if (c->in_flight >= NSLOT) { set_err("three passes are already in flight: collect one first"); return MDH_E_STATE; }
     Slot& sl = c->slot[c->next_slot];
     if (sl.busy) { set_err("internal: slot still busy"); return MDH_E_STATE; }
     // the main stream may not overwrite this slot's buffers before the Hough stage that last read them is done
@@ -819,7 +819,7 @@ extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int o
     if (c->pending) { set_err("mdh_process_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_process_batch: collect the submitted passes first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    // chunks of at most max_batch frames, two in flight: chunk j+1 is queued before chunk j is collected
+    // chunks of at most max_batch frames, up to NSLOT in flight: later chunks are queued before chunk j is collected
     int submitted = 0, collected = 0;
     while (collected < K) {
         int rc;
