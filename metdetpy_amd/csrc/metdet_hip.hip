@@ -54,6 +54,13 @@ struct ProfSpan {
 struct Slot {
     const uint8_t** h_ptrtab = nullptr;  // pinned
     NoiseJob* h_jobs = nullptr;          // pinned
+    // written on the staging / noise stream, read by the pixel stages of the same pass
+    const uint8_t** d_ptrtab = nullptr;
+    NoiseJob* d_jobs = nullptr;
+    long long* d_sums = nullptr;
+    ScalarState* d_jobres = nullptr;
+    int* d_thr = nullptr;
+    hipEvent_t ev_noise = nullptr;
     u64* d_dst = nullptr;
     int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr, *d_bbox = nullptr;
     FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
@@ -72,7 +79,8 @@ struct mdh_ctx {
     int H = 0, W = 0, WW = 0, n = 0, R = 0, Kmax = 0;
     size_t HW = 0, words = 0;
     mdh_cfg cfg{};
-    hipStream_t stream = nullptr;                   // main: pixel stages, state
+    hipStream_t stream = nullptr;                   // main: pixel stages
+    hipStream_t nstream = nullptr;                  // staging + noise / threshold chain (runs one pass ahead of the main stream)
     hipStream_t hstream[2] = {nullptr, nullptr};    // Hough: [0] small-LDS launch + result copies, [1] big-LDS launch
     hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
     hipEvent_t ev_big = nullptr;
@@ -85,12 +93,14 @@ struct mdh_ctx {
     // device buffers used on the main stream only
     uint8_t* d_ring = nullptr;
     uint8_t* d_zero = nullptr;
+    // aliases of the slot being queued (set by slot_begin)
     const uint8_t** d_ptrtab = nullptr;
-    const uint8_t** h_ptrtab = nullptr;  // = slot[cur].h_ptrtab while a pass is being queued
+    const uint8_t** h_ptrtab = nullptr;
     NoiseJob* d_jobs = nullptr;
     long long* d_sums = nullptr;
-    ScalarState *d_state = nullptr, *d_jobres = nullptr;
+    ScalarState* d_jobres = nullptr;
     int* d_thr = nullptr;
+    ScalarState* d_state = nullptr;  // running scalars, only touched on the noise stream
     u64 *d_bbits = nullptr, *d_act = nullptr, *d_planes = nullptr;
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;  // words of act with lit pixels (sparse dynamic-mask pass)
@@ -146,18 +156,19 @@ static void free_all(mdh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* dev[] = {c->d_ring, c->d_zero, c->d_ptrtab, c->d_jobs, c->d_sums, c->d_state, c->d_jobres, c->d_thr, c->d_bbits,
+    void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_bbits,
                    c->d_act, c->d_planes, c->d_bandflag, c->d_nzlist, c->d_nzcount, c->d_work, c->d_accum, c->d_nz_orig,
                    c->d_nz_work, c->d_trig, c->d_hdbg, c->d_expand};
     for (void* p : dev)
         if (p) hipFree(p);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap};
+        void* sdev[] = {s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap, s.d_ptrtab, s.d_jobs, s.d_sums, s.d_jobres, s.d_thr};
         for (void* p : sdev)
             if (p) hipFree(p);
         void* shost[] = {s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
         for (void* p : shost)
             if (p) hipHostFree(p);
+        if (s.ev_noise) hipEventDestroy(s.ev_noise);
         if (s.ev_pix) hipEventDestroy(s.ev_pix);
         if (s.ev_done) hipEventDestroy(s.ev_done);
         for (auto& sp : s.spans) {
@@ -166,7 +177,7 @@ static void free_all(mdh_ctx* c) {
         }
     }
     if (c->ev_big) hipEventDestroy(c->ev_big);
-    hipStream_t st[] = {c->stream, c->hstream[0], c->hstream[1], c->cstream};
+    hipStream_t st[] = {c->stream, c->nstream, c->hstream[0], c->hstream[1], c->cstream};
     for (hipStream_t q : st)
         if (q) hipStreamDestroy(q);
     delete c;
@@ -175,6 +186,7 @@ static void free_all(mdh_ctx* c) {
 static int create_impl(mdh_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->nstream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->hstream[1], hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
@@ -185,12 +197,7 @@ static int create_impl(mdh_ctx* c) {
 #define TRY(x) if ((rc = (x)) != MDH_OK) return rc
     TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
     TRY(dev_alloc(c->d_zero, HW));
-    TRY(dev_alloc(c->d_ptrtab, c->n - 1 + K));
-    TRY(dev_alloc(c->d_jobs, K));
-    TRY(dev_alloc(c->d_sums, 2 * K));
     TRY(dev_alloc(c->d_state, 1));
-    TRY(dev_alloc(c->d_jobres, K + 1));
-    TRY(dev_alloc(c->d_thr, K));
     TRY(dev_alloc(c->d_bbits, K * words));
     TRY(dev_alloc(c->d_act, (size_t)c->R * words));
     if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
@@ -207,6 +214,12 @@ static int create_impl(mdh_ctx* c) {
     for (Slot& s : c->slot) {
         TRY(host_alloc(s.h_ptrtab, c->n - 1 + K));
         TRY(host_alloc(s.h_jobs, K));
+        TRY(dev_alloc(s.d_ptrtab, c->n - 1 + K));
+        TRY(dev_alloc(s.d_jobs, K));
+        TRY(dev_alloc(s.d_sums, 2 * K));
+        TRY(dev_alloc(s.d_jobres, K + 1));
+        TRY(dev_alloc(s.d_thr, K));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_noise, hipEventDisableTiming));
         TRY(dev_alloc(s.d_dst, K * words));
         // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
         TRY(dev_alloc(s.d_rowcount, K * c->H + 5 * K));
@@ -281,6 +294,10 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         set_err("mdh_create: mask_area must be > 0");
         return nullptr;
     }
+    // The context uses five streams that must progress independently; the HIP runtime multiplexes streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue serialise behind each other's event
+    // waits.  Only effective if the runtime is not initialised yet (otherwise set it in the environment).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_err("mdh_create: no HIP device visible -- libmetdet_hip needs an AMD GPU (there is no CPU fallback)");
@@ -388,11 +405,11 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
             const int64_t rs = (t_base + i) % c->R;
             const int run = (int)std::min<int64_t>(K - i, c->R - rs);
             HIPCHK(hipMemcpyAsync(c->d_ring + (size_t)rs * c->HW, frames + (size_t)i * c->HW, (size_t)run * c->HW,
-                                  hipMemcpyHostToDevice, c->stream));
+                                  hipMemcpyHostToDevice, c->nstream));
             i += run;
         }
     }
-    HIPCHK(hipMemcpyAsync(c->d_ptrtab, c->h_ptrtab, sizeof(uint8_t*) * (c->n - 1 + K), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_ptrtab, c->h_ptrtab, sizeof(uint8_t*) * (c->n - 1 + K), hipMemcpyHostToDevice, c->nstream));
     return MDH_OK;
 }
 
@@ -493,27 +510,28 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
     const int rh = r[2] - r[0], rw = r[3] - r[1];
     PassGeom g = geom(c, K, t_base);
     if (nj) {
-        HIPCHK(hipMemcpyAsync(c->d_jobs, sl.h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_jobs, sl.h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->nstream));
+        HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->nstream));
         bool aligned4 = (c->W % 4) == 0;
         for (int e = 0; e < c->n - 1 + K && aligned4; ++e) aligned4 = ((uintptr_t)c->h_ptrtab[e] & 3) == 0;
-        span_begin(c, KK_NOISE_SUMS, c->stream);
+        span_begin(c, KK_NOISE_SUMS, c->nstream);
         if (aligned4) {
             const int xa = r[1] & ~3;
             const int nx4 = (r[1] + rw - xa + 3) >> 2;
-            hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->stream, c->d_ptrtab,
+            hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->nstream, c->d_ptrtab,
                                c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
         } else {
-            hipLaunchKernelGGL(k_noise_sums_bytes, dim3((rh * rw + 255) / 256, nj), dim3(256), 0, c->stream, c->d_ptrtab,
+            hipLaunchKernelGGL(k_noise_sums_bytes, dim3((rh * rw + 255) / 256, nj), dim3(256), 0, c->nstream, c->d_ptrtab,
                                c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
         }
-        span_end(c, c->stream);
+        span_end(c, c->nstream);
     }
-    span_begin(c, KK_NOISE_FINAL, c->stream);
-    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->stream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
+    span_begin(c, KK_NOISE_FINAL, c->nstream);
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
                        sl.d_fscal, c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
-    span_end(c, c->stream);
+    span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
     return MDH_OK;
 }
 
@@ -523,6 +541,7 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     PassGeom g = geom(c, K, t_base);
     const int words = (int)c->words;
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
+    HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_noise, 0));  // thresholds, pointer table and history copies of this pass
     HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), c->stream));
     HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * ((size_t)K * nb * c->WW), c->stream));
     HIPCHK(hipMemsetAsync(c->d_nzcount, 0, sizeof(unsigned), c->stream));
@@ -611,7 +630,7 @@ static int retire_frames(mdh_ctx* c, Slot& sl, int K, int on_device) {
     auto flush = [&]() -> int {
         if (run_len > 0) {
             uint8_t* rs = c->d_ring + (size_t)((t_base + run_i) % c->R) * c->HW;
-            HIPCHK(hipMemcpyAsync(rs, sl.h_ptrtab[keep + run_i], (size_t)run_len * c->HW, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(rs, sl.h_ptrtab[keep + run_i], (size_t)run_len * c->HW, hipMemcpyDeviceToDevice, c->nstream));
         }
         run_len = 0;
         return MDH_OK;
@@ -697,6 +716,7 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     sl.K = K;
     sl.t_base = c->t;
     c->cur_spans = &sl.spans;
+    c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr;
     out = &sl;
     return MDH_OK;
 }
@@ -712,10 +732,12 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
     Slot* sl = nullptr;
     int rc;
     if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
+    // staging stream: pointer table (built from the history BEFORE this pass), history copies, noise / thresholds;
+    // main stream: pixel stages once the thresholds are there
     if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return rc;
+    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return rc;
     if ((rc = run_noise(c, *sl, K)) != MDH_OK) return rc;
     if ((rc = run_detect(c, *sl, K)) != MDH_OK) return rc;
-    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return rc;
     slot_commit(c, *sl);
     return MDH_OK;
 }
@@ -793,9 +815,10 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     int rc;
     if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
     if ((rc = stage_frames(c, *sl, frame, 1, 0)) != MDH_OK) return rc;
+    if ((rc = retire_frames(c, *sl, 1, 0)) != MDH_OK) return rc;
     if ((rc = run_noise(c, *sl, 1)) != MDH_OK) return rc;
     // the caller may reuse `frame` after return (the reference copies it, utils.py:280)
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->nstream));
     c->pending = true;
     return MDH_OK;
 }
@@ -806,8 +829,10 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = c->slot[c->next_slot];
     int rc;
+    c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr;
+    c->h_ptrtab = sl.h_ptrtab;
+    c->cur_spans = &sl.spans;
     if ((rc = run_detect(c, sl, 1)) != MDH_OK) return rc;
-    if ((rc = retire_frames(c, sl, 1, 0)) != MDH_OK) return rc;
     slot_commit(c, sl);
     c->pending = false;
     return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
