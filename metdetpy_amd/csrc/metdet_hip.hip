@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,8 @@ struct ProfSpan {
 };
 
 #define NSLOT 3
+#define NHSET 2  // Hough buffer / stream sets available; MDH_HOUGH_SETS (default 1) of them are used
+#define PACK_HEAD 8  // packed segments per frame (pass average) copied to the host without waiting for the counts
 
 // Everything that crosses the pixel-stage -> Hough boundary or is mirrored to the host, per in-flight pass.
 struct Slot {
@@ -61,10 +64,16 @@ struct Slot {
     ScalarState* d_jobres = nullptr;
     int* d_thr = nullptr;
     hipEvent_t ev_noise = nullptr;
+    // dst is only written where it is non-zero; d_nzlist names the candidate words and k_sparse_clear zeroes them again
+    // on the staging stream before the slot's next pass (ev_prep).
+    unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
+    unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;
+    hipEvent_t ev_prep = nullptr;
     u64* d_dst = nullptr;
     int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr, *d_bbox = nullptr;
     FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
     int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
+    int *d_packed = nullptr, *d_off = nullptr, *h_off = nullptr;  // segments packed back to back (h_lines holds the host copy)
     double *d_gap = nullptr, *h_gap = nullptr;
     hipEvent_t ev_pix = nullptr, ev_done = nullptr;
     std::vector<ProfSpan> spans;
@@ -74,6 +83,17 @@ struct Slot {
     int64_t t_base = 0;
 };
 
+// Hough-private buffers and streams.  Consecutive passes alternate between the sets, so the (latency-bound) Hough stage of
+// one pass overlaps the next pass's instead of queueing behind it.
+struct HoughSet {
+    hipStream_t stream[2] = {nullptr, nullptr};  // [0] small-LDS launch + result copies, [1] big-LDS launch
+    hipEvent_t ev_big = nullptr;
+    u64* d_work = nullptr;
+    int* d_accum = nullptr;
+    unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
+    int last_slot = -1;  // slot of the pass that used the set last
+};
+
 struct mdh_ctx {
     int device = 0;
     int H = 0, W = 0, WW = 0, n = 0, R = 0, Kmax = 0;
@@ -81,9 +101,11 @@ struct mdh_ctx {
     mdh_cfg cfg{};
     hipStream_t stream = nullptr;                   // main: pixel stages
     hipStream_t nstream = nullptr;                  // staging + noise / threshold chain (runs one pass ahead of the main stream)
-    hipStream_t hstream[2] = {nullptr, nullptr};    // Hough: [0] small-LDS launch + result copies, [1] big-LDS launch
+    HoughSet hset[NHSET];
+    unsigned tag_lds = 0;  // MDH_TAG_PASS=1: dynamic LDS bytes that tag a pass's kernels in a rocprofv3 trace (1024 * (1 + pass % 3))
+    int nhset = 1;  // sets in use: with 2, the Hough stages of consecutive passes overlap (experiment switch MDH_HOUGH_SETS)
+    int64_t pass_seq = 0;
     hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
-    hipEvent_t ev_big = nullptr;
     int64_t t = 0;  // frames submitted (SlidingWindow.timer)
     // EMA schedule (host mirror of utils.py:334-368)
     double ema_m0 = 0, ema_warm = 0;
@@ -100,14 +122,11 @@ struct mdh_ctx {
     long long* d_sums = nullptr;
     ScalarState* d_jobres = nullptr;
     int* d_thr = nullptr;
+    unsigned* d_bandflag = nullptr;
     ScalarState* d_state = nullptr;  // running scalars, only touched on the noise stream
-    u64 *d_bbits = nullptr, *d_act = nullptr, *d_planes = nullptr;
-    unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
-    unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;  // words of act with lit pixels (sparse dynamic-mask pass)
-    // Hough-private buffers (Hough stages of consecutive passes run one after the other)
-    u64* d_work = nullptr;
-    int* d_accum = nullptr;
-    unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
+    u64 *d_bbits = nullptr, *d_planes = nullptr;
+    ActWord* d_act = nullptr;  // [R][H][WW] tagged sparse ring of closed binaries
+    unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output (main stream only)
     float* d_trig = nullptr;
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     uint8_t* d_expand = nullptr;
@@ -115,7 +134,6 @@ struct mdh_ctx {
     int next_slot = 0;       // slot the next submitted pass takes
     int oldest = 0;          // slot of the oldest pass not yet collected
     int in_flight = 0;
-    int last_hough_slot = -1;  // slot whose Hough stage was queued last
     std::vector<const uint8_t*> hist;  // device pointers of the last n-1 frames, oldest first
     // update()/detect() protocol
     bool pending = false;
@@ -130,6 +148,8 @@ struct mdh_ctx {
     // profiling
     bool prof = false;
     std::vector<ProfSpan>* cur_spans = nullptr;
+    double host_us[6] = {0};  // MDH_HOST_TRACE=1: submit, wait for ev_done, segment copy, nms + unpack, (spare)
+    int64_t host_n = 0;
     double prof_ms[MDH_NUM_KERNELS] = {0};
     int64_t prof_n[MDH_NUM_KERNELS] = {0};
 };
@@ -152,23 +172,33 @@ static int host_alloc(T*& p, size_t count) {
     return MDH_OK;
 }
 
+static inline double now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 static void free_all(mdh_ctx* c) {
     if (!c) return;
+    if (getenv("MDH_HOST_TRACE") && c->host_n)
+        fprintf(stderr, "[mdh host] passes %lld  per pass: submit %.1f us, wait %.1f us, segment copy %.1f us, nms+unpack %.1f us\n",
+                (long long)c->host_n, c->host_us[0] / c->host_n, c->host_us[1] / c->host_n, c->host_us[2] / c->host_n,
+                c->host_us[3] / c->host_n);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_bbits,
-                   c->d_act, c->d_planes, c->d_bandflag, c->d_nzlist, c->d_nzcount, c->d_work, c->d_accum, c->d_nz_orig,
-                   c->d_nz_work, c->d_trig, c->d_hdbg, c->d_expand};
+                   c->d_act, c->d_worklist, c->d_planes, c->d_trig, c->d_hdbg, c->d_expand};
     for (void* p : dev)
         if (p) hipFree(p);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap, s.d_ptrtab, s.d_jobs, s.d_sums, s.d_jobres, s.d_thr};
+        void* sdev[] = {s.d_packed, s.d_off, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap, s.d_ptrtab, s.d_jobs, s.d_sums, s.d_jobres, s.d_thr};
         for (void* p : sdev)
             if (p) hipFree(p);
-        void* shost[] = {s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
+        void* shost[] = {s.h_off, s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
         for (void* p : shost)
             if (p) hipHostFree(p);
         if (s.ev_noise) hipEventDestroy(s.ev_noise);
+        if (s.ev_prep) hipEventDestroy(s.ev_prep);
         if (s.ev_pix) hipEventDestroy(s.ev_pix);
         if (s.ev_done) hipEventDestroy(s.ev_done);
         for (auto& sp : s.spans) {
@@ -176,8 +206,15 @@ static void free_all(mdh_ctx* c) {
             hipEventDestroy(sp.b);
         }
     }
-    if (c->ev_big) hipEventDestroy(c->ev_big);
-    hipStream_t st[] = {c->stream, c->nstream, c->hstream[0], c->hstream[1], c->cstream};
+    for (HoughSet& h : c->hset) {
+        void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work};
+        for (void* p : hdev)
+            if (p) hipFree(p);
+        if (h.ev_big) hipEventDestroy(h.ev_big);
+        for (hipStream_t q : h.stream)
+            if (q) hipStreamDestroy(q);
+    }
+    hipStream_t st[] = {c->stream, c->nstream, c->cstream};
     for (hipStream_t q : st)
         if (q) hipStreamDestroy(q);
     delete c;
@@ -185,12 +222,28 @@ static void free_all(mdh_ctx* c) {
 
 static int create_impl(mdh_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->nstream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->hstream[1], hipStreamNonBlocking));
+    // Stream priorities (experiment switches): MDH_PRIO_{MAIN,NOISE,HOUGH} = -1 low, 0 normal (default), 1 high.
+    int prio_low = 0, prio_high = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    auto prio_of = [&](const char* name, int dflt) {
+        const char* v = getenv(name);
+        const int k = v ? atoi(v) : dflt;
+        return k > 0 ? prio_high : (k < 0 ? prio_low : (prio_low + prio_high) / 2);
+    };
+    const bool use_prio = getenv("MDH_PRIO_MAIN") || getenv("MDH_PRIO_NOISE") || getenv("MDH_PRIO_HOUGH");
+    auto make_stream = [&](hipStream_t* st, const char* name) -> hipError_t {
+        return use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(name, 0))
+                        : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    HIPCHK(make_stream(&c->stream, "MDH_PRIO_MAIN"));
+    HIPCHK(make_stream(&c->nstream, "MDH_PRIO_NOISE"));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_big, hipEventDisableTiming));
+    for (int hi = 0; hi < c->nhset; ++hi) {
+        HoughSet& h = c->hset[hi];
+        HIPCHK(make_stream(&h.stream[0], "MDH_PRIO_HOUGH"));
+        HIPCHK(make_stream(&h.stream[1], "MDH_PRIO_HOUGH"));
+        HIPCHK(hipEventCreateWithFlags(&h.ev_big, hipEventDisableTiming));
+    }
     const size_t K = c->Kmax, HW = c->HW, words = c->words;
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     int rc;
@@ -199,15 +252,18 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_zero, HW));
     TRY(dev_alloc(c->d_state, 1));
     TRY(dev_alloc(c->d_bbits, K * words));
-    TRY(dev_alloc(c->d_act, (size_t)c->R * words));
+    if (c->cfg.detector == MDH_DET_M3) {
+        TRY(dev_alloc(c->d_act, (size_t)c->R * words));
+        TRY(dev_alloc(c->d_worklist, K * nb * c->WW, false));
+    }
     if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
-    TRY(dev_alloc(c->d_bandflag, K * nb * c->WW));
-    TRY(dev_alloc(c->d_nzlist, K * words, false));
-    TRY(dev_alloc(c->d_nzcount, 1));
-    TRY(dev_alloc(c->d_work, K * words));
-    TRY(dev_alloc(c->d_accum, K * (size_t)NUM_ANGLE * c->numrho));
-    TRY(dev_alloc(c->d_nz_orig, K * HW, false));
-    TRY(dev_alloc(c->d_nz_work, K * HW, false));
+    for (int hi = 0; hi < c->nhset; ++hi) {
+        HoughSet& h = c->hset[hi];
+        TRY(dev_alloc(h.d_work, K * words));
+        TRY(dev_alloc(h.d_accum, K * (size_t)NUM_ANGLE * c->numrho));
+        TRY(dev_alloc(h.d_nz_orig, K * HW, false));
+        TRY(dev_alloc(h.d_nz_work, K * HW, false));
+    }
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
@@ -220,6 +276,10 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_jobres, K + 1));
         TRY(dev_alloc(s.d_thr, K));
         HIPCHK(hipEventCreateWithFlags(&s.ev_noise, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
+        TRY(dev_alloc(s.d_bandflag, K * nb * c->WW));
+        TRY(dev_alloc(s.d_nzlist, K * words, false));
+        TRY(dev_alloc(s.d_nzcount, 2));  // [0] listed words, [1] listed morphology blocks
         TRY(dev_alloc(s.d_dst, K * words));
         // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
         TRY(dev_alloc(s.d_rowcount, K * c->H + 5 * K));
@@ -230,6 +290,9 @@ static int create_impl(mdh_ctx* c) {
         TRY(host_alloc(s.h_fscal, K));
         TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
         TRY(host_alloc(s.h_lines, K * (size_t)MAX_LINES * 4));
+        TRY(dev_alloc(s.d_packed, K * (size_t)MAX_LINES * 4));
+        TRY(dev_alloc(s.d_off, K + 1));
+        TRY(host_alloc(s.h_off, K + 1));
         TRY(dev_alloc(s.d_nraw, K));
         TRY(host_alloc(s.h_nraw, K));
         TRY(dev_alloc(s.d_gap, K));
@@ -327,6 +390,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->hough_serial = env_on("MDH_HOUGH_SERIAL");
     c->hough_global_acc = env_on("MDH_HOUGH_GLOBAL_ACC");
     c->hough_one_wave = env_on("MDH_HOUGH_ONE_WAVE") || c->hough_serial;
+    if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
         free_all(c);
@@ -434,7 +498,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g) {
     nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
                        c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc);
 }
 
@@ -509,6 +573,10 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
     const int* r = c->cfg.roi;
     const int rh = r[2] - r[0], rw = r[3] - r[1];
     PassGeom g = geom(c, K, t_base);
+    // counters the pixel stages accumulate into (the slot's previous pass has been collected, so nothing reads them)
+    const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
+    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), c->nstream));
+    HIPCHK(hipMemsetAsync(sl.d_bandflag, 0, sizeof(unsigned) * ((size_t)K * nb * c->WW), c->nstream));
     if (nj) {
         HIPCHK(hipMemcpyAsync(c->d_jobs, sl.h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->nstream));
         HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->nstream));
@@ -527,11 +595,19 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
         span_end(c, c->nstream);
     }
     span_begin(c, KK_NOISE_FINAL, c->nstream);
-    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
                        sl.d_fscal, c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
+    // Zero the dst words this slot's previous pass left behind.  Their last reader (that pass's Hough stage) is done
+    // because the pass has been collected.
+    if (c->cfg.detector == MDH_DET_M3) {
+        if (sl.used)
+            hipLaunchKernelGGL(k_sparse_clear, dim3(64), dim3(256), 0, c->nstream, sl.d_dst, sl.d_nzlist, sl.d_nzcount);
+        HIPCHK(hipMemsetAsync(sl.d_nzcount, 0, 2 * sizeof(unsigned), c->nstream));
+    }
+    HIPCHK(hipEventRecord(sl.ev_prep, c->nstream));
     return MDH_OK;
 }
 
@@ -541,20 +617,20 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     PassGeom g = geom(c, K, t_base);
     const int words = (int)c->words;
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
-    HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_noise, 0));  // thresholds, pointer table and history copies of this pass
-    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_bandflag, 0, sizeof(unsigned) * ((size_t)K * nb * c->WW), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_nzcount, 0, sizeof(unsigned), c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_noise, 0));  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
         launch_stack_threshold(c, g);
         span_end(c, c->stream);
+        HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_prep, 0));  // act ring rows and dst of this slot are all-zero again
         span_begin(c, KK_MORPH, c->stream);
-        hipLaunchKernelGGL(k_morph_close, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, c->stream, c->d_bbits,
-                           c->d_bandflag, c->d_act, sl.d_dst, c->d_nzlist, c->d_nzcount, g);
+        hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, c->stream, sl.d_bandflag,
+                           c->d_worklist, sl.d_nzcount + 1, g);
+        hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, c->stream, c->d_bbits, c->d_worklist, sl.d_nzcount + 1, c->d_act,
+                           sl.d_nzlist, sl.d_nzcount, g);
         span_end(c, c->stream);
         span_begin(c, KK_DY_APPLY, c->stream);
-        hipLaunchKernelGGL(k_dy_sparse, dim3(256), dim3(256), 0, c->stream, c->d_act, sl.d_dst, c->d_nzlist, c->d_nzcount,
+        hipLaunchKernelGGL(k_dy_sparse, dim3(2048), dim3(256), 0, c->stream, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
                            sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
         span_end(c, c->stream);
     } else {
@@ -576,48 +652,58 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     P.no_lds_acc = c->hough_global_acc;
     P.dbg = c->d_hdbg;
     P.mask_area = c->cfg.mask_area;
-    P.dst_bits = sl.d_dst; P.work_bits = c->d_work; P.rowcount = sl.d_rowcount; P.litcount = sl.d_litcount;
-    P.accum = c->d_accum; P.nz_orig = c->d_nz_orig; P.nz_work = c->d_nz_work; P.nz_cap = (long long)c->HW;
+    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
+    hipStream_t* hstream = hs.stream;
+    P.dst_bits = sl.d_dst; P.work_bits = hs.d_work; P.rowcount = sl.d_rowcount; P.litcount = sl.d_litcount;
+    P.accum = hs.d_accum; P.nz_orig = hs.d_nz_orig; P.nz_work = hs.d_nz_work; P.nz_cap = (long long)c->HW;
     P.out_lines = sl.d_lines; P.out_nraw = sl.d_nraw; P.out_gap = sl.d_gap; P.trig = c->d_trig;
     P.bbox = sl.d_bbox;
     P.big_list = 8192;
     // Hough: a small-LDS launch (2 frames per CU) takes the frames whose point list and accumulator windows fit it, a
     // big-LDS launch (1 frame per CU) takes the rest; both evaluate the same fit test from the lit count and bounding
-    // box, so they run side by side.  They start once this pass's pixel stages are done and the previous pass's Hough
-    // stage has released the shared accumulators / point lists.
+    // box, so they run side by side.  They start once this pass's pixel stages are done and the pass that used this
+    // Hough set before (two passes ago) has released its accumulators / point lists.
     for (int h = 0; h < 2; ++h) {
-        HIPCHK(hipStreamWaitEvent(c->hstream[h], sl.ev_pix, 0));
-        if (c->last_hough_slot >= 0) HIPCHK(hipStreamWaitEvent(c->hstream[h], c->slot[c->last_hough_slot].ev_done, 0));
+        HIPCHK(hipStreamWaitEvent(hstream[h], sl.ev_pix, 0));
+        if (hs.last_slot >= 0) HIPCHK(hipStreamWaitEvent(hstream[h], c->slot[hs.last_slot].ev_done, 0));
     }
-    span_begin(c, KK_HOUGH, c->hstream[0]);
+    span_begin(c, KK_HOUGH, hstream[0]);
     if (c->hough_one_wave) {
         P.small_list = 4096; P.small_cells = 32000;
         P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
-        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[1], P);
-        HIPCHK(hipEventRecord(c->ev_big, c->hstream[1]));
+        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), hstream[1], P);
+        HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
         P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
-        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), c->hstream[0], P);
+        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), hstream[0], P);
     } else {
         // four waves per frame; frames with more than big_list lit pixels go to the one-wave kernel's global-list path
         P.small_list = 4096; P.small_cells = 31000;
         P.tier = 1; P.list_cap = P.big_list; P.cell_cap = 61440;
         hipLaunchKernelGGL(k_hough_ppht4, dim3(K), dim3(256), (P.list_cap + P.cell_cap / 2 + HOUGH4_EXTRA_DWORDS) * sizeof(unsigned),
-                           c->hstream[1], P);
+                           hstream[1], P);
         P.tier = 2; P.list_cap = 0; P.cell_cap = 0;  // global point list, global accumulator, 64 dummy dwords of LDS
-        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (64 + 64) * sizeof(unsigned), c->hstream[1], P);
-        HIPCHK(hipEventRecord(c->ev_big, c->hstream[1]));
+        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (64 + 64) * sizeof(unsigned), hstream[1], P);
+        HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
         P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
         hipLaunchKernelGGL(k_hough_ppht4, dim3(K), dim3(256), (P.list_cap + P.cell_cap / 2 + HOUGH4_EXTRA_DWORDS) * sizeof(unsigned),
-                           c->hstream[0], P);
+                           hstream[0], P);
     }
-    HIPCHK(hipStreamWaitEvent(c->hstream[0], c->ev_big, 0));
-    span_end(c, c->hstream[0]);
+    HIPCHK(hipStreamWaitEvent(hstream[0], hs.ev_big, 0));
+    span_end(c, hstream[0]);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(sl.h_nraw, sl.d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, c->hstream[0]));
-    HIPCHK(hipMemcpyAsync(sl.h_litcount, sl.d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, c->hstream[0]));
-    HIPCHK(hipMemcpyAsync(sl.h_gap, sl.d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, c->hstream[0]));
-    HIPCHK(hipEventRecord(sl.ev_done, c->hstream[0]));
-    c->last_hough_slot = (int)(&sl - c->slot);
+    // pack the segments and send the head of the packed array along with the scalars; collect_pass fetches the rest only
+    // when a pass holds more than PACK_HEAD segments per frame on average
+    hipLaunchKernelGGL(k_pack_lines, dim3(1), dim3(1024), 0, hstream[0], (const int4*)sl.d_lines, sl.d_nraw, K, MAX_LINES,
+                       (int4*)sl.d_packed, sl.d_off);
+    HIPCHK(hipMemcpyAsync(sl.h_off, sl.d_off, sizeof(int) * (K + 1), hipMemcpyDeviceToHost, hstream[0]));
+    HIPCHK(hipMemcpyAsync(sl.h_lines, sl.d_packed, sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K, hipMemcpyDeviceToHost,
+                          hstream[0]));
+    HIPCHK(hipMemcpyAsync(sl.h_nraw, sl.d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, hstream[0]));
+    HIPCHK(hipMemcpyAsync(sl.h_litcount, sl.d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, hstream[0]));
+    HIPCHK(hipMemcpyAsync(sl.h_gap, sl.d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, hstream[0]));
+    HIPCHK(hipEventRecord(sl.ev_done, hstream[0]));
+    hs.last_slot = (int)(&sl - c->slot);
+    c->pass_seq += 1;
     return MDH_OK;
 }
 
@@ -715,8 +801,10 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     if (sl.used) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
     sl.K = K;
     sl.t_base = c->t;
+    if (getenv("MDH_TAG_PASS")) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
     c->cur_spans = &sl.spans;
     c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr;
+    c->d_bandflag = sl.d_bandflag;
     out = &sl;
     return MDH_OK;
 }
@@ -731,6 +819,7 @@ static void slot_commit(mdh_ctx* c, Slot& sl) {
 static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
     Slot* sl = nullptr;
     int rc;
+    const double t0 = now_us();
     if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
     // staging stream: pointer table (built from the history BEFORE this pass), history copies, noise / thresholds;
     // main stream: pixel stages once the thresholds are there
@@ -739,6 +828,7 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
     if ((rc = run_noise(c, *sl, K)) != MDH_OK) return rc;
     if ((rc = run_detect(c, *sl, K)) != MDH_OK) return rc;
     slot_commit(c, *sl);
+    c->host_us[0] += now_us() - t0;
     return MDH_OK;
 }
 
@@ -747,23 +837,24 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
     if (c->in_flight <= 0) { set_err("no pass in flight"); return MDH_E_STATE; }
     Slot& sl = c->slot[c->oldest];
     const int K = sl.K;
+    const double t0 = now_us();
     HIPCHK(hipEventSynchronize(sl.ev_done));
+    const double t1 = now_us();
     spans_collect(c, sl);
-    // strided copy of the segments: only as many per frame as the fullest frame of the pass holds
-    int most = 0;
-    for (int i = 0; i < K; ++i) most = std::max(most, std::min(sl.h_nraw[i], MAX_LINES));
-    if (most > 0) {
-        const size_t pitch = sizeof(int) * 4 * MAX_LINES;
-        HIPCHK(hipMemcpy2DAsync(sl.h_lines, pitch, sl.d_lines, pitch, sizeof(int) * 4 * (size_t)most, K, hipMemcpyDeviceToHost,
-                                c->cstream));
+    // the head of the packed segment array came with the scalars; fetch the tail if there is one
+    const size_t head = (size_t)std::min(PACK_HEAD, MAX_LINES) * K, total = (size_t)sl.h_off[K];
+    if (total > head) {
+        HIPCHK(hipMemcpyAsync(sl.h_lines + 4 * head, sl.d_packed + 4 * head, sizeof(int) * 4 * (total - head), hipMemcpyDeviceToHost,
+                              c->cstream));
         HIPCHK(hipStreamSynchronize(c->cstream));
     }
+    const double t2 = now_us();
     std::vector<int32_t> tmp_l(4 * MAX_LINES);
     std::vector<double> tmp_p(MAX_LINES);
     for (int i = 0; i < K; ++i) {
         const int n_raw = sl.h_nraw[i];
         const int stored = std::min(n_raw, MAX_LINES);
-        const int32_t* L = sl.h_lines + (size_t)i * MAX_LINES * 4;
+        const int32_t* L = sl.h_lines + (size_t)sl.h_off[i] * 4;
         if (raw_lines) memcpy(raw_lines + (size_t)i * MAX_LINES * 4, L, sizeof(int32_t) * 4 * stored);
         int n_nms = 0;
         if (n_raw > 0 && n_raw <= 500) {  // NUM_LINES_TOOMUCH (Detector.py:30, 358-360)
@@ -783,6 +874,10 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
             o.hough_gap = sl.h_gap[i];
         }
     }
+    c->host_us[1] += t1 - t0;
+    c->host_us[2] += t2 - t1;
+    c->host_us[3] += now_us() - t2;
+    c->host_n += 1;
     sl.busy = false;
     c->last_slot = c->oldest;
     c->oldest = (c->oldest + 1) % NSLOT;
@@ -829,7 +924,7 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = c->slot[c->next_slot];
     int rc;
-    c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr;
+    c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr; c->d_bandflag = sl.d_bandflag;
     c->h_ptrtab = sl.h_ptrtab;
     c->cur_spans = &sl.spans;
     if ((rc = run_detect(c, sl, 1)) != MDH_OK) return rc;
@@ -872,18 +967,18 @@ extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {
     if (index < 0) index = sl.K - 1;
     if (index >= sl.K) { set_err("mdh_get_binary: index beyond the last pass"); return MDH_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    const u64* bits;
+    const int total = (int)c->HW;
     if (stage == 0) {
-        bits = sl.d_dst + (size_t)index * c->words;
+        hipLaunchKernelGGL(k_expand_bits, dim3((total + 255) / 256), dim3(256), 0, c->stream, sl.d_dst + (size_t)index * c->words,
+                           c->d_expand, c->H, c->W, c->WW);
     } else if (stage == 1 && c->cfg.detector == MDH_DET_M3) {
         const int64_t t = sl.t_base + 1 + index;
-        bits = c->d_act + (size_t)((t - 1) % c->R) * c->words;
+        hipLaunchKernelGGL(k_expand_act, dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_act + (size_t)((t - 1) % c->R) * c->words, c->d_expand, c->H, c->W, c->WW, (u64)t);
     } else {
         set_err("mdh_get_binary: unknown stage");
         return MDH_E_ARG;
     }
-    const int total = (int)c->HW;
-    hipLaunchKernelGGL(k_expand_bits, dim3((total + 255) / 256), dim3(256), 0, c->stream, bits, c->d_expand, c->H, c->W, c->WW);
     HIPCHK(hipMemcpyAsync(out, c->d_expand, c->HW, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return MDH_OK;

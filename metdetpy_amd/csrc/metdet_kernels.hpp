@@ -21,6 +21,12 @@ typedef unsigned __int128 u128;
 
 // ------------------------------------------------------------------------------------------------
 // Parameters shared by the pixel-stage kernels.
+// Everything except the window kernel is short or latency-bound (serial chains, a few waves per CU).  When such a
+// kernel shares a SIMD with the window kernel's VALU-saturating waves it would get one issue slot in four and its
+// critical path would stretch accordingly; at raised wave priority it keeps (almost) its stand-alone latency, and the
+// window kernel only loses the few slots those waves actually use.
+#define RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
 struct PassGeom {
     int H, W, WW;       // frame size, words per bit row
     int n;              // window length
@@ -47,6 +53,7 @@ struct NoiseJob {
 
 __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __restrict__ ptrtab, const NoiseJob* __restrict__ jobs,
                                                     long long* __restrict__ sums, PassGeom g, int r0, int c0, int rh, int rw) {
+    RAISE_WAVE_PRIORITY();
     // One thread = 4 horizontally adjacent pixels (one aligned dword per frame) of one ROI row.
     const NoiseJob job = jobs[blockIdx.y];
     const int k = job.k_used;
@@ -112,6 +119,7 @@ __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __rest
 __global__ void __launch_bounds__(256) k_noise_sums_bytes(const uint8_t* const* __restrict__ ptrtab,
                                                           const NoiseJob* __restrict__ jobs, long long* __restrict__ sums,
                                                           PassGeom g, int r0, int c0, int rh, int rw) {
+    RAISE_WAVE_PRIORITY();
     const NoiseJob job = jobs[blockIdx.y];
     const int k = job.k_used;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,6 +168,7 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
                                                         int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
                                                         double coef_a, double coef_b) {
+    RAISE_WAVE_PRIORITY();
     // jobres[0] = state on entry, jobres[j+1] = state after job j
     if (threadIdx.x == 0) {
         ScalarState s = *st;
@@ -410,6 +419,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
         }
     }
     const int e_max = g.K + N - 2;
+    const int len0 = window_len(g, i0);  // window_len(g, i0 + s) = min(n, len0 + s), in 32-bit scalar arithmetic
     // Bursts of U frames; the loads of burst b+1 are issued before burst b is consumed (double buffering), so a
     // wave always has loads in flight while it computes.
     constexpr int NB = (N + U - 1) / U;  // bursts per window period
@@ -417,6 +427,10 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = fetch(min(i0 + u + N - 1, e_max));
     for (int sb = 0; sb < steps; sb += N) {
+        // thresholds of the whole window period up front (scalar loads, off the per-frame critical path)
+        int Tp[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) Tp[u] = thr_tab[min(i0 + sb + u, g.K - 1)];
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
             const int ub = bi * U;
@@ -436,9 +450,9 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                         PK a[RW];
                         unpack(cur[u], a);
                         const int i = i0 + s;
-                        const unsigned short T = (unsigned short)thr_tab[i];
-                        const unsigned short len = (unsigned short)window_len(g, i);
-                        const u16x2 Tv = {T, T}, Lv = {len, len};
+                        const unsigned short T = (unsigned short)Tp[ub + u];
+                        const unsigned short nlen = (unsigned short)(0 - min(g.n, len0 + s));  // -window_len(g, i)
+                        const u16x2 Tv = {T, T}, NLv = {nlen, nlen};
                         unsigned acc = 0;
                         const int grp = slot / GS;  // the group of 4 window slots the new frame falls into (static after unrolling)
 #pragma unroll
@@ -454,17 +468,28 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                             m = gmax[0][r];
 #pragma unroll
                             for (int k = 1; k < NG; ++k) m = __builtin_elementwise_max(m, gmax[k][r]);
-                            // sum < (max - T) * len  <=>  bit 15 of the 16-bit difference (all terms < 2^15 for n <= 128)
+                            // sum < (max - T) * len  <=>  bit 15 of sum + (max - T) * (-len) mod 2^16 (all terms < 2^15 for
+                            // n <= 128); written as a multiply-add so that it maps to one v_pk_mad_u16
                             PK d;
-                            d.v = sum[r] - __builtin_elementwise_sub_sat(m, Tv) * Lv;
+                            d.v = __builtin_elementwise_sub_sat(m, Tv) * NLv + sum[r];
                             acc = (acc >> 1) | (d.u & 0x80008000u);
                         }
                         // reg r landed on bit 8+r-(8-RW) ... after RW shifts: low half bits (16-RW)..15 = pixels 0..RW-1,
                         // high half bits (32-RW)..31 = pixels RW..PPL-1
                         const unsigned bits = ((acc >> (16 - RW)) & ((1u << RW) - 1)) | ((acc >> (32 - 2 * RW)) & (((1u << RW) - 1) << RW));
-                        u64 v = (u64)bits << (q * PPL);
+                        u64 v;
+                        if constexpr (PPL == 16) {
+                            // the four lanes of a word hold 16 result bits each: gather them in lane q == 0 with two
+                            // quad-permute DPP moves (lane 0 <- 1, lane 2 <- 3; then lane 0 <- 2)
+                            const unsigned odd = (unsigned)__builtin_amdgcn_mov_dpp((int)bits, 0xF5, 0xF, 0xF, true);
+                            const unsigned pair = bits | (odd << 16);
+                            const unsigned upper = (unsigned)__builtin_amdgcn_mov_dpp((int)pair, 0xAA, 0xF, 0xF, true);
+                            v = (u64)pair | ((u64)upper << 32);
+                        } else {
+                            v = (u64)bits << (q * PPL);
 #pragma unroll
-                        for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
+                            for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
+                        }
                         if (q == 0 && gw < words) {
                             bbits[(size_t)i * words + gw] = v;
                             if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
@@ -506,6 +531,25 @@ __device__ __forceinline__ u128 load_win(const u64* __restrict__ row, int w, int
     return (u128)(l >> 61) | ((u128)c << 3) | ((u128)r << 67);
 }
 
+// The ring of closed binaries (`act`, one row per frame, R rows) is SPARSE: k_morph_close stores only the words that
+// have lit pixels, each with the number of the frame it belongs to, and never clears anything.  A reader asks for
+// frame t and treats a word whose tag differs (never written, or left over from frame t - k*R) as zero.
+struct __attribute__((aligned(16))) ActWord {
+    u64 bits;
+    u64 tag;  // frame number t >= 1 (0 = never written)
+};
+__device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw, u64 t) {
+    const ActWord a = row[gw];
+    return a.tag == t ? a.bits : 0ull;
+}
+// load_win on a row of a tagged frame; `row` points at word 0 of image row y
+__device__ __forceinline__ u128 load_win_act(const ActWord* __restrict__ row, int w, int WW, u64 t) {
+    const u64 c = act_word(row, w, t);
+    const u64 l = w > 0 ? act_word(row, w - 1, t) : 0ull;
+    const u64 r = w + 1 < WW ? act_word(row, w + 1, t) : 0ull;
+    return (u128)(l >> 61) | ((u128)c << 3) | ((u128)r << 67);
+}
+
 // horizontal 3-sum of a bit row with REPLICATED image border (cv2.medianBlur): returns the 2-bit count planes
 __device__ __forceinline__ void hsum3_replicate(u128 b, const Win& q, u128& h0, u128& h1) {
     u128 L = b << 1, Rr = b >> 1;
@@ -540,25 +584,21 @@ __device__ __forceinline__ u128 hor_and3_open(u128 d, const Win& q) {
 
 // a5 + a6 + a7: act = MORPH_CLOSE( median3(diff) > T ) computed from b = (diff > T):
 //   median3(diff) > T  <=>  at least 5 of the 9 (border-replicated) neighbours have diff > T.
-// One thread owns one word column and a band of RB rows and slides down it with 3-row pipelines.
-__global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbits, const unsigned* __restrict__ blockcnt,
-                                                     u64* __restrict__ act_ring, u64* __restrict__ dst_bits,
-                                                     unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
+// Work selection: a pixel survives the median only with >= 5 set samples in its 3x3 window, and every stencil reaches at
+// most 3 rows / 3 columns, so if the 3x3 neighbourhood of (8-row band, word column) blocks of b holds fewer than 5 set
+// bits (border replication can count a sample twice per axis) the whole output block is zero and nothing is stored
+// for it (absent words read as zero).  The blocks that may produce output are compacted into a work list, so that
+// the stencil kernel runs with full waves instead of a few live lanes per wave.
+__global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
+                                                      unsigned* __restrict__ workcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
     const int i = blockIdx.y;
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= nb * g.WW) return;
-    const int band = tid / g.WW, w = tid - band * g.WW;
-    const int y0 = band * MORPH_RB;
-    const Win q = make_win(w, g.W);
-    const u64* src = bbits + (size_t)i * g.H * g.WW;
-    const long long t = g.t_base + 1 + i;
-    u64* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
-    // A pixel survives the median only with >= 5 set samples in its 3x3 window, and every stencil reaches at most
-    // 3 rows / 3 columns, so if the 3x3 neighbourhood of (8-row band, word column) blocks of b holds fewer than 5
-    // set bits (border replication can count a sample twice per axis) the whole output block is zero.
-    u64* dzero = dst_bits + (size_t)i * g.H * g.WW;
-    {
+    bool keep = false;
+    if (tid < nb * g.WW) {
+        const int band = tid / g.WW, w = tid - band * g.WW;
+        const int y0 = band * MORPH_RB;
         unsigned total = 0;
         for (int db = -1; db <= 1; ++db) {
             const int bb = band + db;
@@ -570,14 +610,34 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
         }
         const unsigned my = (y0 - 3 < 0 || y0 + MORPH_RB + 2 > g.H - 1) ? 2u : 1u;
         const unsigned mx = (w == 0 || 64 * (w + 1) + 3 > g.W - 1) ? 2u : 1u;
-        if (total * my * mx < 5u) {
-            for (int ya = y0; ya < y0 + MORPH_RB && ya < g.H; ++ya) {
-                dst[(size_t)ya * g.WW + w] = 0;
-                dzero[(size_t)ya * g.WW + w] = 0;
-            }
-            return;
-        }
+        keep = total * my * mx >= 5u;
     }
+    const u64 m = __ballot(keep);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(workcount, (unsigned)__popcll(m));
+    base = __shfl(base, 0);
+    if (keep) worklist[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
+}
+
+// One thread owns one listed block (a word column x a band of RB rows) and slides down it with 3-row pipelines.
+__global__ void __launch_bounds__(64) k_morph_close(const u64* __restrict__ bbits, const unsigned* __restrict__ worklist,
+                                                    const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
+                                                    unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+  const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
+  const unsigned nwork = *workcount;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < nwork; e += gridDim.x * blockDim.x) {
+    const unsigned item = worklist[e];
+    const int i = item / (unsigned)(nb * g.WW);
+    const int tid = item - (unsigned)i * (unsigned)(nb * g.WW);
+    const int band = tid / g.WW, w = tid - band * g.WW;
+    const int y0 = band * MORPH_RB;
+    const Win q = make_win(w, g.W);
+    const u64* src = bbits + (size_t)i * g.H * g.WW;
+    const long long t = g.t_base + 1 + i;
+    ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
     u128 hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
     u128 mA = 0, mB = 0;
     u128 dA = 0, dB = 0;
@@ -602,17 +662,17 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
         const int ya = yy - 3;
         if (ya >= y0 && ya < g.H) {
             const u64 a = (u64)((dA & dB & eC & q.valid) >> 3);
-            dst[(size_t)ya * g.WW + w] = a;
-            // words without lit pixels are final (dst = 0); the others go to the sparse dynamic-mask pass
-            if (a)
+            // Only words with lit pixels are stored, and listed for the sparse dynamic-mask pass.
+            if (a) {
+                dst[(size_t)ya * g.WW + w] = ActWord{a, (u64)t};
                 nzlist[atomicAdd(nzcount, 1u)] = (unsigned)((size_t)i * g.H * g.WW + (size_t)ya * g.WW + w);
-            else
-                dzero[(size_t)ya * g.WW + w] = 0;
+            }
         }
         hA0 = hB0; hA1 = hB1; hB0 = hC0; hB1 = hC1;
         mA = mB; mB = mC;
         dA = dB; dB = eC;
     }
+  }
 }
 
 // a8 + a9 count.  Dynamic mask (Detector.py:234-242): a pixel is "alive" unless it was lit in ALL of the last
@@ -620,34 +680,65 @@ __global__ void __launch_bounds__(256) k_morph_close(const u64* __restrict__ bbi
 // Only words with lit pixels need the mask, and those are rare, so alive is evaluated on the fly from the ring of
 // binaries for the 3x3 word neighbourhood instead of being materialised for the whole frame.
 // Also: per-row and per-frame popcounts.
-__global__ void __launch_bounds__(256) k_dy_sparse(const u64* __restrict__ act_ring, u64* __restrict__ dst_bits,
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+// SIXTEEN LANES PER LISTED WORD (four words per wave): lane 3 * (dy + 1) + (k + 1) of a group fetches word w + k of row
+// y + dy from each of the len history frames (independent loads) and ANDs them; the 3x3 erode is finished by lanes 1,
+// 4, 7 of the group (one per row) and lane 0 stores the result.
+__global__ void __launch_bounds__(256) k_dy_sparse(const ActWord* __restrict__ act_ring, u64* __restrict__ dst_bits,
                                                    const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount,
                                                    int* __restrict__ rowcount, int* __restrict__ litcount,
                                                    int* __restrict__ bbox, PassGeom g, int use_dy) {
+    RAISE_WAVE_PRIORITY();
     const int words = g.H * g.WW;
     const unsigned total = *nzcount;
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const unsigned idx = nzlist[e];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, gbase = lane & 48;
+    const unsigned ngroups = gridDim.x * (blockDim.x >> 4);
+    const int dy = sub / 3 - 1, k = sub % 3 - 1;  // sub >= 9: idle
+    const unsigned first_e = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    // all lanes of a wave run the same number of iterations (shuffles inside)
+    for (unsigned e0 = first_e - (lane >> 4); e0 < total; e0 += ngroups) {
+        const unsigned e = e0 + (lane >> 4);
+        const bool live = e < total;
+        const unsigned idx = live ? nzlist[e] : 0u;
         const int i = idx / words, gw = idx - i * words;
         const int y = gw / g.WW, w = gw - y * g.WW;
         const long long t = g.t_base + 1 + i;
-        u64 out = act_ring[(size_t)((t - 1) % g.R) * words + gw];
+        u64 out;
         if (use_dy) {
-            const Win q = make_win(w, g.W);
             const int len = window_len(g, i);
-            u128 e3 = ~(u128)0;
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int yy = y + dy;
-                if (yy < 0 || yy >= g.H) continue;
-                u128 all = ~(u128)0;
-                for (int j = 0; j < len; ++j)
-                    all &= load_win(act_ring + (size_t)((t - 1 - j) % g.R) * words + (size_t)yy * g.WW, w, g.WW);
-                e3 &= hor_and3_open(~all & q.valid, q);
+            const int yy = y + dy, ww = w + k;
+            const bool row_in = sub < 9 && yy >= 0 && yy < g.H;
+            const bool word_in = ww >= 0 && ww < g.WW;
+            u64 all = ~0ull, first = 0;
+            if (live && row_in) {
+                if (word_in) {
+                    for (int j = 0; j < len; ++j) {
+                        const u64 v = act_word(act_ring + (size_t)((t - 1 - j) % g.R) * words, yy * g.WW + ww, (u64)(t - j));
+                        if (j == 0) first = v;
+                        all &= v;
+                    }
+                } else {
+                    all = 0;
+                }
             }
-            out &= (u64)((e3 & q.valid) >> 3);
+            const u64 l = shfl64(all, gbase + ((sub + 15) & 15)), r = shfl64(all, gbase + ((sub + 1) & 15));
+            u64 m = ~0ull;
+            if (row_in) {
+                const Win q = make_win(w, g.W);
+                const u128 a128 = (u128)(l >> 61) | ((u128)all << 3) | ((u128)r << 67);
+                m = (u64)((hor_and3_open(~a128 & q.valid, q) & q.valid) >> 3);
+            }
+            out = shfl64(first, gbase + 4) & shfl64(m, gbase + 1) & shfl64(m, gbase + 4) & shfl64(m, gbase + 7);
+        } else {
+            out = (live && sub == 0) ? act_word(act_ring + (size_t)((t - 1) % g.R) * words, gw, (u64)t) : 0ull;
         }
-        dst_bits[(size_t)i * words + gw] = out;
-        if (out) {
+        if (live && sub == 0 && out) {
+            dst_bits[(size_t)i * words + gw] = out;
             const int c = __popcll(out);
             atomicAdd(&rowcount[i * g.H + y], c);
             atomicAdd(&litcount[i], c);
@@ -661,12 +752,62 @@ __global__ void __launch_bounds__(256) k_dy_sparse(const u64* __restrict__ act_r
     }
 }
 
+// dst (per slot, [K][H][WW]) is written only where it is non-zero, on an all-zero background; this restores the
+// background before the slot's next pass.  nzlist (from k_morph_close) names every word that can be non-zero.
+__global__ void __launch_bounds__(256) k_sparse_clear(u64* __restrict__ dst_bits, const unsigned* __restrict__ nzlist,
+                                                      const unsigned* __restrict__ nzcount) {
+    RAISE_WAVE_PRIORITY();
+    const unsigned total = *nzcount;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) dst_bits[nzlist[e]] = 0;
+}
+
+// Result packing: the segments of a pass, [K][MAX_LINES][4] with nraw[i] valid rows each, are packed back to back
+// (frame order) so that the host fetches them with ONE contiguous copy; off[i] = first packed segment of frame i,
+// off[K] = total.  One workgroup: a scan over the frames, then a thread per frame moves its segments.
+__global__ void __launch_bounds__(1024) k_pack_lines(const int4* __restrict__ lines, const int* __restrict__ nraw, int K,
+                                                     int max_lines, int4* __restrict__ packed, int* __restrict__ off) {
+    RAISE_WAVE_PRIORITY();
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < K; base += 1024) {
+        const int i = base + tid;
+        const int cnt = i < K ? min(nraw[i], max_lines) : 0;
+        int incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int k = 0; k < wave; ++k) before += wsum[k];
+        const int start = before + incl - cnt;
+        if (i < K) {
+            off[i] = start;
+            for (int q = 0; q < cnt; ++q) packed[start + q] = lines[(size_t)i * max_lines + q];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = start + cnt;
+        __syncthreads();
+    }
+    if (tid == 0) off[K] = carry_s;
+}
+
 // bit image -> u8 {0,255} image (mdh_get_binary)
 __global__ void k_expand_bits(const u64* __restrict__ bits, uint8_t* __restrict__ out, int H, int W, int WW) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
     out[p] = ((bits[(size_t)y * WW + (x >> 6)] >> (x & 63)) & 1) ? 255 : 0;
+}
+__global__ void k_expand_act(const ActWord* __restrict__ row, uint8_t* __restrict__ out, int H, int W, int WW, u64 t) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    out[p] = ((act_word(row, y * WW + (x >> 6), t) >> (x & 63)) & 1) ? 255 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1133,6 +1274,7 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
 }
 
 __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
+    RAISE_WAVE_PRIORITY();
     // dynamic LDS: [ point list: list_cap dwords | accumulator cells: cell_cap/2 dwords | 64 dummy dwords ]
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     unsigned* lds_list = lds_dyn;
@@ -1581,6 +1723,7 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
 // LDS: [ point list: list_cap | cells: cell_cap/2 | 256 dummy | 16 mailbox | 180*3 window table ]  (dwords)
 #define HOUGH4_EXTRA_DWORDS (256 + 16 + 3 * NUM_ANGLE)
 __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
+    RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     unsigned* lds_list = lds_dyn;
     unsigned* lds_cells = lds_dyn + P.list_cap;
@@ -1589,6 +1732,7 @@ __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
     const int i = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = P.litcount[i];
+    const long long w0 = P.dbg ? wall_clock64() : 0;
     double gap = P.max_gap;
     if (!P.fixed_gap) {
         const double dst_sum = (double)N / P.mask_area * 100;
@@ -1709,8 +1853,14 @@ __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
         C.span = wtab[3 * tid + 1];
         C.off = wtab[3 * tid + 2];
     }
+    const long long w1 = P.dbg ? wall_clock64() : 0;
     ppht4_grouped(C, N, lds_list);
     if (tid == 0) P.out_nraw[i] = C.found;
+    if (P.dbg && tid == 0) {  // MDH_HOUGH_DEBUG=1: points, tier, 100 MHz ticks (set-up, PPHT), segments, LDS cells
+        long long* d = P.dbg + (size_t)i * 8;
+        d[0] = N; d[1] = P.tier; d[2] = w1 - w0; d[3] = wall_clock64() - w1; d[4] = C.found; d[5] = cells_used;
+        d[6] = wall_clock64(); d[7] = w0;
+    }
     // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
     const unsigned long long any_global = __ballot(C.touched_global);
     if (lane == 0) mbox[12 + wave] = any_global ? 1u : 0u;  // (mbox[12], [13] are no longer needed)

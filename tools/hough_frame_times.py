@@ -1,0 +1,39 @@
+"""Per-frame Hough cost of one bench pass (MDH_HOUGH_DEBUG=1): points, tier, set-up / PPHT time, segments."""
+import os, sys, ctypes as C
+os.environ["MDH_HOUGH_DEBUG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from metdetpy_amd import M3Detector, _lib
+from metdetpy_amd.synth import SkyStream
+
+H, W, n, B, uniq = 1080, 1920, 8, 1024, 256
+mask = np.ones((H, W), np.uint8)
+frames = SkyStream(H, W, bench.WORKLOADS["C2"]["seed"]).take(uniq)
+det = M3Detector(1, n, mask, 10, bench.make_cfg(), None, max_batch=B)
+ctx = det._ctx
+pool = ctx.device_alloc(B * H * W)
+for start in range(0, B, uniq):
+    ctx.device_upload(pool + start * H * W, frames)
+info = np.zeros(B, _lib.FRAME_INFO_DTYPE)
+for _ in range(3):
+    ctx.process_batch_into(pool, B, True, info, None, None, None)
+dbg = np.zeros((B, 8), np.int64)
+rc = ctx.L.mdh_debug_hough(C.c_void_p(ctx.handle), dbg.ctypes.data_as(C.POINTER(C.c_longlong)), B)
+assert rc == 0
+act = dbg[:, 0] > 0
+t = dbg[:, 3] / 100.0  # us
+print("frames with points", int(act.sum()), "of", B, " tiers:", {int(k): int((dbg[act, 1] == k).sum()) for k in np.unique(dbg[act, 1])})
+print("points: median %d  p90 %d  max %d" % tuple(np.percentile(dbg[act, 0], [50, 90, 100])))
+print("PPHT us: median %.1f  p90 %.1f  p99 %.1f  max %.1f   sum %.0f" % (*np.percentile(t[act], [50, 90, 99, 100]), t[act].sum()))
+print("set-up us: median %.1f max %.1f" % tuple(np.percentile(dbg[act, 2] / 100.0, [50, 100])))
+span = (dbg[act, 6].max() - dbg[act, 7].min()) / 100.0
+print("first start -> last end: %.1f us" % span)
+order = np.argsort(-t)[:12]
+for i in order:
+    print("frame %4d  N %5d  tier %d  ppht %.1f us  segs %d  cells %d  start +%.1f us" % (i, dbg[i, 0], dbg[i, 1], t[i], dbg[i, 4], dbg[i, 5], (dbg[i, 7] - dbg[act, 7].min()) / 100.0))
+# time vs N
+for lo, hi in ((1, 50), (50, 200), (200, 500), (500, 1000), (1000, 4000), (4000, 100000)):
+    m = act & (dbg[:, 0] >= lo) & (dbg[:, 0] < hi)
+    if m.any():
+        print("N in [%d,%d): %d frames, mean ppht %.1f us, mean segs %.1f" % (lo, hi, m.sum(), t[m].mean(), dbg[m, 4].mean()))
