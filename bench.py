@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one native pass (mdh_submit_batch / mdh_collect_batch, up to three passes in flight) over a batch of `--batch` consecutive frames of a seeded synthetic
+One "step" = one native pass (mdh_submit_batch / mdh_collect_batch, several passes in flight) over a batch of `--batch` consecutive frames of a seeded synthetic
 night-sky stream that is already resident in HBM (a pool of `--batch` frames per GPU, cycled): update + detect incl.
 Hough and NMS, results on the host.  N > 1: one process per GPU (torchrun), one independent stream per GPU
 (BASELINE config C4), no data-path collective; RCCL only gathers the per-rank detection counts at the end.
@@ -184,11 +184,11 @@ def main():
         tally[2] += int(info["lit_count"].sum())
 
     def run(nsteps):
-        """nsteps passes, up to _lib.MAX_IN_FLIGHT queued: later passes are submitted before earlier ones are collected,
+        """nsteps passes, up to ctx.max_in_flight queued: later passes are submitted before earlier ones are collected,
         so the pixel stages of one pass overlap the Hough stage of the previous one and the host stays ahead of the
         GPU.  Every pass is fully collected before run() returns."""
         for _s in range(nsteps):
-            if ctx.in_flight == _lib.MAX_IN_FLIGHT:
+            if ctx.in_flight == ctx.max_in_flight:
                 collect()
             ctx.submit(pool, B, True)
         while ctx.in_flight:

@@ -96,11 +96,13 @@ int mdh_process_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device,
 
 /* Asynchronous form of mdh_process_batch for K <= cfg.max_batch: mdh_submit_batch queues the pass and returns at
  * once; mdh_collect_batch waits for the OLDEST queued pass and returns its frame count (> 0) or a negative error.
- * At most three passes may be in flight; the pixel stages of a later pass overlap the Hough stage of an earlier one.
+ * At most mdh_max_in_flight(ctx) passes (4 by default) may be in flight; the window kernel of a later pass overlaps the
+ * morphology / Hough stages of the earlier ones.
  * `frames` must stay valid (and, for device memory, unmodified) until its pass has been collected. */
 int mdh_submit_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device);
 int mdh_collect_batch(mdh_ctx* ctx, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);
 int mdh_in_flight(const mdh_ctx* ctx);
+int mdh_max_in_flight(const mdh_ctx* ctx);
 
 /* The binary image `dst` (H*W u8 of {0,255}) of frame `index` of the most recent pass (0 .. frames_in_pass-1;
  * -1 = the last frame).  For visu() and parity tests.  stage: 0 = dst (after the dynamic mask), 1 = the image

@@ -15,7 +15,6 @@ LIB_PATH = os.path.join(_HERE, "libmetdet_hip.so")
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
-MAX_IN_FLIGHT = 3
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 SENSITIVITY_ID = {"low": 0, "normal": 1, "high": 2}
 
@@ -42,7 +41,7 @@ EXPORTS = [
     "mdh_create", "mdh_destroy", "mdh_last_error", "mdh_update", "mdh_detect", "mdh_process_batch", "mdh_get_binary",
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
-    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_debug_hough"
+    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough"
 ]
 
 _lib = None
@@ -73,6 +72,7 @@ def load():
     L.mdh_submit_batch.argtypes = [vp, vp, i32, i32]
     L.mdh_collect_batch.argtypes = [vp, vp, vp, vp, vp]
     L.mdh_in_flight.argtypes = [vp]
+    L.mdh_max_in_flight.argtypes = [vp]
     L.mdh_get_binary.argtypes = [vp, i32, i32, vp]
     L.mdh_lineset_nms.argtypes = [vp, i32, vp, vp]
     L.mdh_device_alloc.argtypes = [vp, u64]
@@ -180,7 +180,7 @@ class Context:
                                        prob.ctypes.data if prob is not None else None), "mdh_process_batch")
 
     def submit(self, ptr, K, on_device):
-        """Queue a pass of K <= max_batch frames and return at once (at most MAX_IN_FLIGHT passes may be queued).  The
+        """Queue a pass of K <= max_batch frames and return at once (at most self.max_in_flight passes may be queued).  The
         frames must stay valid until the pass has been collected."""
         check(self.L.mdh_submit_batch(self.handle, int(ptr), int(K), int(bool(on_device))), "mdh_submit_batch")
 
@@ -196,6 +196,10 @@ class Context:
     @property
     def in_flight(self) -> int:
         return self.L.mdh_in_flight(self.handle)
+
+    @property
+    def max_in_flight(self) -> int:
+        return self.L.mdh_max_in_flight(self.handle)
 
     def get_binary(self, index=-1, stage=0):
         out = np.empty((self.H, self.W), np.uint8)

@@ -49,7 +49,7 @@ struct ProfSpan {
     hipEvent_t a, b;
 };
 
-#define NSLOT 3
+#define NSLOT_MAX 6  // slots allocated at most; ctx->nslot (default 4, MDH_SLOTS) passes may be in flight
 #define NHSET 2  // Hough buffer / stream sets available; MDH_HOUGH_SETS (default 1) of them are used
 #define PACK_HEAD 8  // packed segments per frame (pass average) copied to the host without waiting for the counts
 
@@ -69,6 +69,11 @@ struct Slot {
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;
     hipEvent_t ev_prep = nullptr;
+    u64* d_bbits = nullptr;          // [K][H][WW] b = (diff > T), written by the window kernel, read by the morphology
+    u64* d_planes = nullptr;         // Classic: [K][2][H][WW]
+    unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output
+    hipEvent_t ev_k1 = nullptr;      // window kernel done (main stream) -> the post stream may start
+    hipEvent_t ev_close = nullptr;   // binaries of this pass are in the ring (the next pass's dynamic mask reads them)
     u64* d_dst = nullptr;
     int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr, *d_bbox = nullptr;
     FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
@@ -99,11 +104,14 @@ struct mdh_ctx {
     int H = 0, W = 0, WW = 0, n = 0, R = 0, Kmax = 0;
     size_t HW = 0, words = 0;
     mdh_cfg cfg{};
-    hipStream_t stream = nullptr;                   // main: pixel stages
+    hipStream_t mstream[2] = {nullptr, nullptr};    // main streams: window kernel of even / odd passes
+    hipStream_t stream = nullptr;                   // the main stream of the pass being queued
     hipStream_t nstream = nullptr;                  // staging + noise / threshold chain (runs one pass ahead of the main stream)
     HoughSet hset[NHSET];
+    hipEvent_t ev_base = nullptr;  // MDH_HOST_LOG: origin of the GPU-side span times
     unsigned tag_lds = 0;  // MDH_TAG_PASS=1: dynamic LDS bytes that tag a pass's kernels in a rocprofv3 trace (1024 * (1 + pass % 3))
-    int nhset = 1;  // sets in use: with 2, the Hough stages of consecutive passes overlap (experiment switch MDH_HOUGH_SETS)
+    int nhset = 2;
+    int nmain = 1;  // sets in use: with 2, the Hough stages of consecutive passes overlap (experiment switch MDH_HOUGH_SETS)
     int64_t pass_seq = 0;
     hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
     int64_t t = 0;  // frames submitted (SlidingWindow.timer)
@@ -124,13 +132,14 @@ struct mdh_ctx {
     int* d_thr = nullptr;
     unsigned* d_bandflag = nullptr;
     ScalarState* d_state = nullptr;  // running scalars, only touched on the noise stream
-    u64 *d_bbits = nullptr, *d_planes = nullptr;
+    u64* d_bbits = nullptr;    // alias of the current slot's buffer (set by slot_begin)
     ActWord* d_act = nullptr;  // [R][H][WW] tagged sparse ring of closed binaries
-    unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output (main stream only)
+    int prev_slot = -1;        // slot of the pass submitted before the one being queued
     float* d_trig = nullptr;
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     uint8_t* d_expand = nullptr;
-    Slot slot[NSLOT];
+    Slot slot[NSLOT_MAX];
+    int nslot = 4;
     int next_slot = 0;       // slot the next submitted pass takes
     int oldest = 0;          // slot of the oldest pass not yet collected
     int in_flight = 0;
@@ -158,6 +167,7 @@ extern "C" const char* mdh_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KERNELS) ? kKernelNames[k] : ""; }
 extern "C" int64_t mdh_frames_seen(const mdh_ctx* c) { return c ? c->t : -1; }
 extern "C" int mdh_in_flight(const mdh_ctx* c) { return c ? c->in_flight : -1; }
+extern "C" int mdh_max_in_flight(const mdh_ctx* c) { return c ? c->nslot : -1; }
 
 template <typename T>
 static int dev_alloc(T*& p, size_t count, bool zero = true) {
@@ -177,6 +187,16 @@ static inline double now_us() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
+static bool g_host_log = getenv("MDH_HOST_LOG") != nullptr;  // per-call host timestamps (three clocks, to line up with a trace)
+static void host_log(const char* what, long long seq) {
+    if (!g_host_log) return;
+    timespec a, b, c;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    clock_gettime(CLOCK_MONOTONIC_RAW, &b);
+    clock_gettime(CLOCK_BOOTTIME, &c);
+    fprintf(stderr, "[mdh log] %-14s seq %lld  mono %lld  raw %lld  boot %lld\n", what, seq, a.tv_sec * 1000000000LL + a.tv_nsec,
+            b.tv_sec * 1000000000LL + b.tv_nsec, c.tv_sec * 1000000000LL + c.tv_nsec);
+}
 
 static void free_all(mdh_ctx* c) {
     if (!c) return;
@@ -186,12 +206,11 @@ static void free_all(mdh_ctx* c) {
                 c->host_us[3] / c->host_n);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_bbits,
-                   c->d_act, c->d_worklist, c->d_planes, c->d_trig, c->d_hdbg, c->d_expand};
+    void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand};
     for (void* p : dev)
         if (p) hipFree(p);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_packed, s.d_off, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap, s.d_ptrtab, s.d_jobs, s.d_sums, s.d_jobres, s.d_thr};
+        void* sdev[] = {s.d_bbits, s.d_planes, s.d_worklist, s.d_packed, s.d_off, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap, s.d_ptrtab, s.d_jobs, s.d_sums, s.d_jobres, s.d_thr};
         for (void* p : sdev)
             if (p) hipFree(p);
         void* shost[] = {s.h_off, s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
@@ -199,6 +218,8 @@ static void free_all(mdh_ctx* c) {
             if (p) hipHostFree(p);
         if (s.ev_noise) hipEventDestroy(s.ev_noise);
         if (s.ev_prep) hipEventDestroy(s.ev_prep);
+        if (s.ev_k1) hipEventDestroy(s.ev_k1);
+        if (s.ev_close) hipEventDestroy(s.ev_close);
         if (s.ev_pix) hipEventDestroy(s.ev_pix);
         if (s.ev_done) hipEventDestroy(s.ev_done);
         for (auto& sp : s.spans) {
@@ -214,7 +235,7 @@ static void free_all(mdh_ctx* c) {
         for (hipStream_t q : h.stream)
             if (q) hipStreamDestroy(q);
     }
-    hipStream_t st[] = {c->stream, c->nstream, c->cstream};
+    hipStream_t st[] = {c->mstream[0], c->mstream[1], c->nstream, c->cstream};
     for (hipStream_t q : st)
         if (q) hipStreamDestroy(q);
     delete c;
@@ -235,7 +256,9 @@ static int create_impl(mdh_ctx* c) {
         return use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(name, 0))
                         : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     };
-    HIPCHK(make_stream(&c->stream, "MDH_PRIO_MAIN"));
+    HIPCHK(make_stream(&c->mstream[0], "MDH_PRIO_MAIN"));
+    HIPCHK(make_stream(&c->mstream[1], "MDH_PRIO_MAIN"));
+    c->stream = c->mstream[0];
     HIPCHK(make_stream(&c->nstream, "MDH_PRIO_NOISE"));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     for (int hi = 0; hi < c->nhset; ++hi) {
@@ -251,12 +274,7 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
     TRY(dev_alloc(c->d_zero, HW));
     TRY(dev_alloc(c->d_state, 1));
-    TRY(dev_alloc(c->d_bbits, K * words));
-    if (c->cfg.detector == MDH_DET_M3) {
-        TRY(dev_alloc(c->d_act, (size_t)c->R * words));
-        TRY(dev_alloc(c->d_worklist, K * nb * c->WW, false));
-    }
-    if (c->cfg.detector == MDH_DET_CLASSIC) TRY(dev_alloc(c->d_planes, 2 * K * words));
+    if (c->cfg.detector == MDH_DET_M3) TRY(dev_alloc(c->d_act, (size_t)c->R * words));
     for (int hi = 0; hi < c->nhset; ++hi) {
         HoughSet& h = c->hset[hi];
         TRY(dev_alloc(h.d_work, K * words));
@@ -267,7 +285,8 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
-    for (Slot& s : c->slot) {
+    for (int si = 0; si < c->nslot; ++si) {
+        Slot& s = c->slot[si];
         TRY(host_alloc(s.h_ptrtab, c->n - 1 + K));
         TRY(host_alloc(s.h_jobs, K));
         TRY(dev_alloc(s.d_ptrtab, c->n - 1 + K));
@@ -277,6 +296,14 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_thr, K));
         HIPCHK(hipEventCreateWithFlags(&s.ev_noise, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_k1, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_close, hipEventDisableTiming));
+        if (c->cfg.detector == MDH_DET_M3) {
+            TRY(dev_alloc(s.d_bbits, K * words));
+            TRY(dev_alloc(s.d_worklist, K * nb * c->WW, false));
+        } else {
+            TRY(dev_alloc(s.d_planes, 2 * K * words));
+        }
         TRY(dev_alloc(s.d_bandflag, K * nb * c->WW));
         TRY(dev_alloc(s.d_nzlist, K * words, false));
         TRY(dev_alloc(s.d_nzcount, 2));  // [0] listed words, [1] listed morphology blocks
@@ -377,8 +404,9 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->WW = (W + 63) / 64;
     c->n = n_window;
     c->Kmax = cfg->max_batch > 0 ? cfg->max_batch : 64;
-    // the frame / binary rings must hold the history plus NSLOT passes in flight
-    c->R = c->n - 1 + NSLOT * c->Kmax;
+    if (const char* v = getenv("MDH_SLOTS")) c->nslot = std::max(2, std::min(NSLOT_MAX, atoi(v)));
+    // the frame / binary rings must hold the history plus every pass in flight
+    c->R = c->n - 1 + c->nslot * c->Kmax;
     if (c->R < c->n) c->R = c->n;
     c->HW = (size_t)H * W;
     c->words = (size_t)H * c->WW;
@@ -391,6 +419,8 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->hough_global_acc = env_on("MDH_HOUGH_GLOBAL_ACC");
     c->hough_one_wave = env_on("MDH_HOUGH_ONE_WAVE") || c->hough_serial;
     if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
+    if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
+
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
         free_all(c);
@@ -423,6 +453,12 @@ static void spans_collect(mdh_ctx* c, Slot& sl) {
             c->prof_ms[s.kind] += ms;
             c->prof_n[s.kind] += 1;
         }
+        if (g_host_log && c->ev_base) {  // GPU-side timeline without a profiler attached
+            float t_a = 0, t_b = 0;
+            hipEventElapsedTime(&t_a, c->ev_base, s.a);
+            hipEventElapsedTime(&t_b, c->ev_base, s.b);
+            fprintf(stderr, "[mdh gpu] %-16s start %.1f us  end %.1f us\n", kKernelNames[s.kind], t_a * 1e3, t_b * 1e3);
+        }
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
@@ -431,6 +467,12 @@ static void spans_collect(mdh_ctx* c, Slot& sl) {
 extern "C" int mdh_profile_enable(mdh_ctx* c, int on) {
     if (!c) return MDH_E_ARG;
     c->prof = on != 0;
+    if (c->prof && g_host_log && !c->ev_base) {
+        hipEventCreate(&c->ev_base);
+        hipEventRecord(c->ev_base, c->stream);
+        hipEventSynchronize(c->ev_base);
+        host_log("gpu time base", 0);
+    }
     return MDH_OK;
 }
 extern "C" int mdh_profile_read(mdh_ctx* c, double* ms, int64_t* launches, int reset) {
@@ -617,31 +659,47 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     PassGeom g = geom(c, K, t_base);
     const int words = (int)c->words;
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
+    // Main stream: nothing but the window kernel (the one stage that fills the machine), pass after pass.  Everything
+    // downstream of it -- morphology, dynamic mask, Hough, result packing -- is short or latency-bound and runs on the
+    // pass's post streams, overlapping the window kernel of the following pass(es).
+    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
+    hipStream_t* hstream = hs.stream;
+    hipStream_t post = hstream[0];
     HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_noise, 0));  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
         launch_stack_threshold(c, g);
         span_end(c, c->stream);
-        HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_prep, 0));  // act ring rows and dst of this slot are all-zero again
-        span_begin(c, KK_MORPH, c->stream);
-        hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, c->stream, sl.d_bandflag,
-                           c->d_worklist, sl.d_nzcount + 1, g);
-        hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, c->stream, c->d_bbits, c->d_worklist, sl.d_nzcount + 1, c->d_act,
-                           sl.d_nzlist, sl.d_nzcount, g);
-        span_end(c, c->stream);
-        span_begin(c, KK_DY_APPLY, c->stream);
-        hipLaunchKernelGGL(k_dy_sparse, dim3(2048), dim3(256), 0, c->stream, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
-                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
-        span_end(c, c->stream);
     } else {
         span_begin(c, KK_CLASSIC, c->stream);
-        hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, c->d_planes, g);
-        hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, c->stream, c->d_planes, sl.d_dst,
-                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
+        hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, sl.d_planes, g);
         span_end(c, c->stream);
     }
-    HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(sl.ev_pix, c->stream));
+    HIPCHK(hipEventRecord(sl.ev_k1, c->stream));
+    HIPCHK(hipStreamWaitEvent(post, sl.ev_k1, 0));
+    HIPCHK(hipStreamWaitEvent(post, sl.ev_prep, 0));  // dst of this slot is all-zero again
+    if (c->cfg.detector == MDH_DET_M3) {
+        span_begin(c, KK_MORPH, post);
+        hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_bandflag,
+                           sl.d_worklist, sl.d_nzcount + 1, g);
+        hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_nzcount + 1, c->d_act,
+                           sl.d_nzlist, sl.d_nzcount, g);
+        span_end(c, post);
+        HIPCHK(hipEventRecord(sl.ev_close, post));
+        // the dynamic mask looks n-1 frames back: the previous pass's binaries (written on another post stream when the
+        // Hough sets alternate) must be in the ring; older passes are ordered by the streams themselves
+        if (c->prev_slot >= 0 && c->prev_slot != (int)(&sl - c->slot))
+            HIPCHK(hipStreamWaitEvent(post, c->slot[c->prev_slot].ev_close, 0));
+        span_begin(c, KK_DY_APPLY, post);
+        hipLaunchKernelGGL(k_dy_sparse, dim3(2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
+                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
+        span_end(c, post);
+    } else {
+        hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
+                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
+    }
+    HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, post));
+    HIPCHK(hipEventRecord(sl.ev_pix, post));
     HoughParams P;
     P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
     P.threshold = c->cfg.hough_threshold;
@@ -652,8 +710,6 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     P.no_lds_acc = c->hough_global_acc;
     P.dbg = c->d_hdbg;
     P.mask_area = c->cfg.mask_area;
-    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t* hstream = hs.stream;
     P.dst_bits = sl.d_dst; P.work_bits = hs.d_work; P.rowcount = sl.d_rowcount; P.litcount = sl.d_litcount;
     P.accum = hs.d_accum; P.nz_orig = hs.d_nz_orig; P.nz_work = hs.d_nz_work; P.nz_cap = (long long)c->HW;
     P.out_lines = sl.d_lines; P.out_nraw = sl.d_nraw; P.out_gap = sl.d_gap; P.trig = c->d_trig;
@@ -663,10 +719,8 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     // big-LDS launch (1 frame per CU) takes the rest; both evaluate the same fit test from the lit count and bounding
     // box, so they run side by side.  They start once this pass's pixel stages are done and the pass that used this
     // Hough set before (two passes ago) has released its accumulators / point lists.
-    for (int h = 0; h < 2; ++h) {
-        HIPCHK(hipStreamWaitEvent(hstream[h], sl.ev_pix, 0));
-        if (hs.last_slot >= 0) HIPCHK(hipStreamWaitEvent(hstream[h], c->slot[hs.last_slot].ev_done, 0));
-    }
+    HIPCHK(hipStreamWaitEvent(hstream[1], sl.ev_pix, 0));
+    // (the set's previous user queued its work on these same streams, so its buffers are free by stream order)
     span_begin(c, KK_HOUGH, hstream[0]);
     if (c->hough_one_wave) {
         P.small_list = 4096; P.small_cells = 32000;
@@ -703,6 +757,7 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     HIPCHK(hipMemcpyAsync(sl.h_gap, sl.d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, hstream[0]));
     HIPCHK(hipEventRecord(sl.ev_done, hstream[0]));
     hs.last_slot = (int)(&sl - c->slot);
+    c->prev_slot = (int)(&sl - c->slot);
     c->pass_seq += 1;
     return MDH_OK;
 }
@@ -794,17 +849,20 @@ extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, 
 // Take the next slot for a pass of K frames.  The slot's previous pass must have been collected.
 static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     if (K < 1 || K > c->Kmax) { set_err("pass size must be 1..max_batch"); return MDH_E_ARG; }
-    if (c->in_flight >= NSLOT) { set_err("three passes are already in flight: collect one first"); return MDH_E_STATE; }
+    if (c->in_flight >= c->nslot) { set_err("the maximum number of passes is already in flight: collect one first"); return MDH_E_STATE; }
     Slot& sl = c->slot[c->next_slot];
     if (sl.busy) { set_err("internal: slot still busy"); return MDH_E_STATE; }
     // the main stream may not overwrite this slot's buffers before the Hough stage that last read them is done
+    // MDH_MAIN_STREAMS=2 (experiment): consecutive passes alternate between two main streams, so the next window kernel
+    // fills the machine while the last workgroups of the previous one drain.  Measured slower: the post stages starve.
+    c->stream = c->mstream[c->pass_seq % c->nmain];
     if (sl.used) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
     sl.K = K;
     sl.t_base = c->t;
     if (getenv("MDH_TAG_PASS")) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
     c->cur_spans = &sl.spans;
     c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr;
-    c->d_bandflag = sl.d_bandflag;
+    c->d_bandflag = sl.d_bandflag; c->d_bbits = sl.d_bbits;
     out = &sl;
     return MDH_OK;
 }
@@ -812,7 +870,7 @@ static void slot_commit(mdh_ctx* c, Slot& sl) {
     sl.busy = true;
     sl.used = true;
     c->t += sl.K;
-    c->next_slot = (c->next_slot + 1) % NSLOT;
+    c->next_slot = (c->next_slot + 1) % c->nslot;
     c->in_flight += 1;
 }
 
@@ -820,6 +878,7 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
     Slot* sl = nullptr;
     int rc;
     const double t0 = now_us();
+    host_log("submit begin", c->pass_seq);
     if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
     // staging stream: pointer table (built from the history BEFORE this pass), history copies, noise / thresholds;
     // main stream: pixel stages once the thresholds are there
@@ -829,6 +888,7 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
     if ((rc = run_detect(c, *sl, K)) != MDH_OK) return rc;
     slot_commit(c, *sl);
     c->host_us[0] += now_us() - t0;
+    host_log("submit end", c->pass_seq - 1);
     return MDH_OK;
 }
 
@@ -838,7 +898,9 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
     Slot& sl = c->slot[c->oldest];
     const int K = sl.K;
     const double t0 = now_us();
+    host_log("collect begin", c->pass_seq - c->in_flight);
     HIPCHK(hipEventSynchronize(sl.ev_done));
+    host_log("collect woke", c->pass_seq - c->in_flight);
     const double t1 = now_us();
     spans_collect(c, sl);
     // the head of the packed segment array came with the scalars; fetch the tail if there is one
@@ -880,7 +942,7 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
     c->host_n += 1;
     sl.busy = false;
     c->last_slot = c->oldest;
-    c->oldest = (c->oldest + 1) % NSLOT;
+    c->oldest = (c->oldest + 1) % c->nslot;
     c->in_flight -= 1;
     if (K_out) *K_out = K;
     return MDH_OK;
@@ -924,7 +986,7 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = c->slot[c->next_slot];
     int rc;
-    c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr; c->d_bandflag = sl.d_bandflag;
+    c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr; c->d_bandflag = sl.d_bandflag; c->d_bbits = sl.d_bbits;
     c->h_ptrtab = sl.h_ptrtab;
     c->cur_spans = &sl.spans;
     if ((rc = run_detect(c, sl, 1)) != MDH_OK) return rc;
@@ -939,11 +1001,11 @@ extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int o
     if (c->pending) { set_err("mdh_process_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_process_batch: collect the submitted passes first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    // chunks of at most max_batch frames, up to NSLOT in flight: later chunks are queued before chunk j is collected
+    // chunks of at most max_batch frames, up to nslot in flight: later chunks are queued before chunk j is collected
     int submitted = 0, collected = 0;
     while (collected < K) {
         int rc;
-        while (submitted < K && c->in_flight < NSLOT) {
+        while (submitted < K && c->in_flight < c->nslot) {
             const int k = std::min(K - submitted, c->Kmax);
             if ((rc = submit_pass(c, frames + (size_t)submitted * c->HW, k, on_device)) != MDH_OK) return rc;
             submitted += k;

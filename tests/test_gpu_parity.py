@@ -342,7 +342,7 @@ def test_submit_collect_pipeline_equals_process_batch():
                      np.zeros((k, 512), np.float64))
     pending = []
     for buf in bufs:
-        if ctx.in_flight == _lib.MAX_IN_FLIGHT:
+        if ctx.in_flight == ctx.max_in_flight:
             o = out(len(pending[0])); ctx.collect_into(*o); got.append(o); pending.pop(0)
         ctx.submit(buf.ctypes.data, len(buf), False)
         pending.append(buf)
