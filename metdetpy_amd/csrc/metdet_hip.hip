@@ -1091,7 +1091,7 @@ struct mdh_pre {
 static void linear_table(int dst_n, int src_n, std::vector<int>& idx, std::vector<short>& w) {
     idx.resize(dst_n);
     w.resize(2 * (size_t)dst_n);
-    const double scale = (double)src_n / dst_n;
+    const double scale = 1.0 / ((double)dst_n / src_n);  // resize.cpp: scale = 1. / inv_scale
     for (int d = 0; d < dst_n; ++d) {
         float f = (float)((d + 0.5) * scale - 0.5);
         int s = (int)floorf(f);

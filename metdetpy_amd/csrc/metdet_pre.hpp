@@ -3,7 +3,8 @@
 //   MergeFunction.max         elementwise max over exp_frame processed frames utils.py:202-204
 //   MaxImgContainer           running max over a clip (max_stacker)          stacker.py:43-49, 197-213
 // The OpenCV fixed-point paths are restated (PARITY UNPINNED): 11-bit separable bilinear
-// ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2 and Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+// ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2 and Y = (B*3735 + G*19235 + R*9798 + 16384) >> 15
+// (the 15-bit gray coefficients of OpenCV 4.x, color.hpp RY15/GY15/BY15).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,7 +40,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint8_t* __restrict__ 
             int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
             ch[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
         }
-        const int gray = ((ch[0] * 1868 + ch[1] * 9617 + ch[2] * 4899 + 8192) >> 14) * m;
+        const int gray = ((ch[0] * 3735 + ch[1] * 19235 + ch[2] * 9798 + 16384) >> 15) * m;
         best = max(best, gray & 0xFF);
     }
     out[p] = (uint8_t)best;

@@ -244,6 +244,9 @@ def test_dy_mask_equals_run_length_form():
 def test_bgr2gray_and_resize_kat():
     px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
     assert mo.bgr_to_gray(px).tolist() == [[255, 0, 29, 150, 76]]
+    # 15-bit coefficients (OpenCV 4.x): (17*3735 + 231*19235 + 137*9798 + 16384) >> 15 = 5865490 >> 15 = 179
+    # (the 14-bit set of 2.x/3.x gives 178); (244, 47, 7) -> 1900355 >> 15 = 57 (14-bit: 58)
+    assert mo.bgr_to_gray(np.array([[[17, 231, 137], [244, 47, 7]]], np.uint8)).tolist() == [[179, 57]]
     img = np.arange(16, dtype=np.uint8).reshape(4, 4) * 10
     half = mo.resize_linear(img, (2, 2))
     # exact 2x down-scale == (a+b+c+d+2)>>2
