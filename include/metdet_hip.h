@@ -36,6 +36,12 @@ extern "C" {
 #define MDH_DET_M3 0             /* M3Detector.detect       (Detector.py:324-392) */
 #define MDH_DET_CLASSIC 1        /* ClassicDetector.detect  (Detector.py:257-296) */
 
+/* mdh_cfg.role: what a context runs (row-band tiling of one stream across GPUs, see the end of this file) */
+#define MDH_ROLE_FULL 0          /* the whole path (default) */
+#define MDH_ROLE_BAND 1          /* update() + the pixel stages of detect() on one band of rows (plus halo) */
+#define MDH_ROLE_HOUGH 2         /* detect() from the binary image onwards, on bit planes assembled from the bands */
+#define MDH_BAND_HALO 4          /* rows a band needs from each neighbour: median 1 + dilate 1 + erode 1 + dynamic-mask erode 1 */
+
 #define MDH_SENS_LOW 0
 #define MDH_SENS_NORMAL 1
 #define MDH_SENS_HIGH 2
@@ -53,7 +59,7 @@ typedef struct mdh_cfg {
     int32_t hough_max_gap;       /* cfg.hough_line.max_gap */
     int32_t dy_mask;             /* cfg.dynamic.dy_mask */
     int32_t max_batch;           /* largest K accepted by one internal pass of mdh_process_batch (0 -> 64) */
-    int32_t reserved;
+    int32_t role;                /* MDH_ROLE_* */
     double mask_area;            /* float(np.sum(mask)) (Detector.py:191) */
 } mdh_cfg;
 
@@ -138,6 +144,44 @@ void mdh_pre_destroy(mdh_pre* pre);
  * bytes each (any channel layout). */
 int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint8_t* out,
                   int out_on_device);
+
+/* ---- Row-band tiling of ONE stream across GPUs (BASELINE config 5; SURVEY 8e "spatial row-bands") ----------------
+ *
+ * The frame is cut into nbands bands of band_rows = ceil(H / nbands) rows, one per GPU.  Band b owns rows
+ * [b*band_rows, min(H, (b+1)*band_rows)) and is created (role MDH_ROLE_BAND) on the sub-image made of those rows plus
+ * MDH_BAND_HALO rows of each existing neighbour: every stage of M3Detector.detect before the Hough transform is a 3x3
+ * stencil chain (median, dilate, erode, dynamic-mask erode: Detector.py:329-340, 234-242), so a sub-image processed as
+ * a standalone frame is wrong only within 4 rows of an artificial border, i.e. only inside the halo.  Its cfg.roi is
+ * the part of SNR_SW.std_roi (Detector.py:93-122) inside the OWNED rows, in sub-image coordinates (empty when the band
+ * holds none: roi[2] == roi[0]); cfg.mask_area is the whole frame's.  Per pass of K frames:
+ *
+ *   1. mdh_band_noise      this band's share of the noise sums of the due frames (Detector.py:81-91)
+ *        -> all-reduce(sum) of sums[0 .. 2*n_jobs) over the bands
+ *   2. mdh_band_pixels     thresholds from the global sums, pixel stages, owned rows of the dst bit planes
+ *        -> all-to-all: frame i's rows go to the rank that runs its Hough stage (rank i % nsplit)
+ *   3. mdh_hough_planes    (MDH_ROLE_HOUGH context of the whole frame, any rank) lit count, adaptive gap,
+ *                          HoughLinesP, lineset_nms for the frames whose pieces it received
+ *
+ * All three calls block until their results are ready. */
+
+/* Step 1.  frames: K * H * W u8 (this context's sub-image), host or device.  sums: 2 * K int64 (S1, S2 per due frame,
+ * in frame order); *n_jobs = number of due frames (identical on every band, it depends on the frame counter only). */
+int mdh_band_noise(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device, int64_t* sums, int* n_jobs);
+
+/* Step 2.  sums_total: the all-reduced sums; roi_px_total: pixels of the whole std_roi.  Rows [own_row0, own_row0 +
+ * own_rows) of frame i's dst bit plane (WW = ceil(W/64) u64 words per row, bit k of word w = pixel 64w+k) are written
+ * to dst_rows + (slot(i) * rows_stride) * WW, the rows own_rows .. rows_stride-1 of each slot zero-filled, where
+ * slot(i) = (i % nsplit) * ceil(K / nsplit) + i / nsplit -- the send layout of an equal-split all-to-all in which rank r
+ * receives frames r, r + nsplit, ...; nsplit = 1 gives frame order.  dst_rows: nsplit * ceil(K/nsplit) * rows_stride *
+ * WW u64, host or device.  info (K entries, may be NULL): bi_threshold, bi_threshold_float, snr, sigma filled. */
+int mdh_band_pixels(mdh_ctx* ctx, const int64_t* sums_total, double roi_px_total, int own_row0, int own_rows,
+                    int rows_stride, int nsplit, uint64_t* dst_rows, int out_on_device, mdh_frame_info* info);
+
+/* Step 3.  pieces: nbands * K * band_rows * WW u64; piece b of frame i (rows [b*band_rows, (b+1)*band_rows) of the
+ * frame, rows beyond H ignored) starts at ((b * K + i) * band_rows) * WW -- the receive layout of the all-to-all above.
+ * Outputs as mdh_process_batch (bi_threshold / snr fields of info are left 0: they come from step 2). */
+int mdh_hough_planes(mdh_ctx* ctx, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
+                     mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);
 
 /* Debug: with MDH_HOUGH_DEBUG=1 in the environment at mdh_create, the Hough kernel records 8 cycle counters per frame
  * of the last pass (lit pixels, list build, PPHT total, draws, mask checks, votes, trigger scan, line handling). */

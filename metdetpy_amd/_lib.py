@@ -16,6 +16,8 @@ MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
+MDH_ROLE_FULL, MDH_ROLE_BAND, MDH_ROLE_HOUGH = 0, 1, 2
+MDH_BAND_HALO = 4
 SENSITIVITY_ID = {"low": 0, "normal": 1, "high": 2}
 
 
@@ -23,7 +25,7 @@ class MdhCfg(C.Structure):
     _fields_ = [("detector", C.c_int32), ("adaptive_bi_thre", C.c_int32), ("init_value", C.c_int32),
                 ("sensitivity", C.c_int32), ("interval", C.c_int32), ("roi", C.c_int32 * 4),
                 ("hough_threshold", C.c_int32), ("hough_min_len", C.c_int32), ("hough_max_gap", C.c_int32),
-                ("dy_mask", C.c_int32), ("max_batch", C.c_int32), ("reserved", C.c_int32), ("mask_area", C.c_double)]
+                ("dy_mask", C.c_int32), ("max_batch", C.c_int32), ("role", C.c_int32), ("mask_area", C.c_double)]
 
 
 class MdhFrameInfo(C.Structure):
@@ -41,7 +43,8 @@ EXPORTS = [
     "mdh_create", "mdh_destroy", "mdh_last_error", "mdh_update", "mdh_detect", "mdh_process_batch", "mdh_get_binary",
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
-    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough"
+    "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
+    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes"
 ]
 
 _lib = None
@@ -91,6 +94,9 @@ def load():
     L.mdh_pre_destroy.argtypes = [vp]
     L.mdh_pre_destroy.restype = None
     L.mdh_max_stack.argtypes = [i32, vp, i32, u64, i32, vp, i32]
+    L.mdh_band_noise.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]
+    L.mdh_band_pixels.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32, vp]
+    L.mdh_hough_planes.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -227,6 +233,56 @@ class Context:
         nl = (C.c_int64 * MDH_NUM_KERNELS)()
         check(self.L.mdh_profile_read(self.handle, ms, nl, int(reset)), "mdh_profile_read")
         return {self.L.mdh_kernel_name(k).decode(): (ms[k], nl[k]) for k in range(MDH_NUM_KERNELS)}
+
+    # ---- row-band tiling (include/metdet_hip.h, "Row-band tiling of ONE stream across GPUs") ----
+    def band_noise(self, frames, K=None, on_device=False):
+        """Step 1: stage K sub-image frames, return this band's share of the noise sums (2*n_jobs int64)."""
+        if on_device:
+            ptr = int(frames)
+        else:
+            if frames.ndim != 3 or frames.shape[1:] != (self.H, self.W) or frames.dtype != np.uint8:
+                raise ValueError(f"frames must be uint8 (K,{self.H},{self.W})")
+            frames = np.ascontiguousarray(frames)
+            K, ptr = len(frames), frames.ctypes.data
+        sums = np.zeros(2 * int(K), np.int64)
+        nj = C.c_int(0)
+        check(self.L.mdh_band_noise(self.handle, ptr, int(K), int(bool(on_device)), sums.ctypes.data, C.byref(nj)),
+              "mdh_band_noise")
+        self._band_K = int(K)
+        return sums[:2 * nj.value]
+
+    def band_pixels(self, sums_total, roi_px_total, own_row0, own_rows, rows_stride, nsplit, out=None):
+        """Step 2: thresholds from the global sums, pixel stages, owned dst rows in all-to-all send order.
+        out: None (a host array is returned) or an integer device pointer of nsplit*ceil(K/nsplit)*rows_stride*WW u64."""
+        K = getattr(self, "_band_K", 0) or 1  # without a staged pass the library reports the sequence error
+        WW = (self.W + 63) // 64
+        Kp = -(-K // nsplit)
+        info = np.zeros(K, FRAME_INFO_DTYPE)
+        tot = np.ascontiguousarray(sums_total, dtype=np.int64)
+        tot = tot if len(tot) else np.zeros(2, np.int64)
+        host = None
+        if out is None:
+            host = np.zeros((nsplit, Kp, rows_stride, WW), np.uint64)
+        check(self.L.mdh_band_pixels(self.handle, tot.ctypes.data, float(roi_px_total), int(own_row0), int(own_rows),
+                                     int(rows_stride), int(nsplit), host.ctypes.data if host is not None else int(out),
+                                     int(host is None), info.ctypes.data), "mdh_band_pixels")
+        return host, info
+
+    def hough_planes(self, pieces, K, nbands, band_rows, on_device=False):
+        """Step 3 (MDH_ROLE_HOUGH context): pieces = (nbands, K, band_rows, WW) u64 host array or a device pointer."""
+        if on_device:
+            ptr = int(pieces)
+        else:
+            pieces = np.ascontiguousarray(pieces, dtype=np.uint64)
+            assert pieces.size == nbands * K * band_rows * ((self.W + 63) // 64), pieces.shape
+            ptr = pieces.ctypes.data
+        info = np.zeros(K, FRAME_INFO_DTYPE)
+        raw = np.zeros((K, MDH_MAX_LINES, 4), np.int32)
+        nms = np.zeros((K, MDH_MAX_LINES, 4), np.int32)
+        prob = np.zeros((K, MDH_MAX_LINES), np.float64)
+        check(self.L.mdh_hough_planes(self.handle, ptr, int(K), int(bool(on_device)), int(nbands), int(band_rows),
+                                      info.ctypes.data, raw.ctypes.data, nms.ctypes.data, prob.ctypes.data), "mdh_hough_planes")
+        return info, raw, nms, prob
 
     @property
     def frames_seen(self) -> int:

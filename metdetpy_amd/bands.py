@@ -1,0 +1,266 @@
+"""One stream tiled into row bands across GPUs (BASELINE config 5: a 7680x4320 stream over 8 MI355X; SURVEY 8e
+"spatial row-bands").
+
+Why it shards this way.  Everything `M3Detector.detect` does before `cv2.HoughLinesP` (Detector.py:327-340) is a
+chain of pointwise ops and 3x3 stencils -- median, dilate, erode, and the dynamic mask's erode (Detector.py:234-242) --
+so a band of rows plus MDH_BAND_HALO = 4 rows of each neighbour can be processed as if it were a frame of its own: the
+artificial borders spoil at most the halo rows, which are thrown away.  What is global:
+
+  * the noise sigma (Detector.py:81-91): sums over the sub-ROI, which spans several bands  -> all-reduce of
+    (S1, S2) per due frame, two int64 each; every rank then runs the same EMA / threshold chain,
+  * the Hough transform: sequential per frame (OpenCV's progressive probabilistic Hough), but frames are independent
+    -> the dst bit planes (1 bit per pixel) go through ONE all-to-all per pass so that rank r holds the whole plane
+    of frames r, r + world, ... and runs their Hough stage; the lit-pixel count and the adaptive gap
+    (Detector.py:342-344) are computed there from the assembled plane, so they need no collective of their own,
+  * the results: gathered to rank 0, which owns the MeteorCollector.
+
+Collectives go through torch.distributed ("nccl" = RCCL over xGMI on the GPU box: the band kernels write straight
+into the send buffer in HBM and the Hough context reads the receive buffer in place; "gloo" with host buffers in the
+CPU tests).  torch is plumbing here: rendezvous, buffers for RCCL, collectives.  `LocalBands` runs all bands of a
+frame in one process on one GPU (same code path minus the collectives) for single-GPU parity tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .metstruct import BinaryCfg
+from .utils import select_std_roi
+
+HALO = _lib.MDH_BAND_HALO
+
+
+class BandPlan:
+    """Geometry of the tiling: band b owns rows [own0, own1) and works on rows [sub0, sub1) (owned + halo)."""
+
+    def __init__(self, H: int, W: int, nbands: int, std_roi):
+        if nbands < 1:
+            raise ValueError("nbands must be >= 1")
+        self.H, self.W, self.nbands = int(H), int(W), int(nbands)
+        self.WW = (self.W + 63) // 64
+        self.band_rows = -(-self.H // self.nbands)
+        if (self.nbands - 1) * self.band_rows >= self.H:
+            raise ValueError(f"{H} rows cannot be cut into {nbands} non-empty bands of {self.band_rows} rows")
+        self.std_roi = tuple(int(v) for v in std_roi)
+        r0, c0, r1, c1 = self.std_roi
+        self.roi_px = (r1 - r0) * (c1 - c0)
+        self.bands = []
+        for b in range(self.nbands):
+            own0 = b * self.band_rows
+            own1 = min(self.H, own0 + self.band_rows)
+            sub0, sub1 = max(0, own0 - HALO), min(self.H, own1 + HALO)
+            q0, q1 = max(r0, own0), min(r1, own1)  # rows of the noise ROI this band owns
+            roi = (q0 - sub0, c0, q1 - sub0, c1) if q1 > q0 else (0, c0, 0, c1)
+            self.bands.append(dict(own0=own0, own1=own1, sub0=sub0, sub1=sub1, roi=roi))
+
+    def crop(self, frames: np.ndarray, b: int) -> np.ndarray:
+        """Rows band b works on, of (K,H,W) frames (or of one (H,W) image)."""
+        d = self.bands[b]
+        return np.ascontiguousarray(frames[..., d["sub0"]:d["sub1"], :])
+
+
+class HipBandEngine:
+    """The product engine: one MDH_ROLE_BAND context on this rank's sub-image and one MDH_ROLE_HOUGH context on the whole
+    frame, both on `device`.  (Tests may substitute an engine with the same three methods to exercise the exchange
+    logic without a GPU.)"""
+
+    def __init__(self, plan: BandPlan, b: int, n: int, cfg: BinaryCfg, mask_area: float, max_batch: int, device: int):
+        d = plan.bands[b]
+        self.plan, self.b = plan, b
+
+        def base(role, roi, kmax):
+            c = _lib.MdhCfg()
+            c.detector = _lib.MDH_DET_M3
+            c.adaptive_bi_thre = int(bool(cfg.binary.adaptive_bi_thre))
+            c.init_value = int(cfg.binary.init_value)
+            c.sensitivity = _lib.SENSITIVITY_ID[cfg.binary.sensitivity]
+            c.interval = int(cfg.binary.interval)
+            for k in range(4):
+                c.roi[k] = int(roi[k])
+            c.hough_threshold = int(cfg.hough_line.threshold)
+            c.hough_min_len = int(cfg.hough_line.min_len)
+            c.hough_max_gap = int(cfg.hough_line.max_gap)
+            c.dy_mask = int(bool(cfg.dynamic.dy_mask))
+            c.max_batch = int(kmax)
+            c.role = role
+            c.mask_area = float(mask_area)
+            return c
+
+        self.band = _lib.Context(d["sub1"] - d["sub0"], plan.W, n, base(_lib.MDH_ROLE_BAND, d["roi"], max_batch), device=device)
+        self.kp_max = -(-int(max_batch) // plan.nbands)
+        self.hough = _lib.Context(plan.H, plan.W, 1, base(_lib.MDH_ROLE_HOUGH, (0, 0, 0, 0), self.kp_max), device=device)
+
+    def noise(self, sub_frames):
+        return self.band.band_noise(sub_frames)
+
+    def pixels(self, sums_total, out=None):
+        d = self.plan.bands[self.b]
+        return self.band.band_pixels(sums_total, self.plan.roi_px, d["own0"] - d["sub0"], d["own1"] - d["own0"],
+                                     self.plan.band_rows, self.plan.nbands, out=out)
+
+    def hough_stage(self, pieces, kp, on_device=False):
+        return self.hough.hough_planes(pieces, kp, self.plan.nbands, self.plan.band_rows, on_device=on_device)
+
+    def close(self):
+        self.band.close()
+        self.hough.close()
+
+
+def _package(num_cls, info, raw, nms, prob):
+    """(lines, cls_pred) as M3Detector.detect returns them (Detector.py:358-392)."""
+    n_raw, n_nms = int(info["n_raw"]), int(info["n_nms"])
+    if n_raw == 0 or n_raw > 500:
+        return np.array([]), np.zeros((0, num_cls))
+    pred = np.zeros((n_nms, num_cls))
+    pred[:, -1] = prob[:n_nms]
+    pred[:, 0] = 1 - prob[:n_nms]
+    return nms[:n_nms].copy(), pred
+
+
+class _BandSetup:
+    """What every driver derives from the detector arguments (same constructor as LineDetector, Detector.py:186-220)."""
+
+    def __init__(self, window_sec, fps, mask, num_cls, cfg: BinaryCfg, nbands):
+        self.num_cls = num_cls
+        self.n = int(window_sec * fps)
+        if not 1 <= self.n <= _lib.MDH_MAX_WINDOW:
+            raise ValueError(f"window of {self.n} frames unsupported (1..{_lib.MDH_MAX_WINDOW})")
+        mask = np.asarray(mask)
+        H, W = mask.shape[:2]
+        self.mask_area = float(np.sum(mask))
+        self.plan = BandPlan(H, W, nbands, select_std_roi(mask, cfg.binary.area))
+        self.cfg = cfg
+
+
+def _merge_info(thr_info, hough_info):
+    out = hough_info.copy()
+    for f in ("bi_threshold", "bi_threshold_float", "snr", "sigma"):
+        out[f] = thr_info[f]
+    return out
+
+
+class LocalBands:
+    """All bands of one stream in ONE process on ONE GPU: the same three steps per band, the exchanges done with array
+    copies.  For single-GPU parity tests and for sizing the band path; production runs one BandedM3Detector per GPU."""
+
+    def __init__(self, window_sec, fps, mask, num_cls, cfg, nbands, *, device=0, max_batch=64, engine=HipBandEngine):
+        self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, nbands)
+        p = self.s.plan
+        self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device) for b in range(p.nbands)]
+
+    def detect_batch(self, frames: np.ndarray):
+        """frames: (K,H,W) u8, whole frames.  Returns (results, info) like M3Detector.detect_batch."""
+        p = self.s.plan
+        K, N = len(frames), p.nbands
+        kp = -(-K // N)
+        parts = [e.noise(p.crop(frames, b)) for b, e in enumerate(self.engines)]
+        total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]           # "all-reduce"
+        sent = [e.pixels(total) for e in self.engines]                         # [(N, kp, band_rows, WW), info] per band
+        info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
+        results = [None] * K
+        for r, e in enumerate(self.engines):                                   # "all-to-all": rank r receives slice r of every band
+            mine = len(range(r, K, N))
+            if mine == 0:
+                continue
+            recv = np.stack([sent[b][0][r] for b in range(N)])                 # (N, kp, band_rows, WW)
+            hi, raw, nms, prob = e.hough_stage(recv, kp)
+            for j in range(mine):
+                i = j * N + r
+                info[i] = _merge_info(sent[0][1][i], hi[j])
+                results[i] = _package(self.s.num_cls, hi[j], raw[j], nms[j], prob[j])
+        return results, info
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+
+class BandedM3Detector:
+    """This rank's share of one stream tiled over `world` GPUs (one process per GPU).
+
+    Same constructor arguments as the reference's detectors (`mask` is the WHOLE frame's mask) plus the rank layout.
+    `detect_batch(sub_frames)` takes this rank's rows of K consecutive frames (`plan.crop(frames, rank)`) and returns
+    on rank 0 what `M3Detector.detect_batch` returns for the whole frames; other ranks get (None, info)."""
+
+    def __init__(self, window_sec, fps, mask, num_cls, cfg, logger=None, *, rank: int, world: int, dist=None, device: int = 0,
+                 max_batch: int = 64, engine=HipBandEngine):
+        self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, world)
+        self.rank, self.world, self.dist = int(rank), int(world), dist
+        if world > 1 and dist is None:
+            raise ValueError("world > 1 needs an initialised torch.distributed module (metdetpy_amd.dist.init_from_env)")
+        self.plan = self.s.plan
+        self.engine = engine(self.plan, self.rank, self.s.n, cfg, self.s.mask_area, max_batch, device)
+        self.max_batch = int(max_batch)
+        self._on_gpu = dist is not None and dist.get_backend() == "nccl"
+        self._send = self._recv = None
+
+    # ---- collectives ---------------------------------------------------------------------------
+    def _allreduce_sums(self, sums: np.ndarray) -> np.ndarray:
+        if self.dist is None or len(sums) == 0:
+            return sums
+        import torch
+        t = torch.from_numpy(sums.copy())
+        if self._on_gpu:
+            t = t.cuda()
+        self.dist.all_reduce(t)  # SUM; int64, exact
+        return t.cpu().numpy()
+
+    def _exchange_buffers(self, kp):
+        """Send / receive buffers of the all-to-all, (world, kp_max, band_rows, WW) int64 (bit patterns of u64)."""
+        import torch
+        p = self.plan
+        if self._send is None:
+            shape = (self.world, -(-self.max_batch // self.world), p.band_rows, p.WW)
+            dev = torch.device("cuda", torch.cuda.current_device()) if self._on_gpu else torch.device("cpu")
+            self._send = torch.zeros(shape, dtype=torch.int64, device=dev)
+            self._recv = torch.zeros(shape, dtype=torch.int64, device=dev)
+        return self._send[:, :kp].contiguous() if kp != self._send.shape[1] else self._send, \
+            self._recv[:, :kp].contiguous() if kp != self._recv.shape[1] else self._recv
+
+    def detect_batch(self, sub_frames: np.ndarray):
+        import torch
+        p, N, r = self.plan, self.world, self.rank
+        K = len(sub_frames)
+        if K > self.max_batch:
+            raise ValueError("K exceeds max_batch")
+        kp = -(-K // N)
+        total = self._allreduce_sums(self.engine.noise(sub_frames))
+        if self.dist is None:
+            sent, thr_info = self.engine.pixels(total)
+            recv, on_dev = sent, False  # world == 1: the send layout of one band IS the receive layout
+        elif self._on_gpu:
+            send, recv_t = self._exchange_buffers(kp)
+            _, thr_info = self.engine.pixels(total, out=send.data_ptr())  # kernels write the send buffer in HBM
+            self.dist.all_to_all_single(recv_t, send)                     # RCCL over xGMI
+            torch.cuda.current_stream().synchronize()
+            recv, on_dev = recv_t.data_ptr(), True
+        else:
+            sent, thr_info = self.engine.pixels(total)
+            send = torch.from_numpy(sent.view(np.int64))
+            recv_t = torch.empty_like(send)
+            self.dist.all_to_all_single(recv_t, send)
+            recv, on_dev = recv_t.numpy().view(np.uint64), False
+        mine = len(range(r, K, N))
+        part = []
+        if mine:
+            hi, raw, nms, prob = self.engine.hough_stage(recv, kp, on_device=on_dev)
+            for j in range(mine):
+                part.append((j * N + r, hi[j].copy(), raw[j, :min(int(hi[j]["n_raw"]), _lib.MDH_MAX_LINES)].copy(),
+                             nms[j, :int(hi[j]["n_nms"])].copy(), prob[j, :int(hi[j]["n_nms"])].copy()))
+        if self.dist is None:
+            gathered = [part]
+        else:
+            gathered = [None] * N if r == 0 else None
+            self.dist.gather_object(part, gathered, dst=0)  # the final detection gather
+        if r != 0:
+            return None, thr_info
+        info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
+        results = [None] * K
+        for chunk in gathered:
+            for i, hi, raw, nms, prob in chunk:
+                info[i] = _merge_info(thr_info[i], hi)
+                results[i] = _package(self.s.num_cls, hi, raw, nms, prob)
+        return results, info
+
+    def close(self):
+        self.engine.close()

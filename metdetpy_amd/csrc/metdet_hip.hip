@@ -101,6 +101,7 @@ struct HoughSet {
 
 struct mdh_ctx {
     int device = 0;
+    int role = MDH_ROLE_FULL;
     int H = 0, W = 0, WW = 0, n = 0, R = 0, Kmax = 0;
     size_t HW = 0, words = 0;
     mdh_cfg cfg{};
@@ -144,6 +145,11 @@ struct mdh_ctx {
     int oldest = 0;          // slot of the oldest pass not yet collected
     int in_flight = 0;
     std::vector<const uint8_t*> hist;  // device pointers of the last n-1 frames, oldest first
+    // row-band tiling: pass staged by mdh_band_noise, waiting for the global sums (mdh_band_pixels)
+    Slot* band_slot = nullptr;
+    int band_nj = 0;
+    u64* d_xchg = nullptr;     // exchange staging (band: owned rows going out; Hough: pieces coming in from the host)
+    size_t xchg_words = 0;
     // update()/detect() protocol
     bool pending = false;
     int last_slot = -1;        // slot of the most recently collected pass (mdh_get_binary)
@@ -206,7 +212,7 @@ static void free_all(mdh_ctx* c) {
                 c->host_us[3] / c->host_n);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand};
+    void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg};
     for (void* p : dev)
         if (p) hipFree(p);
     for (Slot& s : c->slot) {
@@ -271,11 +277,15 @@ static int create_impl(mdh_ctx* c) {
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     int rc;
 #define TRY(x) if ((rc = (x)) != MDH_OK) return rc
-    TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
-    TRY(dev_alloc(c->d_zero, HW));
+    // roles (row-band tiling): a BAND context runs no Hough stage, a HOUGH context no pixel stages
+    const bool pix = c->role != MDH_ROLE_HOUGH, hough = c->role != MDH_ROLE_BAND;
+    if (pix) {
+        TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
+        TRY(dev_alloc(c->d_zero, HW));
+        if (c->cfg.detector == MDH_DET_M3) TRY(dev_alloc(c->d_act, (size_t)c->R * words));
+    }
     TRY(dev_alloc(c->d_state, 1));
-    if (c->cfg.detector == MDH_DET_M3) TRY(dev_alloc(c->d_act, (size_t)c->R * words));
-    for (int hi = 0; hi < c->nhset; ++hi) {
+    for (int hi = 0; hi < c->nhset && hough; ++hi) {
         HoughSet& h = c->hset[hi];
         TRY(dev_alloc(h.d_work, K * words));
         TRY(dev_alloc(h.d_accum, K * (size_t)NUM_ANGLE * c->numrho));
@@ -298,14 +308,16 @@ static int create_impl(mdh_ctx* c) {
         HIPCHK(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_k1, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_close, hipEventDisableTiming));
-        if (c->cfg.detector == MDH_DET_M3) {
-            TRY(dev_alloc(s.d_bbits, K * words));
-            TRY(dev_alloc(s.d_worklist, K * nb * c->WW, false));
-        } else {
-            TRY(dev_alloc(s.d_planes, 2 * K * words));
+        if (pix) {
+            if (c->cfg.detector == MDH_DET_M3) {
+                TRY(dev_alloc(s.d_bbits, K * words));
+                TRY(dev_alloc(s.d_worklist, K * nb * c->WW, false));
+            } else {
+                TRY(dev_alloc(s.d_planes, 2 * K * words));
+            }
+            TRY(dev_alloc(s.d_bandflag, K * nb * c->WW));
+            TRY(dev_alloc(s.d_nzlist, K * words, false));
         }
-        TRY(dev_alloc(s.d_bandflag, K * nb * c->WW));
-        TRY(dev_alloc(s.d_nzlist, K * words, false));
         TRY(dev_alloc(s.d_nzcount, 2));  // [0] listed words, [1] listed morphology blocks
         TRY(dev_alloc(s.d_dst, K * words));
         // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
@@ -370,8 +382,20 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         set_err("mdh_create: bad cfg (sensitivity / interval / detector)");
         return nullptr;
     }
+    const int role = cfg->role;
+    if (role != MDH_ROLE_FULL && role != MDH_ROLE_BAND && role != MDH_ROLE_HOUGH) {
+        set_err("mdh_create: cfg.role must be MDH_ROLE_FULL, MDH_ROLE_BAND or MDH_ROLE_HOUGH");
+        return nullptr;
+    }
+    if (role != MDH_ROLE_FULL && cfg->detector != MDH_DET_M3) {
+        set_err("mdh_create: row-band tiling is built for the M3 detector only");
+        return nullptr;
+    }
     const int* r = cfg->roi;
-    if (r[0] < 0 || r[1] < 0 || r[2] > H || r[3] > W || r[2] <= r[0] || r[3] <= r[1]) {
+    // a band may hold no row of the noise ROI (empty roi: r[2] == r[0]); a Hough-only context never looks at it
+    const bool roi_empty_ok = role == MDH_ROLE_BAND && r[2] == r[0] && r[3] >= r[1];
+    if (role != MDH_ROLE_HOUGH && !roi_empty_ok &&
+        (r[0] < 0 || r[1] < 0 || r[2] > H || r[3] > W || r[2] <= r[0] || r[3] <= r[1])) {
         set_err("mdh_create: std_roi outside the frame or empty");
         return nullptr;
     }
@@ -411,6 +435,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->HW = (size_t)H * W;
     c->words = (size_t)H * c->WW;
     c->cfg = *cfg;
+    c->role = role;
     c->numrho = (W + H) * 2 + 1;
     c->force_generic = env_on("MDH_FORCE_GENERIC");
     c->force_bytes = env_on("MDH_FORCE_BYTES");
@@ -583,8 +608,9 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
     }
 }
 
-// LineDetector.update for the K staged frames: noise sums where due, then the scalar chain.
-static int run_noise(mdh_ctx* c, Slot& sl, int K) {
+// LineDetector.update for the K staged frames, first half: which frames are due, and their noise sums over cfg.roi.
+// Returns the number of due frames in *nj_out.  (Row-band tiling all-reduces the sums between the two halves.)
+static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const int64_t t_base = sl.t_base;
     const int n = c->n;
     const int64_t std_interval = (int64_t)c->cfg.interval * n;  // Detector.py:63
@@ -625,7 +651,9 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
         bool aligned4 = (c->W % 4) == 0;
         for (int e = 0; e < c->n - 1 + K && aligned4; ++e) aligned4 = ((uintptr_t)c->h_ptrtab[e] & 3) == 0;
         span_begin(c, KK_NOISE_SUMS, c->nstream);
-        if (aligned4) {
+        if (rh <= 0 || rw <= 0) {
+            // row-band tiling: this band holds no row of the noise ROI; its share of the sums is zero
+        } else if (aligned4) {
             const int xa = r[1] & ~3;
             const int nx4 = (r[1] + rw - xa + 3) >> 2;
             hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->nstream, c->d_ptrtab,
@@ -636,9 +664,17 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
         }
         span_end(c, c->nstream);
     }
+    HIPCHK(hipGetLastError());
+    *nj_out = nj;
+    return MDH_OK;
+}
+
+// Second half: the scalar chain (EMA, threshold) over the due frames from their sums (roi_px = pixels the sums cover),
+// then everything the pixel stages of the pass wait for.
+static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
     span_begin(c, KK_NOISE_FINAL, c->nstream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
-                       sl.d_fscal, c->d_thr, K, (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
+                       sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
@@ -653,8 +689,16 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
     return MDH_OK;
 }
 
-// {M3,Classic}Detector.detect for the K staged frames: pixel stages on the main stream, Hough on the Hough streams.
-static int run_detect(mdh_ctx* c, Slot& sl, int K) {
+static int run_noise(mdh_ctx* c, Slot& sl, int K) {
+    int nj = 0, rc;
+    if ((rc = noise_prepare(c, sl, K, &nj)) != MDH_OK) return rc;
+    const int* r = c->cfg.roi;
+    return noise_finish(c, sl, K, nj, (double)(r[2] - r[0]) * (r[3] - r[1]));
+}
+
+// {M3,Classic}Detector.detect for the K staged frames, pixel stages: window kernel on the main stream, morphology and
+// dynamic mask on the pass's post stream.  Leaves dst bit planes, row / frame lit counts and bounding boxes in the slot.
+static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     const int64_t t_base = sl.t_base;
     PassGeom g = geom(c, K, t_base);
     const int words = (int)c->words;
@@ -700,6 +744,14 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     }
     HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, post));
     HIPCHK(hipEventRecord(sl.ev_pix, post));
+    return MDH_OK;
+}
+
+// detect() from the binary image onwards: adaptive gap, HoughLinesP, result packing.  Runs on the Hough streams of the
+// set run_pixels (or mdh_hough_planes) queued the slot's planes and counters on; starts after sl.ev_pix.
+static int run_hough(mdh_ctx* c, Slot& sl, int K) {
+    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
+    hipStream_t* hstream = hs.stream;
     HoughParams P;
     P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
     P.threshold = c->cfg.hough_threshold;
@@ -760,6 +812,11 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     c->prev_slot = (int)(&sl - c->slot);
     c->pass_seq += 1;
     return MDH_OK;
+}
+
+static int run_detect(mdh_ctx* c, Slot& sl, int K) {
+    const int rc = run_pixels(c, sl, K);
+    return rc != MDH_OK ? rc : run_hough(c, sl, K);
 }
 
 // After a pass is queued: remember where the last n-1 frames live (copying caller-owned device frames into the ring).
@@ -950,6 +1007,7 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
 
 extern "C" int mdh_submit_batch(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
     if (!c || !frames) { set_err("mdh_submit_batch: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_FULL) { set_err("mdh_submit_batch: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
     if (c->pending) { set_err("mdh_submit_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
     return submit_pass(c, frames, K, on_device);
@@ -965,6 +1023,7 @@ extern "C" int mdh_collect_batch(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_
 
 extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if (!c || !frame) { set_err("mdh_update: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_FULL) { set_err("mdh_update: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
     if (c->pending) { set_err("mdh_update: previous frame not yet consumed by mdh_detect"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_update: collect the submitted passes first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
@@ -998,6 +1057,7 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
 extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int on_device, mdh_frame_info* info,
                                  int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
     if (!c || !frames || K < 0) { set_err("mdh_process_batch: bad argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_FULL) { set_err("mdh_process_batch: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
     if (c->pending) { set_err("mdh_process_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_process_batch: collect the submitted passes first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
@@ -1019,6 +1079,125 @@ extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int o
         collected += k;
     }
     return MDH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ row-band tiling
+static int xchg_reserve(mdh_ctx* c, size_t words) {
+    if (c->xchg_words >= words) return MDH_OK;
+    if (c->d_xchg) HIPCHK(hipFree(c->d_xchg));
+    c->d_xchg = nullptr;
+    c->xchg_words = 0;
+    HIPCHK(hipMalloc((void**)&c->d_xchg, words * sizeof(u64)));
+    c->xchg_words = words;
+    return MDH_OK;
+}
+
+extern "C" int mdh_band_noise(mdh_ctx* c, const uint8_t* frames, int K, int on_device, int64_t* sums, int* n_jobs) {
+    if (!c || !frames || !sums || !n_jobs) { set_err("mdh_band_noise: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_noise: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (c->band_slot) { set_err("mdh_band_noise: the previous pass still waits for mdh_band_pixels"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    Slot* sl = nullptr;
+    int rc, nj = 0;
+    if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
+    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return rc;
+    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return rc;
+    if ((rc = noise_prepare(c, *sl, K, &nj)) != MDH_OK) return rc;
+    if (nj) HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof(long long) * 2 * nj, hipMemcpyDeviceToHost, c->nstream));
+    HIPCHK(hipStreamSynchronize(c->nstream));
+    c->band_slot = sl;
+    c->band_nj = nj;
+    *n_jobs = nj;
+    return MDH_OK;
+}
+
+extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi_px_total, int own_row0, int own_rows,
+                               int rows_stride, int nsplit, uint64_t* dst_rows, int out_on_device, mdh_frame_info* info) {
+    if (!c || !sums_total || !dst_rows) { set_err("mdh_band_pixels: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_pixels: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (!c->band_slot) { set_err("mdh_band_pixels: call mdh_band_noise first"); return MDH_E_STATE; }
+    if (own_row0 < 0 || own_rows < 1 || own_row0 + own_rows > c->H || rows_stride < own_rows || nsplit < 1 || !(roi_px_total > 0)) {
+        set_err("mdh_band_pixels: bad owned rows / stride / split / roi_px_total");
+        return MDH_E_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    Slot& sl = *c->band_slot;
+    const int K = sl.K, nj = c->band_nj;
+    int rc;
+    if (nj) HIPCHK(hipMemcpyAsync(c->d_sums, sums_total, sizeof(long long) * 2 * nj, hipMemcpyHostToDevice, c->nstream));
+    if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return rc;
+    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
+    hipStream_t post = hs.stream[0];
+    if ((rc = run_pixels(c, sl, K)) != MDH_OK) return rc;
+    // owned rows -> exchange buffer in all-to-all send order
+    const int Kp = (K + nsplit - 1) / nsplit;
+    const size_t out_words = (size_t)nsplit * Kp * rows_stride * c->WW;
+    u64* dev_out = (u64*)dst_rows;
+    if (!out_on_device) {
+        if ((rc = xchg_reserve(c, out_words)) != MDH_OK) return rc;
+        dev_out = c->d_xchg;
+    }
+    HIPCHK(hipMemsetAsync(dev_out, 0, out_words * sizeof(u64), post));
+    hipLaunchKernelGGL(k_export_rows, dim3((own_rows * c->WW + 255) / 256, K), dim3(256), 0, post, sl.d_dst, dev_out, K, c->H, c->WW,
+                       own_row0, own_rows, rows_stride, nsplit, Kp);
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(dst_rows, dev_out, out_words * sizeof(u64), hipMemcpyDeviceToHost, post));
+    HIPCHK(hipEventRecord(sl.ev_done, post));
+    const int si = (int)(&sl - c->slot);
+    hs.last_slot = si;
+    c->prev_slot = si;
+    c->pass_seq += 1;
+    slot_commit(c, sl);
+    c->band_slot = nullptr;
+    HIPCHK(hipEventSynchronize(sl.ev_done));
+    spans_collect(c, sl);
+    if (info) {
+        for (int i = 0; i < K; ++i) {
+            mdh_frame_info& o = info[i];
+            memset(&o, 0, sizeof(o));
+            o.bi_threshold = sl.h_fscal[i].thr;
+            o.bi_threshold_float = sl.h_fscal[i].thr_f;
+            o.snr = sl.h_fscal[i].snr;
+            o.sigma = sl.h_fscal[i].sigma;
+        }
+    }
+    sl.busy = false;
+    c->last_slot = c->oldest;
+    c->oldest = (c->oldest + 1) % c->nslot;
+    c->in_flight -= 1;
+    return MDH_OK;
+}
+
+extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
+                                mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
+    if (!c || !pieces) { set_err("mdh_hough_planes: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_HOUGH) { set_err("mdh_hough_planes: not a MDH_ROLE_HOUGH context"); return MDH_E_STATE; }
+    if (nbands < 1 || band_rows < 1 || (long long)nbands * band_rows < c->H) {
+        set_err("mdh_hough_planes: the bands do not cover the frame");
+        return MDH_E_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    Slot* slp = nullptr;
+    int rc;
+    if ((rc = slot_begin(c, K, slp)) != MDH_OK) return rc;
+    Slot& sl = *slp;
+    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
+    hipStream_t post = hs.stream[0];
+    const size_t in_words = (size_t)nbands * K * band_rows * c->WW;
+    const u64* src = (const u64*)pieces;
+    if (!on_device) {
+        if ((rc = xchg_reserve(c, in_words)) != MDH_OK) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_xchg, pieces, in_words * sizeof(u64), hipMemcpyHostToDevice, post));
+        src = c->d_xchg;
+    }
+    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), post));
+    hipLaunchKernelGGL(k_assemble_planes, dim3((unsigned)((c->words + 255) / 256), K), dim3(256), 0, post, src, sl.d_dst, sl.d_rowcount,
+                       sl.d_litcount, sl.d_bbox, K, c->H, c->W, c->WW, band_rows);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl.ev_pix, post));
+    if ((rc = run_hough(c, sl, K)) != MDH_OK) return rc;
+    slot_commit(c, sl);
+    return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
 }
 
 extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {

@@ -796,6 +796,42 @@ __global__ void __launch_bounds__(1024) k_pack_lines(const int4* __restrict__ li
     if (tid == 0) off[K] = carry_s;
 }
 
+// Row-band tiling: the owned rows [row0, row0 + rows) of each frame's dst plane -> exchange buffer, frame i
+// at slot(i) = (i % nsplit) * Kp + i / nsplit, rows_stride rows per slot (the buffer is zero-filled beforehand).
+__global__ void __launch_bounds__(256) k_export_rows(const u64* __restrict__ dst_bits, u64* __restrict__ out, int K, int H, int WW,
+                                                     int row0, int rows, int rows_stride, int nsplit, int Kp) {
+    const int i = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * WW) return;
+    const int slot = (i % nsplit) * Kp + i / nsplit;
+    out[(size_t)slot * rows_stride * WW + e] = dst_bits[((size_t)i * H + row0) * WW + e];
+}
+
+// The other end: frame i of a Hough context is assembled from nbands pieces (piece b = rows [b*band_rows, ...) at
+// ((b * K + i) * band_rows) * WW), together with what the Hough stage wants to know about it: per-row and per-frame lit
+// counts and the bounding box of the lit pixels (as k_dy_sparse leaves them).
+__global__ void __launch_bounds__(256) k_assemble_planes(const u64* __restrict__ pieces, u64* __restrict__ dst_bits,
+                                                         int* __restrict__ rowcount, int* __restrict__ litcount,
+                                                         int* __restrict__ bbox, int K, int H, int W, int WW, int band_rows) {
+    const int i = blockIdx.y;
+    const int gw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= H * WW) return;
+    const int y = gw / WW, w = gw - y * WW;
+    const int b = y / band_rows;
+    u64 v = pieces[(((size_t)b * K + i) * band_rows + (y - b * band_rows)) * WW + w];
+    if (w == WW - 1 && (W & 63)) v &= (1ull << (W & 63)) - 1;  // padding bits stay 0 whatever the sender left there
+    dst_bits[(size_t)i * H * WW + gw] = v;
+    if (v) {
+        const int c = __popcll(v);
+        atomicAdd(&rowcount[i * H + y], c);
+        atomicAdd(&litcount[i], c);
+        atomicMax(&bbox[4 * i + 0], W - 1 - (w * 64 + __builtin_ctzll(v)));
+        atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(v));
+        atomicMax(&bbox[4 * i + 2], H - 1 - y);
+        atomicMax(&bbox[4 * i + 3], y);
+    }
+}
+
 // bit image -> u8 {0,255} image (mdh_get_binary)
 __global__ void k_expand_bits(const u64* __restrict__ bits, uint8_t* __restrict__ out, int H, int W, int WW) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
