@@ -25,8 +25,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the library's five streams need their own hardware queues (the HIP default is 4); must be set before HIP / torch start
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the library's streams need their own hardware queues (the HIP default is 4); must be set before HIP / torch start
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 

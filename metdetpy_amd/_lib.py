@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmetdet_hip.so")
+LIB_PATH = os.environ.get("MDH_LIB") or os.path.join(_HERE, "libmetdet_hip.so")  # MDH_LIB: A/B builds of the same library
 
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255

@@ -108,6 +108,7 @@ struct mdh_ctx {
     hipStream_t mstream[2] = {nullptr, nullptr};    // main streams: window kernel of even / odd passes
     hipStream_t stream = nullptr;                   // the main stream of the pass being queued
     hipStream_t nstream = nullptr;                  // staging + noise / threshold chain (runs one pass ahead of the main stream)
+    hipStream_t pstream[2] = {nullptr, nullptr};    // post streams: morphology + dynamic mask of even / odd passes
     HoughSet hset[NHSET];
     hipEvent_t ev_base = nullptr;  // MDH_HOST_LOG: origin of the GPU-side span times
     unsigned tag_lds = 0;  // MDH_TAG_PASS=1: dynamic LDS bytes that tag a pass's kernels in a rocprofv3 trace (1024 * (1 + pass % 3))
@@ -241,7 +242,7 @@ static void free_all(mdh_ctx* c) {
         for (hipStream_t q : h.stream)
             if (q) hipStreamDestroy(q);
     }
-    hipStream_t st[] = {c->mstream[0], c->mstream[1], c->nstream, c->cstream};
+    hipStream_t st[] = {c->mstream[0], c->mstream[1], c->nstream, c->cstream, c->pstream[0], c->pstream[1]};
     for (hipStream_t q : st)
         if (q) hipStreamDestroy(q);
     delete c;
@@ -258,7 +259,29 @@ static int create_impl(mdh_ctx* c) {
         return k > 0 ? prio_high : (k < 0 ? prio_low : (prio_low + prio_high) / 2);
     };
     const bool use_prio = getenv("MDH_PRIO_MAIN") || getenv("MDH_PRIO_NOISE") || getenv("MDH_PRIO_HOUGH");
+    // CU partition.  The window kernel's workgroups live for hundreds of frames and fill every CU, so the short,
+    // latency-bound stages of the other passes in flight (morphology, dynamic mask, Hough: a serial chain per frame)
+    // otherwise queue for a free wave slot instead of overlapping.  MDH_POST_CUS = m reserves m CUs per XCD for them
+    // (experiment switch, default 0 = no partition; measured: no gain, the pipeline was
+    // bound by stream dependencies, not by CU availability): the window streams get the complement.  Bit i of a HIP CU mask is CU i of the
+    // device, and the runtimes differ in whether consecutive bits walk along one XCD or across the 8 XCDs, so the
+    // reserved set {32x + x + 8j : x < 8, j < m} is chosen to put m CUs on every XCD under both numberings.
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    int post_cus = 0;
+    if (const char* v = getenv("MDH_POST_CUS")) post_cus = atoi(v);
+    const int ncu = prop.multiProcessorCount;
+    if (ncu != 256 || post_cus < 0 || post_cus > 3 * 4 || c->role != MDH_ROLE_FULL) post_cus = 0;  // the set above assumes 8 XCDs x 32 CUs
+    uint32_t mask_post[8] = {0}, mask_main[8];
+    for (int x = 0; x < 8; ++x)
+        for (int j = 0; j < post_cus; ++j) {
+            const int bit = 32 * x + ((x + 8 * j) & 31);
+            mask_post[bit >> 5] |= 1u << (bit & 31);
+        }
+    for (int k = 0; k < 8; ++k) mask_main[k] = ~mask_post[k];
     auto make_stream = [&](hipStream_t* st, const char* name) -> hipError_t {
+        const bool is_main = strcmp(name, "MDH_PRIO_MAIN") == 0;
+        if (post_cus > 0 && (is_main || getenv("MDH_POST_MASKED"))) return hipExtStreamCreateWithCUMask(st, 8, is_main ? mask_main : mask_post);
         return use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(name, 0))
                         : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     };
@@ -266,6 +289,8 @@ static int create_impl(mdh_ctx* c) {
     HIPCHK(make_stream(&c->mstream[1], "MDH_PRIO_MAIN"));
     c->stream = c->mstream[0];
     HIPCHK(make_stream(&c->nstream, "MDH_PRIO_NOISE"));
+    HIPCHK(make_stream(&c->pstream[0], "MDH_PRIO_HOUGH"));
+    HIPCHK(make_stream(&c->pstream[1], "MDH_PRIO_HOUGH"));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     for (int hi = 0; hi < c->nhset; ++hi) {
         HoughSet& h = c->hset[hi];
@@ -408,10 +433,10 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         set_err("mdh_create: mask_area must be > 0");
         return nullptr;
     }
-    // The context uses five streams that must progress independently; the HIP runtime multiplexes streams onto
+    // The context uses up to ten streams that must progress independently; the HIP runtime multiplexes streams onto
     // GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue serialise behind each other's event
     // waits.  Only effective if the runtime is not initialised yet (otherwise set it in the environment).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_err("mdh_create: no HIP device visible -- libmetdet_hip needs an AMD GPU (there is no CPU fallback)");
@@ -561,7 +586,8 @@ template <int N, int PPL>
 static void launch_wide(mdh_ctx* c, const PassGeom& g) {
     const int words = (int)c->words;
     const int waves = (words + PPL - 1) / PPL;
-    int nchunks = (4096 + waves - 1) / waves;
+    static const int target_waves = getenv("MDH_WIN_WAVES") ? atoi(getenv("MDH_WIN_WAVES")) : 4096;  // experiment switch
+    int nchunks = (target_waves + waves - 1) / waves;
     nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
@@ -706,13 +732,14 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // Main stream: nothing but the window kernel (the one stage that fills the machine), pass after pass.  Everything
     // downstream of it -- morphology, dynamic mask, Hough, result packing -- is short or latency-bound and runs on the
     // pass's post streams, overlapping the window kernel of the following pass(es).
-    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t* hstream = hs.stream;
-    hipStream_t post = hstream[0];
+    // (the post streams are NOT the Hough streams: morphology of pass p must not queue behind the Hough stage of pass p-2)
+    hipStream_t post = c->pstream[c->pass_seq & 1];
     HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_noise, 0));  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
-        launch_stack_threshold(c, g);
+        static const bool skip_window = getenv("MDH_SKIP_WINDOW") != nullptr;  // timing experiments only: results are wrong
+        if (skip_window) HIPCHK(hipMemsetAsync(c->d_bbits, 0, sizeof(u64) * (size_t)K * c->words, c->stream));
+        else launch_stack_threshold(c, g);
         span_end(c, c->stream);
     } else {
         span_begin(c, KK_CLASSIC, c->stream);
@@ -771,10 +798,15 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     // big-LDS launch (1 frame per CU) takes the rest; both evaluate the same fit test from the lit count and bounding
     // box, so they run side by side.  They start once this pass's pixel stages are done and the pass that used this
     // Hough set before (two passes ago) has released its accumulators / point lists.
+    HIPCHK(hipStreamWaitEvent(hstream[0], sl.ev_pix, 0));
     HIPCHK(hipStreamWaitEvent(hstream[1], sl.ev_pix, 0));
     // (the set's previous user queued its work on these same streams, so its buffers are free by stream order)
     span_begin(c, KK_HOUGH, hstream[0]);
-    if (c->hough_one_wave) {
+    static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr;  // timing experiments only: results are wrong
+    if (skip_hough) {
+        HIPCHK(hipMemsetAsync(sl.d_nraw, 0, sizeof(int) * K, hstream[0]));
+        HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
+    } else if (c->hough_one_wave) {
         P.small_list = 4096; P.small_cells = 32000;
         P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
         hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), hstream[1], P);
@@ -1127,7 +1159,7 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     if (nj) HIPCHK(hipMemcpyAsync(c->d_sums, sums_total, sizeof(long long) * 2 * nj, hipMemcpyHostToDevice, c->nstream));
     if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return rc;
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t post = hs.stream[0];
+    hipStream_t post = c->pstream[c->pass_seq & 1];
     if ((rc = run_pixels(c, sl, K)) != MDH_OK) return rc;
     // owned rows -> exchange buffer in all-to-all send order
     const int Kp = (K + nsplit - 1) / nsplit;
@@ -1181,8 +1213,7 @@ extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int o
     int rc;
     if ((rc = slot_begin(c, K, slp)) != MDH_OK) return rc;
     Slot& sl = *slp;
-    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t post = hs.stream[0];
+    hipStream_t post = c->pstream[c->pass_seq & 1];
     const size_t in_words = (size_t)nbands * K * band_rows * c->WW;
     const u64* src = (const u64*)pieces;
     if (!on_device) {

@@ -353,8 +353,11 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 // pixels fetched with one 128-bit (64-bit) buffer load per frame, i.e. 16x (8x) fewer load instructions than the
 // byte kernel, which is issue-bound on its byte loads.  Pixel r and pixel r + PPL/2 share a packed u16 register
 // (one v_perm_b32 each), so the per-lane result bits come out as two contiguous runs.
+#ifndef WIDE_OCC
+#define WIDE_OCC
+#endif
 template <int N, int PPL>
-__global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
+__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, u64* __restrict__ bbits,
                                                               unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
     constexpr int RW = PPL / 2;   // packed pair registers per window entry
@@ -397,14 +400,18 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
     constexpr int GS = 4;                  // window slots per max group
     constexpr int NG = (N + GS - 1) / GS;  // groups
     PK win[N][RW];
-    u16x2 sum[RW], gmax[NG][RW];
+    u16x2 gmax[NG][RW];
+    // Window sums: two 16-bit fields per register, updated with plain 32-bit adds / subtracts (a field never carries or
+    // borrows: 255 * (N + 1) < 2^16, and the value leaving the window is part of the sum).  v_add_u32 / v_sub_u32 issue at
+    // twice the rate of the packed 16-bit forms on gfx950 (tools/valu_rate.hip).
+    unsigned sum[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) sum[r] = (u16x2){0, 0};
+    for (int r = 0; r < RW; ++r) sum[r] = 0;
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
         unpack(fetch(i0 + k), win[k]);
 #pragma unroll
-        for (int r = 0; r < RW; ++r) sum[r] += win[k][r].v;
+        for (int r = 0; r < RW; ++r) sum[r] += win[k][r].u;
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) win[N - 1][r].u = 0;
@@ -430,7 +437,8 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
         // thresholds of the whole window period up front (scalar loads, off the per-frame critical path)
         int Tp[N];
 #pragma unroll
-        for (int u = 0; u < N; ++u) Tp[u] = thr_tab[min(i0 + sb + u, g.K - 1)];
+        for (int u = 0; u < N; ++u)  // T >= 256 can never fire (diff <= 255); the clamp keeps T * len inside 16 bits
+            Tp[u] = min(__builtin_amdgcn_readfirstlane(thr_tab[min(i0 + sb + u, g.K - 1)]), 256);
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
             const int ub = bi * U;
@@ -450,14 +458,19 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                         PK a[RW];
                         unpack(cur[u], a);
                         const int i = i0 + s;
-                        const unsigned short T = (unsigned short)Tp[ub + u];
-                        const unsigned short nlen = (unsigned short)(0 - min(g.n, len0 + s));  // -window_len(g, i)
-                        const u16x2 Tv = {T, T}, NLv = {nlen, nlen};
+                        // b = (max - floor(sum / len) > T)  <=>  sum + T * len - max * len < 0.  The left side is within
+                        // [-255 len, 510 len], i.e. inside int16 for len <= 16 (this kernel's N), so b is the sign bit of
+                        // one packed multiply-add whose addend is sum + T * len (T >= 256 can never fire; clamping it
+                        // keeps T * len in 16 bits).
+                        const int len = min(g.n, len0 + s);  // window_len(g, i)
+                        const unsigned short nlen = (unsigned short)(0 - len);
+                        const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[ub + u] * len) * 0x10001u;  // scalar unit
+                        const u16x2 NLv = {nlen, nlen};
                         unsigned acc = 0;
                         const int grp = slot / GS;  // the group of 4 window slots the new frame falls into (static after unrolling)
 #pragma unroll
                         for (int r = 0; r < RW; ++r) {
-                            sum[r] += a[r].v - win[slot][r].v;
+                            sum[r] = sum[r] + a[r].u - win[slot][r].u;
                             win[slot][r] = a[r];
                             // two-level max: only the group that changed is re-reduced, then the NG group maxima
                             u16x2 m = win[grp * GS][r].v;
@@ -470,8 +483,9 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                             for (int k = 1; k < NG; ++k) m = __builtin_elementwise_max(m, gmax[k][r]);
                             // sum < (max - T) * len  <=>  bit 15 of sum + (max - T) * (-len) mod 2^16 (all terms < 2^15 for
                             // n <= 128); written as a multiply-add so that it maps to one v_pk_mad_u16
-                            PK d;
-                            d.v = __builtin_elementwise_sub_sat(m, Tv) * NLv + sum[r];
+                            PK d, st;
+                            st.u = sum[r] + tl;
+                            d.v = m * NLv + st.v;
                             acc = (acc >> 1) | (d.u & 0x80008000u);
                         }
                         // reg r landed on bit 8+r-(8-RW) ... after RW shifts: low half bits (16-RW)..15 = pixels 0..RW-1,
@@ -491,7 +505,9 @@ __global__ void __launch_bounds__(256) k_stack_threshold_wide(const uint8_t* con
                             for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
                         }
                         if (q == 0 && gw < words) {
-                            bbits[(size_t)i * words + gw] = v;
+                            // frame base as a scalar (SGPR pair) + the lane's word offset: no per-frame vector multiplies
+                            u64* frame_bits = bbits + (size_t)__builtin_amdgcn_readfirstlane(i) * (size_t)words;
+                            frame_bits[gw] = v;
                             if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
                         }
                     }
