@@ -183,6 +183,25 @@ int mdh_band_pixels(mdh_ctx* ctx, const int64_t* sums_total, double roi_px_total
 int mdh_hough_planes(mdh_ctx* ctx, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
                      mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);
 
+/* ---- One stream cut into time windows across GPUs (SURVEY 8e "time windows of one stream") --------------------------
+ *
+ * Rank r processes frames [s_r, e_r) of the stream, starting 2(n-1) frames early (n-1 to fill the max/mean window of the
+ * first binaries the dynamic mask needs, n-1 more for those binaries themselves); the results of the warm-up frames are
+ * dropped.  What couples the chunks is the threshold: T(t) follows an EMA of the noise sigma with a long memory
+ * (Detector.py:61-62, utils.py:334-368).  The sigma of a due frame depends only on the n frames before it, so every
+ * rank computes the noise sums of the due frames of its own chunk (mdh_band_noise + mdh_band_skip over the chunk),
+ * the sums are all-gathered (16 bytes per due frame), every rank replays the scalar chain on the host up to its start,
+ * positions its context there (mdh_seek) and then runs the chunk through mdh_band_noise / mdh_band_pixels (one band =
+ * the whole frame, sums from the gathered table) and mdh_hough_planes.  metdetpy_amd/timeshard.py drives it. */
+
+/* Drop the pass staged by mdh_band_noise without running its pixel stages (the frames stay in the window). */
+int mdh_band_skip(mdh_ctx* ctx);
+
+/* Reposition a context in its stream: the next frame is number t0 + 1 (SlidingWindow.timer == t0), the window and the
+ * ring of binaries are empty, the noise EMA has been updated ema_updates times and stands at snr (EMA.cur_value), with
+ * sigma / thr_float / thr the values in force after frame t0.  No pass may be in flight. */
+int mdh_seek(mdh_ctx* ctx, int64_t t0, int64_t ema_updates, double snr, double sigma, double thr_float, int thr);
+
 /* Debug: with MDH_HOUGH_DEBUG=1 in the environment at mdh_create, the Hough kernel records 8 cycle counters per frame
  * of the last pass (lit pixels, list build, PPHT total, draws, mask checks, votes, trigger scan, line handling). */
 int mdh_debug_hough(mdh_ctx* ctx, long long* out, int K);

@@ -44,7 +44,7 @@ EXPORTS = [
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
-    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes"
+    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek"
 ]
 
 _lib = None
@@ -97,6 +97,8 @@ def load():
     L.mdh_band_noise.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]
     L.mdh_band_pixels.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32, vp]
     L.mdh_hough_planes.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.mdh_band_skip.argtypes = [vp]
+    L.mdh_seek.argtypes = [vp, i64, i64, dbl, dbl, dbl, i32]
     _lib = L
     return L
 
@@ -267,6 +269,15 @@ class Context:
                                      int(rows_stride), int(nsplit), host.ctypes.data if host is not None else int(out),
                                      int(host is None), info.ctypes.data), "mdh_band_pixels")
         return host, info
+
+    def band_skip(self):
+        """Drop the pass staged by band_noise (its frames stay in the window)."""
+        check(self.L.mdh_band_skip(self.handle), "mdh_band_skip")
+
+    def seek(self, t0, ema_updates=0, snr=0.0, sigma=0.0, thr_float=0.0, thr=0):
+        """Reposition the context: the next frame is number t0 + 1; noise EMA / threshold state as given."""
+        check(self.L.mdh_seek(self.handle, int(t0), int(ema_updates), float(snr), float(sigma), float(thr_float), int(thr)),
+              "mdh_seek")
 
     def hough_planes(self, pieces, K, nbands, band_rows, on_device=False):
         """Step 3 (MDH_ROLE_HOUGH context): pieces = (nbands, K, band_rows, WW) u64 host array or a device pointer."""

@@ -101,6 +101,12 @@ class HipBandEngine:
     def hough_stage(self, pieces, kp, on_device=False):
         return self.hough.hough_planes(pieces, kp, self.plan.nbands, self.plan.band_rows, on_device=on_device)
 
+    def skip(self):
+        self.band.band_skip()
+
+    def seek(self, t0, **state):
+        self.band.seek(t0, **state)
+
     def close(self):
         self.band.close()
         self.hough.close()

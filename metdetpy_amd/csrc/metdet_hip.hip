@@ -1200,6 +1200,59 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     return MDH_OK;
 }
 
+extern "C" int mdh_band_skip(mdh_ctx* c) {
+    if (!c) { set_err("mdh_band_skip: null context"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_skip: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (!c->band_slot) { set_err("mdh_band_skip: call mdh_band_noise first"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    Slot& sl = *c->band_slot;
+    // the frames are in the window (mdh_band_noise staged and retired them); nothing else happens for this pass
+    HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
+    HIPCHK(hipEventRecord(sl.ev_prep, c->nstream));
+    HIPCHK(hipEventRecord(sl.ev_done, c->nstream));
+    slot_commit(c, sl);
+    c->band_slot = nullptr;
+    HIPCHK(hipEventSynchronize(sl.ev_done));
+    spans_collect(c, sl);
+    sl.busy = false;
+    sl.used = false;  // no dst words to clear, no binaries written
+    c->oldest = (c->oldest + 1) % c->nslot;
+    c->in_flight -= 1;
+    return MDH_OK;
+}
+
+extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr, double sigma, double thr_float, int thr) {
+    if (!c) { set_err("mdh_seek: null context"); return MDH_E_ARG; }
+    if (c->role == MDH_ROLE_HOUGH) { set_err("mdh_seek: a MDH_ROLE_HOUGH context has no stream position"); return MDH_E_STATE; }
+    if (c->in_flight || c->pending || c->band_slot) { set_err("mdh_seek: collect / finish the passes in flight first"); return MDH_E_STATE; }
+    if (t0 < 0 || ema_updates < 0) { set_err("mdh_seek: negative position"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    c->t = t0;
+    c->hist.assign(c->n - 1, c->d_zero);  // the window restarts empty: the next 2(n-1) frames are warm-up
+    c->ema_t = ema_updates;
+    c->ema_warm = c->n;  // the schedule (utils.py:360-368) is a function of the update count alone; it re-derives "ramp over"
+    ScalarState st{};
+    st.ema_v = snr;
+    st.sigma = sigma;
+    st.thr_f = thr_float;
+    st.thr = thr;
+    HIPCHK(hipMemcpy(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
+    // binaries of the previous position must not be taken for frames of the new one (the ring is tagged by frame number)
+    if (c->d_act) HIPCHK(hipMemset(c->d_act, 0, sizeof(ActWord) * (size_t)c->R * c->words));
+    for (int si = 0; si < c->nslot; ++si) {
+        Slot& sl = c->slot[si];
+        if (sl.used && sl.d_dst && sl.d_nzlist) {
+            hipLaunchKernelGGL(k_sparse_clear, dim3(64), dim3(256), 0, c->nstream, sl.d_dst, sl.d_nzlist, sl.d_nzcount);
+            sl.used = false;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->nstream));
+    c->prev_slot = -1;
+    c->last_slot = -1;
+    return MDH_OK;
+}
+
 extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
                                 mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
     if (!c || !pieces) { set_err("mdh_hough_planes: null argument"); return MDH_E_ARG; }

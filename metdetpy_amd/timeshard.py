@@ -1,0 +1,192 @@
+"""One stream cut into contiguous time windows across GPUs (SURVEY 8e "time windows of one stream"; the sharding
+BASELINE.json's north_star names: embarrassingly parallel, a collective only for the threshold table and the final gather).
+
+Rank r owns frames [s_r, e_r).  Two things tie a frame to its past:
+
+  * the n-frame max / mean window and the n-deep ring of binaries of the dynamic mask (Detector.py:225-242, 327-340):
+    rank r starts 2(n-1) frames early and drops the results of those warm-up frames -- after them every piece of pixel
+    state is exactly what a single detector would hold;
+  * the binary threshold: T(t) = round(a * snr(t)^2 + b) with snr an EMA of the noise sigma (Detector.py:61-63, 81-91,
+    177-229; utils.py:334-368) whose memory spans the whole stream.  But the sigma of a due frame is a function of the n
+    frames before it only, so the ranks compute the noise sums (S1, S2) of the due frames of their own chunks in a
+    cheap first sweep (the sub-ROI of every 2n-th frame's window), all-gather them -- 16 bytes per due frame -- and
+    replay the scalar chain on the host (NoiseChain, the same arithmetic as the library's k_noise_finalize); each rank
+    then positions its context at its start (mdh_seek) with the exact EMA / threshold state.
+
+The second sweep is the band path with a single band: mdh_band_noise -> mdh_band_pixels (sums from the gathered table)
+-> mdh_hough_planes.  Results are identical to one detector running the whole stream (tests/test_timeshard.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib
+from .bands import HipBandEngine, _BandSetup, _merge_info, _package
+
+ABS_SENSITIVITY = {"high": 3, "normal": 5, "low": 7}          # Detector.py:183
+SENSITIVITY_COEF = {"low": (2.0, 4.4), "normal": (1.2, 3.6), "high": (0.9, 3.0)}  # Detector.py:177-182
+
+
+def due_frames(t: int, n: int, interval: int) -> int:
+    """How many frames the sigma evaluated after frame t (1-based) covers; 0 = not due (Detector.py:81-91)."""
+    if t > n and t % (interval * n) == 0:
+        return n
+    if 1 < t <= n:
+        return t
+    return 0
+
+
+class NoiseChain:
+    """EMA of sigma with the warm-up schedule of utils.py:334-368 and the threshold rule of Detector.py:225-229, in the
+    operation order of the library's k_noise_finalize / noise_prepare (IEEE doubles, no fused multiply-add on either side)."""
+
+    def __init__(self, n, interval, roi_px, sensitivity, adaptive, init_value):
+        self.m0 = 1 - interval / 60
+        self.n = n
+        self.roi_px = float(roi_px)
+        self.adaptive = bool(adaptive)
+        self.a, self.b = SENSITIVITY_COEF[sensitivity]
+        self.updates = 0
+        self.snr = 0.0
+        self.sigma = 0.0
+        self.thr = ABS_SENSITIVITY[sensitivity] if adaptive else int(init_value)
+        self.thr_f = float(self.thr)
+
+    def update(self, k_used: int, s1: int, s2: int):
+        m = self.m0
+        ramp = self.updates * (1 - self.m0) * self.n
+        if ramp < 1:
+            u = 1 - ramp
+            m = self.m0 * (1 - u * u)
+        self.updates += 1
+        cnt = float(k_used) * self.roi_px
+        mu = float(s1) / cnt
+        var = float(s2) / cnt - mu * mu
+        if var < 0:
+            var = 0.0
+        self.sigma = math.sqrt(var)
+        self.snr = m * self.snr + (1 - m) * self.sigma
+        if self.adaptive and self.snr != 0:
+            self.thr_f = self.a * (self.snr * self.snr) + self.b
+            self.thr = int(round(self.thr_f))  # half to even
+
+    def state(self):
+        return dict(ema_updates=self.updates, snr=self.snr, sigma=self.sigma, thr_float=self.thr_f, thr=self.thr)
+
+
+def chunk_bounds(total: int, world: int):
+    per = -(-total // world)
+    return [(min(total, r * per), min(total, (r + 1) * per)) for r in range(world)]
+
+
+class TimeShard:
+    """Rank `rank` of `world`: scan() -> the noise sums of the due frames it owns; after the all-gather, finish(table)
+    -> its frames' results.  `read(lo, hi)` returns frames [lo, hi) of the stream as a (hi-lo, H, W) uint8 array."""
+
+    def __init__(self, window_sec, fps, mask, num_cls, cfg, total_frames, read, *, rank=0, world=1, device=0, max_batch=64,
+                 engine=HipBandEngine):
+        self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, 1)
+        self.cfg, self.read, self.total = cfg, read, int(total_frames)
+        self.rank, self.world, self.B = int(rank), int(world), int(max_batch)
+        n = self.s.n
+        self.start, self.end = chunk_bounds(self.total, self.world)[self.rank]
+        self.warm = max(0, self.start - 2 * (n - 1))
+        if self.world > 1 and self.end - self.start < 2 * (n - 1) and self.end > self.start:
+            raise ValueError("chunks shorter than 2(n-1) frames: use fewer ranks for this stream")
+        self.engine = engine(self.s.plan, 0, n, cfg, self.s.mask_area, self.B, device)
+
+    def _chain(self):
+        b = self.cfg.binary
+        return NoiseChain(self.s.n, b.interval, self.s.plan.roi_px, b.sensitivity, b.adaptive_bi_thre, b.init_value)
+
+    def scan(self):
+        """First sweep: {t: (k_used, S1, S2)} for the due frames t (1-based) this rank owns."""
+        n, itv = self.s.n, self.cfg.binary.interval
+        out = {}
+        if self.end <= self.start:
+            return out
+        st0 = self._chain().state()
+        self.engine.seek(self.warm, **st0)  # the scalar state plays no part in the sums
+        for lo in range(self.warm, self.end, self.B):
+            hi = min(self.end, lo + self.B)
+            sums = self.engine.noise(self.read(lo, hi))
+            self.engine.skip()
+            j = 0
+            for t in range(lo + 1, hi + 1):
+                k = due_frames(t, n, itv)
+                if k:
+                    if t > self.start:  # owned; its k frames are all behind the warm-up start
+                        assert t - k >= self.warm
+                        out[t] = (k, int(sums[2 * j]), int(sums[2 * j + 1]))
+                    j += 1
+            assert 2 * j == len(sums)
+        return out
+
+    def finish(self, table: dict):
+        """Second sweep.  table: the merged {t: (k_used, S1, S2)} of every rank.  Returns [(frame, info, lines, cls_pred)]
+        for the frames this rank owns."""
+        n, itv = self.s.n, self.cfg.binary.interval
+        res = []
+        if self.end <= self.start:
+            return res
+        chain = self._chain()
+        for t in sorted(table):
+            if t > self.warm:
+                break
+            chain.update(*table[t])
+        self.engine.seek(self.warm, **chain.state())
+        for lo in range(self.warm, self.end, self.B):
+            hi = min(self.end, lo + self.B)
+            K = hi - lo
+            self.engine.noise(self.read(lo, hi))  # stages the pass; its own sums are superseded by the table
+            due = [t for t in range(lo + 1, hi + 1) if due_frames(t, n, itv)]
+            tot = np.array([v for t in due for v in table[t][1:]], np.int64)
+            planes, thr_info = self.engine.pixels(tot)
+            hinfo, raw, nms, prob = self.engine.hough_stage(planes, K)
+            for j in range(K):
+                i = lo + j
+                if i >= self.start:
+                    info = _merge_info(thr_info[j], hinfo[j])
+                    lines, pred = _package(self.s.num_cls, hinfo[j], raw[j], nms[j], prob[j])
+                    res.append((i, info, lines, pred))
+        return res
+
+    def close(self):
+        self.engine.close()
+
+
+def run_time_sharded(window_sec, fps, mask, num_cls, cfg, total_frames, read, *, dist=None, rank=0, world=1, device=0,
+                     max_batch=64, engine=HipBandEngine):
+    """All of it for one rank: scan, all-gather of the sums table, finish, gather of the results to rank 0.
+    Returns (results, info) on rank 0 -- results[i] = (lines, cls_pred) as M3Detector.detect gives them -- else None."""
+    if world > 1 and dist is None:
+        raise ValueError("world > 1 needs an initialised torch.distributed module")
+    shard = TimeShard(window_sec, fps, mask, num_cls, cfg, total_frames, read, rank=rank, world=world, device=device,
+                      max_batch=max_batch, engine=engine)
+    mine = shard.scan()
+    if dist is None:
+        tables = [mine]
+    else:
+        tables = [None] * world
+        dist.all_gather_object(tables, mine)  # the threshold table: 16 bytes of sums per due frame
+    table = {}
+    for part in tables:
+        table.update(part)
+    part = shard.finish(table)
+    shard.close()
+    if dist is None:
+        gathered = [part]
+    else:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(part, gathered, dst=0)  # the final detection gather
+    if rank != 0:
+        return None
+    info = np.zeros(total_frames, _lib.FRAME_INFO_DTYPE)
+    results = [None] * total_frames
+    for chunk in gathered:
+        for i, fi, lines, pred in chunk:
+            info[i] = fi
+            results[i] = (lines, pred)
+    return results, info

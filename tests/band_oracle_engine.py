@@ -122,5 +122,20 @@ class OracleBandEngine:
                 nms[j, :len(kept)], prob[j, :len(kept)] = kept, nonline
         return info, raw, nms, prob
 
+    def skip(self):
+        """Drop the staged pass: the frames stay in the noise window, nothing else happens."""
+        self.t += len(self._staged)
+        self._staged = None
+
+    def seek(self, t0, ema_updates=0, snr=0.0, sigma=0.0, thr_float=0.0, thr=0):
+        r = self.roi
+        self.ring = mo.RingWindow(self.n, self.shape)
+        self.dy_ring = mo.RingWindow(self.n, self.shape)
+        self.roi_ring = mo.RingWindow(self.n, (r[2] - r[0], r[3] - r[1]))
+        self.t = int(t0)
+        self.ema = mo.WarmupEMA(1 - self.cfg.binary.interval / 60, self.n)
+        self.ema.t, self.ema.value = int(ema_updates), snr
+        self.thr, self.thr_f, self.sigma = int(thr), thr_float, sigma
+
     def close(self):
         pass

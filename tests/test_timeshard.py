@@ -1,0 +1,185 @@
+"""One stream cut into time windows across ranks (metdetpy_amd/timeshard.py; SURVEY 8e "time windows of one stream").
+
+CPU: the host replay of the noise EMA / threshold chain against the oracle's series, the two-sweep scheme with an engine
+made of the oracle's functions (ranks simulated in-process, and two real processes over gloo) -- identical to one oracle
+detector running the whole stream.  GPU (-m gpu): the same with the HIP contexts, against the whole-stream HIP detector."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from metdetpy_amd.timeshard import NoiseChain, TimeShard, chunk_bounds, due_frames, run_time_sharded
+from metdetpy_amd.utils import select_std_roi
+from oracle import m3_oracle as mo
+from tests.band_oracle_engine import OracleBandEngine
+from tests.helpers import binary_cfg, frames_normal
+from tests.test_bands import check_against, make_case, whole_frame_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_chunk_bounds_and_due_frames():
+    assert chunk_bounds(100, 3) == [(0, 34), (34, 68), (68, 100)]
+    assert chunk_bounds(5, 8)[-1] == (5, 5)
+    n, itv = 4, 2
+    assert [due_frames(t, n, itv) for t in range(1, 18)] == [0, 2, 3, 4, 0, 0, 0, 4, 0, 0, 0, 0, 0, 0, 0, 4, 0]
+
+
+@pytest.mark.parametrize("sens,sigma", [("normal", 2.5), ("high", 1.0), ("low", 6.0)])
+def test_noise_chain_replays_the_oracle_series(sens, sigma):
+    H, W, n = 60, 100, 5
+    mask = np.ones((H, W), np.uint8)
+    cfg = binary_cfg(sens)
+    frames = frames_normal(11, 90, (H, W), 30, sigma)
+    orc = mo.M3Oracle(n, mask, sensitivity=sens)
+    r = select_std_roi(mask, 0.1)
+    chain = NoiseChain(n, 2, (r[2] - r[0]) * (r[3] - r[1]), sens, True, 7)
+    changes = 0
+    for t, f in enumerate(frames, 1):
+        orc.update(f)
+        k = due_frames(t, n, cfg.binary.interval)
+        if k:
+            s1, s2, _ = mo.noise_sums(orc.stack.sub.ring, orc.stack.sub.mean, k)
+            before = chain.thr
+            chain.update(k, s1, s2)
+            changes += chain.thr != before
+        assert chain.thr == orc.bi_threshold, t
+        assert chain.snr == pytest.approx(orc.stack.snr, rel=1e-12, abs=0)
+    assert changes > 0
+
+
+def simulate(world, frames, n, mask, cfg, B, engine):
+    total = len(frames)
+    read = lambda lo, hi: frames[lo:hi]
+    shards = [TimeShard(n / 10, 10, mask, 10, cfg, total, read, rank=r, world=world, max_batch=B, engine=engine)
+              for r in range(world)]
+    table = {}
+    for s in shards:
+        part = s.scan()
+        assert not (set(part) & set(table))
+        table.update(part)
+    assert sorted(table) == [t for t in range(1, total + 1) if due_frames(t, n, cfg.binary.interval)]
+    out = []
+    for s in shards:
+        out += s.finish(table)
+        s.close()
+    assert [o[0] for o in out] == list(range(total))
+    return out
+
+
+@pytest.mark.parametrize("kind,world,H,W,n,total,B", [("sky", 2, 96, 160, 4, 60, 16), ("sky", 3, 90, 128, 6, 96, 11),
+                                                       ("busy", 2, 64, 96, 5, 40, 7), ("sky", 1, 64, 128, 4, 30, 8)])
+def test_simulated_ranks_equal_whole_stream_oracle(kind, world, H, W, n, total, B):
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case(kind, H, W, n, total, 5 + world)
+    want = whole_frame_oracle(frames, n, mask, cfg)
+    assert sum(w["n_raw"] for w in want) > 0 and len({w["thr"] for w in want}) > (1 if kind == "sky" else 0)
+    out = simulate(world, frames, n, mask, cfg, B, OracleBandEngine)
+    check_against([(o[2], o[3]) for o in out], [o[1] for o in out], want)
+
+
+TS_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from metdetpy_amd import dist as md
+from metdetpy_amd.timeshard import run_time_sharded
+from tests.band_oracle_engine import OracleBandEngine
+from tests.test_bands import make_case
+use_hip = sys.argv[2] == "hip"
+rank, local, world, dist = md.init_from_env("gloo")
+H, W, n, total, B = (96, 160, 5, 70, 12) if not use_hip else (270, 448, 8, 150, 32)
+mask = np.ones((H, W), np.uint8)
+frames, cfg = make_case("sky", H, W, n, total, 31)
+kw = {} if use_hip else dict(engine=OracleBandEngine)
+res = run_time_sharded(n / 10, 10, mask, 10, cfg, total, lambda lo, hi: frames[lo:hi], dist=dist, rank=rank, world=world,
+                       max_batch=B, **kw)
+if rank == 0:
+    results, info = res
+    print(json.dumps([dict(lines=np.asarray(l).reshape(-1, 4).tolist(), pred=np.asarray(p).tolist(), thr=int(fi["bi_threshold"]),
+                           lit=int(fi["lit_count"]), n_raw=int(fi["n_raw"])) for (l, p), fi in zip(results, info)]))
+else:
+    assert res is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def run_two_ranks(tmp_path, mode):
+    script = tmp_path / "ts_worker.py"
+    script.write_text(TS_WORKER)
+    port = 33000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-3000:]
+    return json.loads(outs[0][0].decode().strip().splitlines()[-1])
+
+
+def compare(got, H, W, n, total):
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case("sky", H, W, n, total, 31)
+    want = whole_frame_oracle(frames, n, mask, cfg)
+    assert len(got) == total and sum(w["n_raw"] for w in want) > 0
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert (g["thr"], g["lit"], g["n_raw"]) == (w["thr"], w["lit"], w["n_raw"]), i
+        assert np.array_equal(np.array(g["lines"], np.int32).reshape(-1, 4), w["lines"]), i
+        assert np.array_equal(np.array(g["pred"]).reshape(-1, 10), w["pred"]), i
+
+
+def test_two_process_gloo_time_shards_equal_whole_stream_oracle(tmp_path):
+    compare(run_two_ranks(tmp_path, "oracle"), 96, 160, 5, 70)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world,H,W,n,total,B", [("sky", 2, 270, 480, 8, 120, 32), ("sky", 3, 135, 250, 5, 100, 16),
+                                                       ("busy", 2, 128, 192, 4, 48, 8), ("sky", 4, 272, 448, 8, 200, 64)])
+def test_hip_time_shards_equal_whole_stream(kind, world, H, W, n, total, B):
+    from metdetpy_amd import M3Detector
+    from metdetpy_amd.bands import HipBandEngine
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case(kind, H, W, n, total, 5 + world)
+    want = whole_frame_oracle(frames, n, mask, cfg)
+    assert sum(w["n_raw"] for w in want) > 0
+    out = simulate(world, frames, n, mask, cfg, B, HipBandEngine)
+    check_against([(o[2], o[3]) for o in out], [o[1] for o in out], want)
+    whole = M3Detector(n / 10, 10, mask, 10, cfg, None, max_batch=B)
+    _, winfo = whole.detect_batch(frames)
+    whole.close()
+    for i, o in enumerate(out):
+        for f in ("n_raw", "n_nms", "lit_count", "bi_threshold", "bi_threshold_float", "snr", "sigma", "dst_sum", "hough_gap"):
+            assert o[1][f] == winfo[i][f], (i, f, o[1][f], winfo[i][f])  # the host chain replays the device chain bit for bit
+
+
+@pytest.mark.gpu
+def test_two_process_gloo_hip_time_shards(tmp_path):
+    compare(run_two_ranks(tmp_path, "hip"), 270, 448, 8, 150)
+
+
+@pytest.mark.gpu
+def test_seek_errors_and_restart():
+    """mdh_seek on a full context: rewinding to 0 reproduces the first run; seeking with a pass staged is refused."""
+    from metdetpy_amd import M3Detector, _lib
+    H, W, n = 96, 128, 4
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case("sky", H, W, n, 24, 3)
+    det = M3Detector(n / 10, 10, mask, 10, cfg, None, max_batch=8)
+    first, info1 = det.detect_batch(frames)
+    det._ctx.seek(0, thr=5, thr_float=5.0)
+    again, info2 = det.detect_batch(frames)
+    for a, b in zip(first, again):
+        assert np.array_equal(np.asarray(a[0]).reshape(-1, 4), np.asarray(b[0]).reshape(-1, 4))
+    assert np.array_equal(info1, info2)
+    det._ctx.update(frames[0])
+    with pytest.raises(_lib.MetDetHipError, match="in flight"):
+        det._ctx.seek(0)
+    det.close()
