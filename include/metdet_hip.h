@@ -102,7 +102,7 @@ int mdh_process_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device,
 
 /* Asynchronous form of mdh_process_batch for K <= cfg.max_batch: mdh_submit_batch queues the pass and returns at
  * once; mdh_collect_batch waits for the OLDEST queued pass and returns its frame count (> 0) or a negative error.
- * At most mdh_max_in_flight(ctx) passes (4 by default) may be in flight; the window kernel of a later pass overlaps the
+ * At most mdh_max_in_flight(ctx) passes (6 by default) may be in flight; the window kernel of a later pass overlaps the
  * morphology / Hough stages of the earlier ones.
  * `frames` must stay valid (and, for device memory, unmodified) until its pass has been collected. */
 int mdh_submit_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device);

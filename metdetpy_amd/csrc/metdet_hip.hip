@@ -49,14 +49,18 @@ struct ProfSpan {
     hipEvent_t a, b;
 };
 
-#define NSLOT_MAX 6  // slots allocated at most; ctx->nslot (default 4, MDH_SLOTS) passes may be in flight
+#define NSLOT_MAX 8  // slots allocated at most; ctx->nslot (default 6, MDH_SLOTS) passes may be in flight
 #define NHSET 2  // Hough buffer / stream sets available; MDH_HOUGH_SETS (default 1) of them are used
 #define PACK_HEAD 8  // packed segments per frame (pass average) copied to the host without waiting for the counts
 
 // Everything that crosses the pixel-stage -> Hough boundary or is mirrored to the host, per in-flight pass.
 struct Slot {
-    const uint8_t** h_ptrtab = nullptr;  // pinned
-    NoiseJob* h_jobs = nullptr;          // pinned
+    // pass header [pointer table (n-1+K) | noise jobs (K)]: one pinned block, one device block, ONE host-to-device copy
+    uint8_t *h_hdr = nullptr, *d_hdr = nullptr;
+    size_t hdr_jobs_off = 0;
+    int nj = 0;                          // due frames of the pass
+    const uint8_t** h_ptrtab = nullptr;  // view into h_hdr
+    NoiseJob* h_jobs = nullptr;          // view into h_hdr
     // written on the staging / noise stream, read by the pixel stages of the same pass
     const uint8_t** d_ptrtab = nullptr;
     NoiseJob* d_jobs = nullptr;
@@ -65,21 +69,25 @@ struct Slot {
     int* d_thr = nullptr;
     hipEvent_t ev_noise = nullptr;
     // dst is only written where it is non-zero; d_nzlist names the candidate words and k_sparse_clear zeroes them again
-    // on the staging stream before the slot's next pass (ev_prep).
+    // on the staging stream before the slot's next pass (k_pass_prepare, ahead of ev_noise).
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;
-    hipEvent_t ev_prep = nullptr;
     u64* d_bbits = nullptr;          // [K][H][WW] b = (diff > T), written by the window kernel, read by the morphology
     u64* d_planes = nullptr;         // Classic: [K][2][H][WW]
     unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output
     hipEvent_t ev_k1 = nullptr;      // window kernel done (main stream) -> the post stream may start
     hipEvent_t ev_close = nullptr;   // binaries of this pass are in the ring (the next pass's dynamic mask reads them)
     u64* d_dst = nullptr;
-    int *d_rowcount = nullptr, *d_litcount = nullptr, *h_litcount = nullptr, *d_bbox = nullptr;
-    FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
-    int *d_lines = nullptr, *h_lines = nullptr, *d_nraw = nullptr, *h_nraw = nullptr;
-    int *d_packed = nullptr, *d_off = nullptr, *h_off = nullptr;  // segments packed back to back (h_lines holds the host copy)
+    int *d_rowcount = nullptr, *d_litcount = nullptr, *d_bbox = nullptr;
+    int* d_lines = nullptr;
+    // result block [off (K+1) | nraw (K) | lit counts (K) | gap (K) | frame scalars (K) | packed segments]: same layout on
+    // the device and in pinned host memory, so the scalars and the head of the packed segments travel in ONE copy
+    uint8_t *d_res = nullptr, *h_res = nullptr;
+    size_t res_lines_off = 0;
+    int *d_off = nullptr, *h_off = nullptr, *d_nraw = nullptr, *h_nraw = nullptr, *d_litcopy = nullptr, *h_litcount = nullptr;
     double *d_gap = nullptr, *h_gap = nullptr;
+    FrameScalars *d_fscal = nullptr, *h_fscal = nullptr;
+    int *d_packed = nullptr, *h_lines = nullptr;  // segments packed back to back
     hipEvent_t ev_pix = nullptr, ev_done = nullptr;
     std::vector<ProfSpan> spans;
     // the pass occupying the slot
@@ -141,7 +149,7 @@ struct mdh_ctx {
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     uint8_t* d_expand = nullptr;
     Slot slot[NSLOT_MAX];
-    int nslot = 4;
+    int nslot = 6;
     int next_slot = 0;       // slot the next submitted pass takes
     int oldest = 0;          // slot of the oldest pass not yet collected
     int in_flight = 0;
@@ -164,6 +172,7 @@ struct mdh_ctx {
     // profiling
     bool prof = false;
     std::vector<ProfSpan>* cur_spans = nullptr;
+    std::vector<hipEvent_t> ev_pool;  // recycled timing events
     double host_us[6] = {0};  // MDH_HOST_TRACE=1: submit, wait for ev_done, segment copy, nms + unpack, (spare)
     int64_t host_n = 0;
     double prof_ms[MDH_NUM_KERNELS] = {0};
@@ -217,14 +226,13 @@ static void free_all(mdh_ctx* c) {
     for (void* p : dev)
         if (p) hipFree(p);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_bbits, s.d_planes, s.d_worklist, s.d_packed, s.d_off, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_fscal, s.d_lines, s.d_nraw, s.d_gap, s.d_ptrtab, s.d_jobs, s.d_sums, s.d_jobres, s.d_thr};
+        void* sdev[] = {s.d_bbits, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr};
         for (void* p : sdev)
             if (p) hipFree(p);
-        void* shost[] = {s.h_off, s.h_ptrtab, s.h_jobs, s.h_litcount, s.h_fscal, s.h_lines, s.h_nraw, s.h_gap};
+        void* shost[] = {s.h_hdr, s.h_res};
         for (void* p : shost)
             if (p) hipHostFree(p);
         if (s.ev_noise) hipEventDestroy(s.ev_noise);
-        if (s.ev_prep) hipEventDestroy(s.ev_prep);
         if (s.ev_k1) hipEventDestroy(s.ev_k1);
         if (s.ev_close) hipEventDestroy(s.ev_close);
         if (s.ev_pix) hipEventDestroy(s.ev_pix);
@@ -234,6 +242,7 @@ static void free_all(mdh_ctx* c) {
             hipEventDestroy(sp.b);
         }
     }
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     for (HoughSet& h : c->hset) {
         void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work};
         for (void* p : hdev)
@@ -322,15 +331,20 @@ static int create_impl(mdh_ctx* c) {
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
     for (int si = 0; si < c->nslot; ++si) {
         Slot& s = c->slot[si];
-        TRY(host_alloc(s.h_ptrtab, c->n - 1 + K));
-        TRY(host_alloc(s.h_jobs, K));
-        TRY(dev_alloc(s.d_ptrtab, c->n - 1 + K));
-        TRY(dev_alloc(s.d_jobs, K));
+        {
+            const size_t ptr_bytes = (sizeof(uint8_t*) * (c->n - 1 + K) + 15) & ~(size_t)15;
+            s.hdr_jobs_off = ptr_bytes;
+            TRY(host_alloc(s.h_hdr, ptr_bytes + sizeof(NoiseJob) * K));
+            TRY(dev_alloc(s.d_hdr, ptr_bytes + sizeof(NoiseJob) * K));
+            s.h_ptrtab = (const uint8_t**)s.h_hdr;
+            s.h_jobs = (NoiseJob*)(s.h_hdr + ptr_bytes);
+            s.d_ptrtab = (const uint8_t**)s.d_hdr;
+            s.d_jobs = (NoiseJob*)(s.d_hdr + ptr_bytes);
+        }
         TRY(dev_alloc(s.d_sums, 2 * K));
         TRY(dev_alloc(s.d_jobres, K + 1));
         TRY(dev_alloc(s.d_thr, K));
         HIPCHK(hipEventCreateWithFlags(&s.ev_noise, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_k1, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_close, hipEventDisableTiming));
         if (pix) {
@@ -349,18 +363,22 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_rowcount, K * c->H + 5 * K));
         s.d_litcount = s.d_rowcount + K * c->H;
         s.d_bbox = s.d_litcount + K;
-        TRY(host_alloc(s.h_litcount, K));
-        TRY(dev_alloc(s.d_fscal, K));
-        TRY(host_alloc(s.h_fscal, K));
         TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
-        TRY(host_alloc(s.h_lines, K * (size_t)MAX_LINES * 4));
-        TRY(dev_alloc(s.d_packed, K * (size_t)MAX_LINES * 4));
-        TRY(dev_alloc(s.d_off, K + 1));
-        TRY(host_alloc(s.h_off, K + 1));
-        TRY(dev_alloc(s.d_nraw, K));
-        TRY(host_alloc(s.h_nraw, K));
-        TRY(dev_alloc(s.d_gap, K));
-        TRY(host_alloc(s.h_gap, K));
+        {
+            auto a16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+            const size_t o_nraw = a16(sizeof(int) * (K + 1)), o_lit = o_nraw + a16(sizeof(int) * K), o_gap = o_lit + a16(sizeof(int) * K);
+            const size_t o_fs = o_gap + a16(sizeof(double) * K), o_lines = o_fs + a16(sizeof(FrameScalars) * K);
+            const size_t total = o_lines + sizeof(int) * 4 * K * (size_t)MAX_LINES;
+            TRY(dev_alloc(s.d_res, total));
+            TRY(host_alloc(s.h_res, total));
+            s.res_lines_off = o_lines;
+            s.d_off = (int*)s.d_res;                 s.h_off = (int*)s.h_res;
+            s.d_nraw = (int*)(s.d_res + o_nraw);     s.h_nraw = (int*)(s.h_res + o_nraw);
+            s.d_litcopy = (int*)(s.d_res + o_lit);   s.h_litcount = (int*)(s.h_res + o_lit);
+            s.d_gap = (double*)(s.d_res + o_gap);    s.h_gap = (double*)(s.h_res + o_gap);
+            s.d_fscal = (FrameScalars*)(s.d_res + o_fs);  s.h_fscal = (FrameScalars*)(s.h_res + o_fs);
+            s.d_packed = (int*)(s.d_res + o_lines);  s.h_lines = (int*)(s.h_res + o_lines);
+        }
         HIPCHK(hipEventCreateWithFlags(&s.ev_pix, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     }
@@ -483,12 +501,24 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
 extern "C" void mdh_destroy(mdh_ctx* c) { free_all(c); }
 
 // ------------------------------------------------------------------------------------------------ profiling
+// Timing events are taken from a per-context pool (creating and destroying a pair per kernel per pass cost more host
+// time than the launches themselves).
+static inline hipEvent_t pool_event(mdh_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
 static inline void span_begin(mdh_ctx* c, int kind, hipStream_t st) {
     if (!c->prof) return;
     ProfSpan s;
     s.kind = kind;
-    hipEventCreate(&s.a);
-    hipEventCreate(&s.b);
+    s.a = pool_event(c);
+    s.b = pool_event(c);
     hipEventRecord(s.a, st);
     c->cur_spans->push_back(s);
 }
@@ -509,8 +539,8 @@ static void spans_collect(mdh_ctx* c, Slot& sl) {
             hipEventElapsedTime(&t_b, c->ev_base, s.b);
             fprintf(stderr, "[mdh gpu] %-16s start %.1f us  end %.1f us\n", kKernelNames[s.kind], t_a * 1e3, t_b * 1e3);
         }
-        hipEventDestroy(s.a);
-        hipEventDestroy(s.b);
+        c->ev_pool.push_back(s.a);
+        c->ev_pool.push_back(s.b);
     }
     sl.spans.clear();
 }
@@ -565,7 +595,36 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
             i += run;
         }
     }
-    HIPCHK(hipMemcpyAsync(c->d_ptrtab, c->h_ptrtab, sizeof(uint8_t*) * (c->n - 1 + K), hipMemcpyHostToDevice, c->nstream));
+    // which frames are due for a noise sigma, and with which EMA momentum (host mirror of Detector.py:81-91, utils.py:360-368)
+    const int n = c->n;
+    const int64_t std_interval = (int64_t)c->cfg.interval * n;  // Detector.py:63
+    int nj = 0;
+    for (int i = 0; i < K; ++i) {
+        const int64_t t = t_base + 1 + i;
+        int k_used = 0;
+        if (t > n && t % std_interval == 0) k_used = n;      // Detector.py:82
+        else if (t > 1 && t <= n) k_used = (int)t;           // Detector.py:87
+        if (!k_used) continue;
+        double m = c->ema_m0;
+        if (c->ema_warm != 0) {  // utils.py:360-368
+            const double ramp = (double)c->ema_t * (1 - c->ema_m0) * c->ema_warm;
+            if (ramp < 1) {
+                const double u = 1 - ramp;
+                m = c->ema_m0 * (1 - u * u);
+            } else {
+                c->ema_warm = 0;
+            }
+        }
+        c->ema_t += 1;
+        NoiseJob& j = sl.h_jobs[nj++];
+        j.frame = i;
+        j.k_used = k_used;
+        j.m_cur = m;
+        j.one_minus = 1 - m;
+    }
+    sl.nj = nj;
+    // pointer table and jobs in one copy
+    HIPCHK(hipMemcpyAsync(sl.d_hdr, sl.h_hdr, sl.hdr_jobs_off + sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->nstream));
     return MDH_OK;
 }
 
@@ -638,42 +697,19 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
 // Returns the number of due frames in *nj_out.  (Row-band tiling all-reduces the sums between the two halves.)
 static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const int64_t t_base = sl.t_base;
-    const int n = c->n;
-    const int64_t std_interval = (int64_t)c->cfg.interval * n;  // Detector.py:63
-    int nj = 0;
-    for (int i = 0; i < K; ++i) {
-        const int64_t t = t_base + 1 + i;
-        int k_used = 0;
-        if (t > n && t % std_interval == 0) k_used = n;      // Detector.py:82
-        else if (t > 1 && t <= n) k_used = (int)t;           // Detector.py:87
-        if (!k_used) continue;
-        double m = c->ema_m0;
-        if (c->ema_warm != 0) {  // utils.py:360-368
-            const double ramp = (double)c->ema_t * (1 - c->ema_m0) * c->ema_warm;
-            if (ramp < 1) {
-                const double u = 1 - ramp;
-                m = c->ema_m0 * (1 - u * u);
-            } else {
-                c->ema_warm = 0;
-            }
-        }
-        c->ema_t += 1;
-        NoiseJob& j = sl.h_jobs[nj++];
-        j.frame = i;
-        j.k_used = k_used;
-        j.m_cur = m;
-        j.one_minus = 1 - m;
-    }
+    const int nj = sl.nj;  // built by stage_frames
     const int* r = c->cfg.roi;
     const int rh = r[2] - r[0], rw = r[3] - r[1];
     PassGeom g = geom(c, K, t_base);
-    // counters the pixel stages accumulate into (the slot's previous pass has been collected, so nothing reads them)
+    // One launch clears the counters the pixel stages accumulate into, the block bit counts, the noise sums and the dst
+    // words this slot's previous pass left behind (its last reader, that pass's Hough stage, is done: the pass has been
+    // collected).
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
-    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), c->nstream));
-    HIPCHK(hipMemsetAsync(sl.d_bandflag, 0, sizeof(unsigned) * ((size_t)K * nb * c->WW), c->nstream));
+    const bool m3 = c->cfg.detector == MDH_DET_M3;
+    hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
+                       (unsigned)((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), sl.d_bandflag, (unsigned)((size_t)K * nb * c->WW),
+                       (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
-        HIPCHK(hipMemcpyAsync(c->d_jobs, sl.h_jobs, sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->nstream));
-        HIPCHK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * 2 * nj, c->nstream));
         bool aligned4 = (c->W % 4) == 0;
         for (int e = 0; e < c->n - 1 + K && aligned4; ++e) aligned4 = ((uintptr_t)c->h_ptrtab[e] & 3) == 0;
         span_begin(c, KK_NOISE_SUMS, c->nstream);
@@ -700,18 +736,10 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
 static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
     span_begin(c, KK_NOISE_FINAL, c->nstream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
-                       sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b);
+                       sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
-    // Zero the dst words this slot's previous pass left behind.  Their last reader (that pass's Hough stage) is done
-    // because the pass has been collected.
-    if (c->cfg.detector == MDH_DET_M3) {
-        if (sl.used)
-            hipLaunchKernelGGL(k_sparse_clear, dim3(64), dim3(256), 0, c->nstream, sl.d_dst, sl.d_nzlist, sl.d_nzcount);
-        HIPCHK(hipMemsetAsync(sl.d_nzcount, 0, 2 * sizeof(unsigned), c->nstream));
-    }
-    HIPCHK(hipEventRecord(sl.ev_prep, c->nstream));
     return MDH_OK;
 }
 
@@ -748,7 +776,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     }
     HIPCHK(hipEventRecord(sl.ev_k1, c->stream));
     HIPCHK(hipStreamWaitEvent(post, sl.ev_k1, 0));
-    HIPCHK(hipStreamWaitEvent(post, sl.ev_prep, 0));  // dst of this slot is all-zero again
+    // (dst of this slot is all-zero again: k_pass_prepare ran before ev_noise, which the window kernel waited for)
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_MORPH, post);
         hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_bandflag,
@@ -769,7 +797,6 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
                            sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
     }
-    HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, post));
     HIPCHK(hipEventRecord(sl.ev_pix, post));
     return MDH_OK;
 }
@@ -832,13 +859,10 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     // pack the segments and send the head of the packed array along with the scalars; collect_pass fetches the rest only
     // when a pass holds more than PACK_HEAD segments per frame on average
     hipLaunchKernelGGL(k_pack_lines, dim3(1), dim3(1024), 0, hstream[0], (const int4*)sl.d_lines, sl.d_nraw, K, MAX_LINES,
-                       (int4*)sl.d_packed, sl.d_off);
-    HIPCHK(hipMemcpyAsync(sl.h_off, sl.d_off, sizeof(int) * (K + 1), hipMemcpyDeviceToHost, hstream[0]));
-    HIPCHK(hipMemcpyAsync(sl.h_lines, sl.d_packed, sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K, hipMemcpyDeviceToHost,
-                          hstream[0]));
-    HIPCHK(hipMemcpyAsync(sl.h_nraw, sl.d_nraw, sizeof(int) * K, hipMemcpyDeviceToHost, hstream[0]));
-    HIPCHK(hipMemcpyAsync(sl.h_litcount, sl.d_litcount, sizeof(int) * K, hipMemcpyDeviceToHost, hstream[0]));
-    HIPCHK(hipMemcpyAsync(sl.h_gap, sl.d_gap, sizeof(double) * K, hipMemcpyDeviceToHost, hstream[0]));
+                       (int4*)sl.d_packed, sl.d_off, sl.d_litcount, sl.d_litcopy);
+    // ONE copy: offsets, counts, gaps, frame scalars and the head of the packed segments
+    HIPCHK(hipMemcpyAsync(sl.h_res, sl.d_res, sl.res_lines_off + sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K,
+                          hipMemcpyDeviceToHost, hstream[0]));
     HIPCHK(hipEventRecord(sl.ev_done, hstream[0]));
     hs.last_slot = (int)(&sl - c->slot);
     c->prev_slot = (int)(&sl - c->slot);
@@ -1174,6 +1198,7 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
                        own_row0, own_rows, rows_stride, nsplit, Kp);
     HIPCHK(hipGetLastError());
     if (!out_on_device) HIPCHK(hipMemcpyAsync(dst_rows, dev_out, out_words * sizeof(u64), hipMemcpyDeviceToHost, post));
+    HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, post));
     HIPCHK(hipEventRecord(sl.ev_done, post));
     const int si = (int)(&sl - c->slot);
     hs.last_slot = si;
@@ -1208,7 +1233,6 @@ extern "C" int mdh_band_skip(mdh_ctx* c) {
     Slot& sl = *c->band_slot;
     // the frames are in the window (mdh_band_noise staged and retired them); nothing else happens for this pass
     HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
-    HIPCHK(hipEventRecord(sl.ev_prep, c->nstream));
     HIPCHK(hipEventRecord(sl.ev_done, c->nstream));
     slot_commit(c, sl);
     c->band_slot = nullptr;

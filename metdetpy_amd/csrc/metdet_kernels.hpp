@@ -167,8 +167,10 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
                                                         const long long* __restrict__ sums, ScalarState* __restrict__ st,
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
                                                         int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
-                                                        double coef_a, double coef_b) {
+                                                        double coef_a, double coef_b, unsigned* __restrict__ nzcount) {
     RAISE_WAVE_PRIORITY();
+    // the slot's list counters ([0] lit words, [1] morphology blocks): k_pass_prepare, earlier on this stream, was their last reader
+    if (nzcount && threadIdx.x < 2) nzcount[threadIdx.x] = 0;
     // jobres[0] = state on entry, jobres[j+1] = state after job j
     if (threadIdx.x == 0) {
         ScalarState s = *st;
@@ -777,12 +779,38 @@ __global__ void __launch_bounds__(256) k_sparse_clear(u64* __restrict__ dst_bits
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) dst_bits[nzlist[e]] = 0;
 }
 
+// Everything a pass needs zeroed before its kernels run, in ONE launch (each separate memset / kernel costs a trip through
+// the command processor, and the noise chain that follows is on the critical path of the pass): the counters the pixel
+// stages accumulate into, the block bit counts, the noise sums, and the dst words the slot's previous pass left behind
+// (listed in nzlist; nzcount itself is reset by k_noise_finalize, which runs next on the same stream).
+__global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ counters, unsigned n_counters,
+                                                      unsigned* __restrict__ blockcnt, unsigned n_blockcnt,
+                                                      unsigned* __restrict__ sums32, unsigned n_sums32, u64* __restrict__ dst_bits,
+                                                      const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount) {
+    RAISE_WAVE_PRIORITY();
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (unsigned e = tid; e < n_counters / 4; e += nth) ((uint4*)counters)[e] = z;
+    for (unsigned e = (n_counters & ~3u) + tid; e < n_counters; e += nth) counters[e] = 0;
+    for (unsigned e = tid; e < n_blockcnt / 4; e += nth) ((uint4*)blockcnt)[e] = z;
+    for (unsigned e = (n_blockcnt & ~3u) + tid; e < n_blockcnt; e += nth) blockcnt[e] = 0;
+    for (unsigned e = tid; e < n_sums32; e += nth) sums32[e] = 0;
+    if (nzcount) {
+        const unsigned total = *nzcount;
+        for (unsigned e = tid; e < total; e += nth) dst_bits[nzlist[e]] = 0;
+    }
+}
+
 // Result packing: the segments of a pass, [K][MAX_LINES][4] with nraw[i] valid rows each, are packed back to back
 // (frame order) so that the host fetches them with ONE contiguous copy; off[i] = first packed segment of frame i,
 // off[K] = total.  One workgroup: a scan over the frames, then a thread per frame moves its segments.
+// The per-frame lit counts are copied next to the other per-frame results, so that everything the host wants from a pass
+// sits in one contiguous block (one device-to-host copy).
 __global__ void __launch_bounds__(1024) k_pack_lines(const int4* __restrict__ lines, const int* __restrict__ nraw, int K,
-                                                     int max_lines, int4* __restrict__ packed, int* __restrict__ off) {
+                                                     int max_lines, int4* __restrict__ packed, int* __restrict__ off,
+                                                     const int* __restrict__ litcount, int* __restrict__ litcopy) {
     RAISE_WAVE_PRIORITY();
+    for (int i = threadIdx.x; i < K; i += blockDim.x) litcopy[i] = litcount[i];
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
