@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per step (and frames resident in HBM per GPU)")
+    ap.add_argument("--batch", type=int, default=2048, help="frames per step (and frames resident in HBM per GPU)")
     ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames generated per GPU; the resident "
                     "batch repeats them (generation is NumPy on the host and would otherwise dominate the run time)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
@@ -257,8 +257,10 @@ def main():
             achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
             traffic = None
             tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.workload}.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("stack_threshold_bytes_per_launch")
+            if os.path.exists(tpath):  # rocprofv3 PMC passes of this workload (tools/profile_round.sh), scaled to this batch
+                t = json.load(open(tpath))
+                if t.get("stack_threshold_bytes_per_launch"):
+                    traffic = int(t["stack_threshold_bytes_per_launch"] * B / t.get("frames_per_launch", B))
             out["roofline"] = {"bound": "hbm", "kernel": "stack_threshold", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "avg_launch_ms": ms / max(launches, 1), "launches": launches,
