@@ -145,6 +145,10 @@ void mdh_pre_destroy(mdh_pre* pre);
 int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint8_t* out,
                   int out_on_device);
 
+/* np.sum(frame) for K frames of frame_bytes bytes each (a multiple of 16, 16-byte aligned): the per-frame brightness series
+ * exposure estimation works on (_rf_est_kernel, videoloader.py:796-819).  sums: K uint64, host memory. */
+int mdh_frame_sums(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint64_t* sums);
+
 /* ---- Row-band tiling of ONE stream across GPUs (BASELINE config 5; SURVEY 8e "spatial row-bands") ----------------
  *
  * The frame is cut into nbands bands of band_rows = ceil(H / nbands) rows, one per GPU.  Band b owns rows

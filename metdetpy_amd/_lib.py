@@ -44,7 +44,7 @@ EXPORTS = [
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
-    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek"
+    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums"
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def load():
     L.mdh_band_pixels.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32, vp]
     L.mdh_hough_planes.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.mdh_band_skip.argtypes = [vp]
+    L.mdh_frame_sums.argtypes = [i32, vp, i32, u64, i32, vp]
     L.mdh_seek.argtypes = [vp, i64, i64, dbl, dbl, dbl, i32]
     _lib = L
     return L

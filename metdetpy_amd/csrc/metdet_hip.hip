@@ -1502,3 +1502,35 @@ extern "C" int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t 
     if (d_out) hipFree(d_out);
     return MDH_OK;
 }
+
+extern "C" int mdh_frame_sums(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint64_t* sums) {
+    if (!frames || !sums || K < 1 || frame_bytes == 0) { set_err("mdh_frame_sums: bad argument"); return MDH_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_err("mdh_frame_sums: no such HIP device (there is no CPU fallback)");
+        return MDH_E_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    uint8_t* d_in = nullptr;
+    unsigned long long* d_sums = nullptr;
+    const uint8_t* src = frames;
+    if (!on_device) {
+        HIPCHK(hipMalloc((void**)&d_in, (size_t)K * frame_bytes));
+        HIPCHK(hipMemcpy(d_in, frames, (size_t)K * frame_bytes, hipMemcpyHostToDevice));
+        src = d_in;
+    }
+    if (((uintptr_t)src | frame_bytes) & 15) {  // the vector loop wants 16-byte aligned frames
+        if (d_in) hipFree(d_in);
+        set_err("mdh_frame_sums: frames must be 16-byte aligned and a multiple of 16 bytes long");
+        return MDH_E_ARG;
+    }
+    HIPCHK(hipMalloc((void**)&d_sums, sizeof(unsigned long long) * K));
+    HIPCHK(hipMemset(d_sums, 0, sizeof(unsigned long long) * K));
+    const unsigned per_frame = (unsigned)std::min<size_t>(std::max<size_t>(frame_bytes / 16 / 256 / 4, 1), 64);
+    hipLaunchKernelGGL(k_frame_sums, dim3(per_frame, K), dim3(256), 0, 0, src, (size_t)frame_bytes, d_sums);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(sums, d_sums, sizeof(unsigned long long) * K, hipMemcpyDeviceToHost));
+    if (d_in) hipFree(d_in);
+    hipFree(d_sums);
+    return MDH_OK;
+}

@@ -79,3 +79,29 @@ __global__ void __launch_bounds__(256) k_max_stack(const uint8_t* __restrict__ f
         out[p] = m;
     }
 }
+
+// Per-frame pixel sums, np.sum(frame) of _rf_est_kernel (videoloader.py:796-819): the only thing exposure estimation
+// looks at.  grid = (blocks per frame, K); 16 bytes per lane per step, v_sad_u8 adds four bytes at a time; one 64-bit
+// atomic per block.  sums must be zero on entry.
+__global__ void __launch_bounds__(256) k_frame_sums(const uint8_t* __restrict__ frames, size_t bytes,
+                                                    unsigned long long* __restrict__ sums) {
+    const uint8_t* f = frames + (size_t)blockIdx.y * bytes;
+    const size_t nvec = bytes / 16;
+    unsigned acc = 0;  // <= 255 * 16 per step: no overflow below 2^20 steps per lane
+    unsigned long long total = 0;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+        const uint4 q = ((const uint4*)f)[v];
+        acc = __builtin_amdgcn_sad_u8(q.x, 0u, acc);
+        acc = __builtin_amdgcn_sad_u8(q.y, 0u, acc);
+        acc = __builtin_amdgcn_sad_u8(q.z, 0u, acc);
+        acc = __builtin_amdgcn_sad_u8(q.w, 0u, acc);
+        if (acc > 0xF0000000u) { total += acc; acc = 0; }
+    }
+    total += acc;
+    if (blockIdx.x == 0 && threadIdx.x < bytes % 16) total += f[nvec * 16 + threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[blockIdx.y], part[0] + part[1] + part[2] + part[3]);
+}

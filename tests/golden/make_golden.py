@@ -16,6 +16,8 @@ Fixtures
   g5_collector.json       MeteorCollector scripted (frame, lines, cates) -> MDRF records (collector.py:372-770)
   g6_time.json            frame2ts / ts2frame / time2frame / frame2time                  (utils.py:635-720)
   g7_ema.json             EMA.update series                                             (utils.py:324-368)
+  g8_exposure.json        rf_estimator / _rf_est_kernel / sigma_clip / init_exp_time on scripted frame-sum series
+                          (videoloader.py:440-494, 796-870; utils.py:516-540)
 """
 import json
 import os
@@ -310,6 +312,100 @@ def main():
         g7.append({"momentum": m, "warmup_speed": w, "x": xs.tolist(), "value": vals, "cur_momentum": moms})
     json.dump(g7, open(os.path.join(HERE, "g7_ema.json"), "w"))
     print("golden fixtures written to", HERE)
+    # ---------------------------------------------------------------- G8: exposure estimation
+    gen_exposure()
+
+
+class ScriptedLoader:
+    """The attributes and calls rf_estimator / _rf_est_kernel / init_exp_time make on a video loader, over a scripted series
+    of per-frame pixel sums (each frame is a 1-pixel image holding its sum: np.sum(frame) is all the reference looks at)."""
+
+    def __init__(self, sums, fps):
+        self.all = [float(v) for v in sums]
+        self.start_frame, self.end_frame = 0, len(self.all)
+        self.exp_frame = 1
+        self.pos = 0
+        self.windows = []
+
+        class _V:
+            pass
+
+        self.video = _V()
+        self.video.fps = fps
+
+        class _L:
+            def info(self, *a):
+                pass
+
+            warning = info
+
+        self.logger = _L()
+
+    @property
+    def iterations(self):
+        return self.cur_end - self.cur_start if hasattr(self, "cur_start") else self.end_frame - self.start_frame
+
+    def reset(self, start_frame=None, end_frame=None, **kw):
+        self.cur_start = self.start_frame if start_frame is None else start_frame
+        self.cur_end = self.end_frame if end_frame is None else end_frame
+
+    def start(self):
+        if not hasattr(self, "cur_start"):
+            self.reset()
+        self.pos = self.cur_start
+        self.windows.append([self.cur_start, self.cur_end])
+
+    @property
+    def stopped(self):
+        return self.pos >= self.cur_end
+
+    def pop(self):
+        v = self.all[self.pos]
+        self.pos += 1
+        return np.array([[v]])
+
+    def stop(self):
+        pass
+
+
+def exposure_series(seed, length, period, jitter=0.0, drift=0.0):
+    """Per-frame sums of a camera whose real exposure spans `period` video frames: the sum jumps when a new exposure starts and
+    repeats (plus noise) in between."""
+    rng = np.random.default_rng(seed)
+    out, level = [], 5.0e7
+    for i in range(length):
+        if i % period == 0:
+            level = 5.0e7 + rng.normal(0, 4.0e5) + drift * i
+        out.append(float(np.rint(level + rng.normal(0, jitter))))
+    return out
+
+
+def gen_exposure():
+    from MetLib import videoloader as VL
+    from MetLib.utils import sigma_clip
+    g8 = {"rf": [], "sigma_clip": [], "init_exp_time": []}
+    cases = [(1, 120, 1, 0.0), (2, 250, 2, 50.0), (3, 299, 3, 500.0), (4, 300, 2, 100.0), (5, 1000, 4, 2000.0), (6, 777, 5, 0.0),
+             (7, 90, 6, 3.0e4), (8, 400, 1, 1.0e5), (9, 10, 2, 0.0), (10, 4, 1, 0.0)]
+    for seed, length, period, jitter in cases:
+        sums = exposure_series(seed, length, period, jitter)
+        ld = ScriptedLoader(sums, 25.0)
+        est = VL.rf_estimator(ld)
+        g8["rf"].append(dict(seed=seed, length=length, period=period, jitter=jitter, sums=sums, windows=ld.windows,
+                             estimate=float(est)))
+    rng = np.random.default_rng(3)
+    for k in range(8):
+        seq = rng.integers(1, 6, int(rng.integers(3, 40))).tolist()
+        if k % 2:
+            seq += [int(rng.integers(20, 90))]
+        g8["sigma_clip"].append(dict(seq=seq, out=[int(v) for v in sigma_clip(seq)]))
+    for opt, fps, ub in [("auto", 25.0, 0.25), ("auto", 50.0, 0.5), ("slow", 30.0, 0.25), ("real-time", 30.0, 0.25),
+                         ("0.5", 25.0, 0.25), (0.01, 25.0, 0.25), (0.2, 25.0, 0.25), ("auto", 3.0, 0.25), (1, 4.0, 0.25)]:
+        sums = exposure_series(42, 260, 3, 80.0)
+        ld = ScriptedLoader(sums, fps)
+        val = VL.VanillaVideoLoader.init_exp_time(ld, opt, ub)
+        g8["init_exp_time"].append(dict(option=opt, fps=fps, upper_bound=ub, sums=sums, exp_time=float(val),
+                                        exp_frame=int(round(float(val) * fps))))
+    json.dump(g8, open(os.path.join(HERE, "g8_exposure.json"), "w"))
 
 
 if __name__ == "__main__":
