@@ -206,6 +206,48 @@ int mdh_band_skip(mdh_ctx* ctx);
  * sigma / thr_float / thr the values in force after frame t0.  No pass may be in flight. */
 int mdh_seek(mdh_ctx* ctx, int64_t t0, int64_t ema_updates, double snr, double sigma, double thr_float, int thr);
 
+/* ---- Native MeteorCollector bookkeeping (collector.py:372-631) ---------------------------------------------
+ * Host code, no GPU needed.  Consumes (frame, lines, cates) exactly as MeteorCollector.update does and queues the series it
+ * finishes as mdh_target records (unrounded); metdetpy_amd/collector.py turns them into MDRF records. */
+typedef struct mdh_collector_cfg {
+    double min_len, max_interval;        /* MeteorCfg.min_len, .max_interval (seconds) */
+    double time_range[2], speed_range[2], drct_range[2];
+    double det_thre;
+    double thre2;                        /* MeteorCfg.thre2 (multiplied by exp_frame inside, collector.py:403) */
+    double fps;                          /* RuntimeParams.fps */
+    int32_t exp_frame;
+    int32_t runtime_w, runtime_h;        /* RuntimeParams.runtime_size */
+    int32_t num_cls;
+} mdh_collector_cfg;
+
+typedef struct mdh_target {              /* MeteorSeries.get_met_attr + score, before rounding (collector.py:283-306, 617-627) */
+    int32_t flag;                        /* 0: dropped series (DROP_FLAG), 1: member of an exported waiting list (ACTIVE_FLAG) */
+    int32_t group;                       /* records of one export() call share a group number, in export order */
+    int64_t start_frame, end_frame, last_activate_frame, duration;
+    double speed, dist, fix_dist, fix_speed, fix_motion_duration, fix_duration, drct_loss, score;
+    int32_t num_pts, category;           /* category: class id (arg-max of the accumulated class probabilities) */
+    int32_t pt1[2], pt2[2];
+    int32_t center_off, n_center;        /* centre points: centers[2*(center_off + j)], [.. + 1], j < n_center (float64 means) */
+    int32_t score_is_int;                /* the reference's score is a Python int here (all four factors on flat parts of their curves) */
+    int32_t reserved;
+} mdh_target;
+
+typedef struct mdh_collector mdh_collector;
+mdh_collector* mdh_collector_create(const mdh_collector_cfg* cfg);
+void mdh_collector_destroy(mdh_collector* c);
+/* MeteorCollector.update(cur_frame, lines, cates): lines n x 4 int32, cates n x num_cls float64 (n may be 0). */
+int mdh_collector_update(mdh_collector* c, int64_t cur_frame, const int32_t* lines, const double* cates, int n);
+/* K frames of one detector pass in one call, with the main loop's gating (MetDetPy.py:200-202): frame i of the pass is
+ * iteration it0 + i and video frame frame0 + i * exp_frame; it is fed when it has lines or its iteration is a multiple of
+ * eq_int_fps.  info / nms_lines / nonline: as mdh_collect_batch returns them (cls_pred is rebuilt as column 0 = 1 - nonline,
+ * last column = nonline, Detector.py:382-392). */
+int mdh_collector_update_batch(mdh_collector* c, int K, int64_t frame0, int64_t it0, int eq_int_fps, const mdh_frame_info* info,
+                               const int32_t* nms_lines, const double* nonline);
+/* Queued records: returns their number (negative on error) and copies up to cap of them / cap_centers centre points; the
+ * queue is emptied only when everything fitted (call with cap = 0 to size the buffers: *n_centers is always set). */
+int mdh_collector_events(mdh_collector* c, mdh_target* out, int cap, double* centers, int cap_centers, int* n_centers);
+int mdh_collector_active(const mdh_collector* c);   /* series currently open (without the reference's sentinel) */
+
 /* Debug: with MDH_HOUGH_DEBUG=1 in the environment at mdh_create, the Hough kernel records 8 cycle counters per frame
  * of the last pass (lit pixels, list build, PPHT total, draws, mask checks, votes, trigger scan, line handling). */
 int mdh_debug_hough(mdh_ctx* ctx, long long* out, int K);

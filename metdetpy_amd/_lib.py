@@ -34,6 +34,21 @@ class MdhFrameInfo(C.Structure):
                 ("hough_gap", C.c_double)]
 
 
+class MdhCollectorCfg(C.Structure):
+    _fields_ = [("min_len", C.c_double), ("max_interval", C.c_double), ("time_range", C.c_double * 2),
+                ("speed_range", C.c_double * 2), ("drct_range", C.c_double * 2), ("det_thre", C.c_double), ("thre2", C.c_double),
+                ("fps", C.c_double), ("exp_frame", C.c_int32), ("runtime_w", C.c_int32), ("runtime_h", C.c_int32),
+                ("num_cls", C.c_int32)]
+
+
+TARGET_DTYPE = np.dtype([("flag", "<i4"), ("group", "<i4"), ("start_frame", "<i8"), ("end_frame", "<i8"),
+                         ("last_activate_frame", "<i8"), ("duration", "<i8"), ("speed", "<f8"), ("dist", "<f8"),
+                         ("fix_dist", "<f8"), ("fix_speed", "<f8"), ("fix_motion_duration", "<f8"), ("fix_duration", "<f8"),
+                         ("drct_loss", "<f8"), ("score", "<f8"), ("num_pts", "<i4"), ("category", "<i4"), ("pt1", "<i4", (2, )),
+                         ("pt2", "<i4", (2, )), ("center_off", "<i4"), ("n_center", "<i4"), ("score_is_int", "<i4"),
+                         ("reserved", "<i4")])
+assert TARGET_DTYPE.itemsize == 144
+
 FRAME_INFO_DTYPE = np.dtype([("n_raw", "<i4"), ("n_nms", "<i4"), ("lit_count", "<i4"), ("bi_threshold", "<i4"),
                              ("bi_threshold_float", "<f8"), ("snr", "<f8"), ("sigma", "<f8"), ("dst_sum", "<f8"),
                              ("hough_gap", "<f8")])
@@ -44,7 +59,9 @@ EXPORTS = [
     "mdh_lineset_nms", "mdh_device_alloc", "mdh_device_free", "mdh_device_upload", "mdh_profile_enable",
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
-    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums"
+    "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
+    "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
+    "mdh_collector_active"
 ]
 
 _lib = None
@@ -98,6 +115,14 @@ def load():
     L.mdh_band_pixels.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32, vp]
     L.mdh_hough_planes.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.mdh_band_skip.argtypes = [vp]
+    L.mdh_collector_create.argtypes = [C.POINTER(MdhCollectorCfg)]
+    L.mdh_collector_create.restype = vp
+    L.mdh_collector_destroy.argtypes = [vp]
+    L.mdh_collector_destroy.restype = None
+    L.mdh_collector_update.argtypes = [vp, i64, vp, vp, i32]
+    L.mdh_collector_update_batch.argtypes = [vp, i32, i64, i64, i32, vp, vp, vp]
+    L.mdh_collector_events.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.mdh_collector_active.argtypes = [vp]
     L.mdh_frame_sums.argtypes = [i32, vp, i32, u64, i32, vp]
     L.mdh_seek.argtypes = [vp, i64, i64, dbl, dbl, dbl, i32]
     _lib = L

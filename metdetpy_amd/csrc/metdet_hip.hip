@@ -15,6 +15,7 @@
 // to frame (frame ring, ring of binaries, running scalars) is only touched on the main stream, in stream order.
 #include "metdet_kernels.hpp"
 #include "metdet_pre.hpp"
+#include "metdet_collector.hpp"
 
 #include "../../include/metdet_hip.h"
 
@@ -1533,4 +1534,65 @@ extern "C" int mdh_frame_sums(int device, const uint8_t* frames, int K, uint64_t
     if (d_in) hipFree(d_in);
     hipFree(d_sums);
     return MDH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ native collector
+extern "C" mdh_collector* mdh_collector_create(const mdh_collector_cfg* cfg) {
+    if (!cfg || !(cfg->fps > 0) || cfg->num_cls < 2 || cfg->exp_frame < 1 || cfg->runtime_w < 1 || cfg->runtime_h < 1) {
+        set_err("mdh_collector_create: bad configuration");
+        return nullptr;
+    }
+    mdh_collector* c = new mdh_collector();
+    c->cfg = *cfg;
+    c->max_interval = cfg->max_interval * cfg->fps;
+    c->max_acti_frame = (int64_t)(cfg->max_interval * cfg->fps);  // int(): truncation
+    c->thre2 = cfg->thre2 * cfg->exp_frame;
+    c->runtime_length = (double)std::max(cfg->runtime_w, cfg->runtime_h);
+    c->time_prob = mdc::ProbFunc{cfg->time_range[0], cfg->time_range[1]};
+    c->speed_prob = mdc::ProbFunc{cfg->speed_range[0], cfg->speed_range[1]};
+    c->len_prob = mdc::ProbFunc{cfg->min_len, std::numeric_limits<double>::infinity()};
+    c->drct_prob = mdc::ProbFunc{cfg->drct_range[0], cfg->drct_range[1]};
+    return c;
+}
+extern "C" void mdh_collector_destroy(mdh_collector* c) { delete c; }
+extern "C" int mdh_collector_active(const mdh_collector* c) { return c ? (int)c->active.size() : -1; }
+
+extern "C" int mdh_collector_update(mdh_collector* c, int64_t cur_frame, const int32_t* lines, const double* cates, int n) {
+    if (!c || (n > 0 && (!lines || !cates))) { set_err("mdh_collector_update: null argument"); return MDH_E_ARG; }
+    const int rc = c->update(cur_frame, lines, cates, n);
+    if (rc != MDH_OK) set_err("mdh_collector_update: " + c->err);
+    return rc;
+}
+
+extern "C" int mdh_collector_update_batch(mdh_collector* c, int K, int64_t frame0, int64_t it0, int eq_int_fps,
+                                          const mdh_frame_info* info, const int32_t* nms_lines, const double* nonline) {
+    if (!c || !info || !nms_lines || !nonline || K < 0 || eq_int_fps < 1) { set_err("mdh_collector_update_batch: bad argument"); return MDH_E_ARG; }
+    const int num_cls = c->cfg.num_cls;
+    std::vector<double> cates;
+    for (int i = 0; i < K; ++i) {
+        const int n = (info[i].n_raw > 0 && info[i].n_raw <= 500) ? info[i].n_nms : 0;  // NUM_LINES_TOOMUCH (Detector.py:30, 358-360)
+        if (n == 0 && (it0 + i) % eq_int_fps != 0) continue;
+        cates.assign((size_t)n * num_cls, 0.0);
+        const double* p = nonline + (size_t)i * MDH_MAX_LINES;
+        for (int k = 0; k < n; ++k) {
+            cates[(size_t)k * num_cls + num_cls - 1] = p[k];
+            cates[(size_t)k * num_cls] = 1 - p[k];
+        }
+        const int rc = c->update(frame0 + (int64_t)i * c->cfg.exp_frame, nms_lines + (size_t)i * MDH_MAX_LINES * 4, cates.data(), n);
+        if (rc != MDH_OK) { set_err("mdh_collector_update_batch: " + c->err); return rc; }
+    }
+    return MDH_OK;
+}
+
+extern "C" int mdh_collector_events(mdh_collector* c, mdh_target* out, int cap, double* centers, int cap_centers, int* n_centers) {
+    if (!c) { set_err("mdh_collector_events: null collector"); return MDH_E_ARG; }
+    const int n = (int)c->events.size(), nc = (int)(c->centers.size() / 2);
+    if (n_centers) *n_centers = nc;
+    if (n <= cap && nc <= cap_centers && out && (centers || nc == 0)) {
+        if (n) memcpy(out, c->events.data(), sizeof(mdh_target) * n);
+        if (nc) memcpy(centers, c->centers.data(), sizeof(double) * 2 * nc);
+        c->events.clear();
+        c->centers.clear();
+    }
+    return n;
 }

@@ -8,7 +8,7 @@ from typing import Iterable, Optional
 
 import numpy as np
 
-from .collector import MeteorCollector
+from .collector import MeteorCollector, NativeMeteorCollector
 from .detector import M3Detector
 from .metstruct import BinaryCfg, CollectorCfg, RuntimeParams
 from .utils import VERSION, get_num_class
@@ -16,13 +16,14 @@ from .utils import VERSION, get_num_class
 
 def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: BinaryCfg, collector_cfg: CollectorCfg,
                   rt: RuntimeParams, *, window_sec: float = 1.0, batch: int = 64, device: int = 0, logger=None,
-                  detector_cls=M3Detector, start_frame: int = 0):
+                  detector_cls=M3Detector, start_frame: int = 0, native_collector: bool = False):
     """Feed `frames` (each (H,W) uint8, one per exposure frame) through the detector and the collector exactly in the
     order the reference's loop does: collector.update(i, lines, cates) when the frame has lines, or on every
     eq_int_fps-th iteration (MetDetPy.py:200-202); collector.clear() at the end (MetDetPy.py:237).
-    Returns (records, per_frame_info)."""
+    With native_collector=True the result arrays of a pass go to the native collector in one call (same records; the
+    per-frame Python bookkeeping is what limits the loop otherwise).  Returns (records, per_frame_info)."""
     det = detector_cls(window_sec, rt.eq_fps, mask, get_num_class(), detector_cfg, logger, device=device, max_batch=batch)
-    col = MeteorCollector(collector_cfg, rt, None, logger)
+    col = (NativeMeteorCollector if native_collector else MeteorCollector)(collector_cfg, rt, None, logger)
     infos = []
     it = 0
     buf = []
@@ -30,6 +31,13 @@ def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: 
     def flush():
         nonlocal it
         if not buf:
+            return
+        if native_collector and detector_cls is M3Detector:
+            info, _raw, nms, prob = det._ctx.process_batch(np.stack(buf))
+            col.update_batch(start_frame + it * rt.exp_frame, it, info, nms, prob)
+            it += len(buf)
+            infos.append(info)
+            buf.clear()
             return
         results, info = det.detect_batch(np.stack(buf))
         for (lines, cates) in results:

@@ -49,6 +49,9 @@ def test_stream_records_equal_oracle_pipeline_and_find_the_streaks():
     got = [r.to_dict() for r in records]
     assert got == want
     assert to_mdrf(records, [W * 2, H * 2], rt)["results"] == want
+    # the native collector fed one pass at a time gives the same records
+    records_n, info_n = detect_stream(frames, mask, cfg, ccfg, rt, batch=64, native_collector=True)
+    assert [r.to_dict() for r in records_n] == want and np.array_equal(info_n["n_raw"], info["n_raw"])
     # every injected streak is matched by a positive record (evaluate.py rule)
     targets = [t for r in records for t in r.target if t.category == "METEOR" and t.score > 0.5]
     assert targets, [t.category for r in records for t in r.target]
