@@ -138,6 +138,10 @@ const char* mdh_kernel_name(int k);
 typedef struct mdh_pre mdh_pre;
 mdh_pre* mdh_pre_create(int device, int src_h, int src_w, int dst_h, int dst_w, const uint8_t* mask01);
 int mdh_pre_run(mdh_pre* pre, const uint8_t* bgr, int exp_frame, int src_on_device, uint8_t* out, int out_on_device);
+/* n_out output frames in one launch: bgr holds n_out * exp_frame source frames, out receives n_out * dst_h * dst_w bytes --
+ * with out_on_device = 1 a buffer that mdh_submit_batch / mdh_process_batch consume in place (on_device = 1), so decoded
+ * frames reach the detector without leaving HBM. */
+int mdh_pre_run_batch(mdh_pre* pre, const uint8_t* bgr, int n_out, int exp_frame, int src_on_device, uint8_t* out, int out_on_device);
 void mdh_pre_destroy(mdh_pre* pre);
 
 /* stacker.max_stacker / MaxImgContainer (stacker.py:43-49, 197-213): elementwise max over K frames of frame_bytes

@@ -61,7 +61,7 @@ EXPORTS = [
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
-    "mdh_collector_active"
+    "mdh_collector_active", "mdh_pre_run_batch"
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def load():
     L.mdh_pre_create.argtypes = [i32, i32, i32, i32, i32, vp]
     L.mdh_pre_create.restype = vp
     L.mdh_pre_run.argtypes = [vp, vp, i32, i32, vp, i32]
+    L.mdh_pre_run_batch.argtypes = [vp, vp, i32, i32, i32, vp, i32]
     L.mdh_pre_destroy.argtypes = [vp]
     L.mdh_pre_destroy.restype = None
     L.mdh_max_stack.argtypes = [i32, vp, i32, u64, i32, vp, i32]

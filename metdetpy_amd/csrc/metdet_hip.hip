@@ -1372,7 +1372,7 @@ struct mdh_pre {
     int *d_xi = nullptr, *d_yi = nullptr;
     short *d_xw = nullptr, *d_yw = nullptr;
     uint8_t *d_mask = nullptr, *d_src = nullptr, *d_out = nullptr;
-    size_t src_cap = 0;
+    size_t src_cap = 0, out_cap = 0;
 };
 
 // OpenCV resize(INTER_LINEAR) coefficient tables: fx = (float)((d+0.5)*scale-0.5), clamp, weights cvRound(w*2048)
@@ -1415,6 +1415,7 @@ static int pre_init(mdh_pre* p, const uint8_t* mask01) {
         (rc = dev_alloc(p->d_xw, xw.size(), false)) || (rc = dev_alloc(p->d_yw, yw.size(), false)) ||
         (rc = dev_alloc(p->d_out, (size_t)p->g.dh * p->g.dw, false)))
         return rc;
+    p->out_cap = (size_t)p->g.dh * p->g.dw;
     HIPCHK(hipMemcpy(p->d_xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_xw, xw.data(), xw.size() * sizeof(short), hipMemcpyHostToDevice));
@@ -1448,10 +1449,17 @@ extern "C" mdh_pre* mdh_pre_create(int device, int src_h, int src_w, int dst_h, 
     return p;
 }
 
+extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int exp_frame, int src_on_device, uint8_t* out,
+                                 int out_on_device);
 extern "C" int mdh_pre_run(mdh_pre* p, const uint8_t* bgr, int exp_frame, int src_on_device, uint8_t* out, int out_on_device) {
-    if (!p || !bgr || !out || exp_frame < 1) { set_err("mdh_pre_run: bad argument"); return MDH_E_ARG; }
+    return mdh_pre_run_batch(p, bgr, 1, exp_frame, src_on_device, out, out_on_device);
+}
+
+extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int exp_frame, int src_on_device, uint8_t* out,
+                                 int out_on_device) {
+    if (!p || !bgr || !out || exp_frame < 1 || n_out < 1) { set_err("mdh_pre_run_batch: bad argument"); return MDH_E_ARG; }
     HIPCHK(hipSetDevice(p->device));
-    const size_t frame = (size_t)p->g.sh * p->g.sw * 3, need = frame * exp_frame;
+    const size_t frame = (size_t)p->g.sh * p->g.sw * 3, need = frame * exp_frame * n_out;
     const uint8_t* src = bgr;
     if (!src_on_device) {
         if (p->src_cap < need) {
@@ -1463,12 +1471,18 @@ extern "C" int mdh_pre_run(mdh_pre* p, const uint8_t* bgr, int exp_frame, int sr
         HIPCHK(hipMemcpyAsync(p->d_src, bgr, need, hipMemcpyHostToDevice, p->stream));
         src = p->d_src;
     }
-    uint8_t* dst = out_on_device ? out : p->d_out;
     const int px = p->g.dh * p->g.dw;
-    hipLaunchKernelGGL(k_preprocess, dim3((px + 255) / 256), dim3(256), 0, p->stream, src, exp_frame, p->g, p->d_xi, p->d_xw,
+    if (!out_on_device && p->out_cap < (size_t)px * n_out) {
+        if (p->d_out) HIPCHK(hipFree(p->d_out));
+        p->d_out = nullptr;
+        HIPCHK(hipMalloc((void**)&p->d_out, (size_t)px * n_out));
+        p->out_cap = (size_t)px * n_out;
+    }
+    uint8_t* dst = out_on_device ? out : p->d_out;
+    hipLaunchKernelGGL(k_preprocess, dim3((px + 255) / 256, n_out), dim3(256), 0, p->stream, src, exp_frame, p->g, p->d_xi, p->d_xw,
                        p->d_yi, p->d_yw, p->d_mask, dst);
     HIPCHK(hipGetLastError());
-    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, p->d_out, (size_t)px, hipMemcpyDeviceToHost, p->stream));
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, p->d_out, (size_t)px * n_out, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return MDH_OK;
 }

@@ -20,6 +20,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint8_t* __restrict__ 
                                                     const uint8_t* __restrict__ mask01, uint8_t* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.dh * g.dw) return;
+    // blockIdx.y = output frame of a batch: its exp_frame source frames follow each other, its output is frame y of `out`
+    src += (size_t)blockIdx.y * exp_frame * g.sh * g.sw * 3;
+    out += (size_t)blockIdx.y * g.dh * g.dw;
     const int dy = p / g.dw, dx = p - dy * g.dw;
     const int x0 = xi[dx], x1 = min(x0 + 1, g.sw - 1);
     const int y0 = yi[dy], y1 = min(y0 + 1, g.sh - 1);

@@ -34,6 +34,20 @@ class Preprocessor:
         _lib.check(self.L.mdh_pre_run(self._h, f.ctypes.data, f.shape[0], 0, out.ctypes.data, 0), "mdh_pre_run")
         return out
 
+    def batch(self, bgr_frames: np.ndarray, exp_frame: int = 1) -> np.ndarray:
+        """bgr_frames: (n_out * exp_frame, H, W, 3) uint8 -> (n_out, dst_h, dst_w) uint8, one launch."""
+        f = np.ascontiguousarray(bgr_frames, dtype=np.uint8)
+        if f.ndim != 4 or f.shape[1:] != (self.sh, self.sw, 3) or len(f) % exp_frame:
+            raise ValueError(f"frames must be (n*{exp_frame},{self.sh},{self.sw},3), got {f.shape}")
+        n_out = len(f) // exp_frame
+        out = np.empty((n_out, self.dh, self.dw), np.uint8)
+        _lib.check(self.L.mdh_pre_run_batch(self._h, f.ctypes.data, n_out, int(exp_frame), 0, out.ctypes.data, 0), "mdh_pre_run_batch")
+        return out
+
+    def batch_device(self, src_ptr: int, n_out: int, exp_frame: int, out_ptr: int):
+        """Device to device: out_ptr (n_out * dst_h * dst_w bytes) can be handed to the detector with on_device=True."""
+        _lib.check(self.L.mdh_pre_run_batch(self._h, int(src_ptr), int(n_out), int(exp_frame), 1, int(out_ptr), 1), "mdh_pre_run_batch")
+
     def run_device(self, src_ptr: int, exp_frame: int, out_ptr: int):
         _lib.check(self.L.mdh_pre_run(self._h, int(src_ptr), int(exp_frame), 1, int(out_ptr), 1), "mdh_pre_run")
 
@@ -56,3 +70,31 @@ def max_stack(frames: np.ndarray, device: int = 0) -> np.ndarray:
     _lib.check(_lib.load().mdh_max_stack(int(device), f.ctypes.data, f.shape[0], out.nbytes, 0, out.ctypes.data, 0),
                "mdh_max_stack")
     return out
+
+
+def load_mask(image: np.ndarray | None, kind: str = "jpg", dsize_wh=None, grayscale: bool = True, device: int = 0) -> np.ndarray:
+    """fileio.load_mask (fileio.py:250-292) on a decoded mask image (decoding is the caller's: the reference uses cv2.imread).
+    kind "jpg": BGR image -> resize -> BGR2GRAY -> (> 128 -> 1);  kind "png": BGRA image -> alpha channel -> resize ->
+    (> 128 -> 0, else 1).  image None: all ones of size dsize_wh.  The resize / gray arithmetic runs in the same GPU kernel
+    as the frame preprocessing (a gray of three equal channels is the channel itself: the 15-bit weights sum to 2^15)."""
+    if image is None:
+        if dsize_wh is None:
+            raise ValueError("opencv_resize is required when mask_fname is empty!")
+        m = np.ones((int(dsize_wh[1]), int(dsize_wh[0])), np.uint8)
+    else:
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if kind == "jpg":
+            if img.ndim != 3 or img.shape[2] != 3:
+                raise ValueError("a .jpg mask must be a BGR image")
+            src = img
+        elif kind == "png":
+            if img.ndim != 3:
+                raise ValueError("a .png mask must have an alpha channel")
+            src = np.repeat(img[:, :, -1:], 3, axis=2)
+        else:
+            raise ValueError("mask kind must be 'jpg' or 'png'")
+        pre = Preprocessor(src.shape[:2], dsize_wh, None, device=device)
+        g = pre(src)
+        pre.close()
+        m = (g > 128).astype(np.uint8) if kind == "jpg" else (g <= 128).astype(np.uint8)
+    return m if grayscale else np.repeat(m[:, :, None], 3, axis=2)
