@@ -73,7 +73,7 @@ struct Slot {
     // on the staging stream before the slot's next pass (k_pass_prepare, ahead of ev_noise).
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;
-    u64* d_bbits = nullptr;          // [K][H][WW] b = (diff > T), written by the window kernel, read by the morphology
+    ActWord* d_bbits = nullptr;      // [K][H][WW] b = (diff > T), sparse + tagged: written by the window kernel, read by the morphology
     u64* d_planes = nullptr;         // Classic: [K][2][H][WW]
     unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output
     hipEvent_t ev_k1 = nullptr;      // window kernel done (main stream) -> the post stream may start
@@ -143,7 +143,7 @@ struct mdh_ctx {
     int* d_thr = nullptr;
     unsigned* d_bandflag = nullptr;
     ScalarState* d_state = nullptr;  // running scalars, only touched on the noise stream
-    u64* d_bbits = nullptr;    // alias of the current slot's buffer (set by slot_begin)
+    ActWord* d_bbits = nullptr;  // alias of the current slot's buffer (set by slot_begin)
     ActWord* d_act = nullptr;  // [R][H][WW] tagged sparse ring of closed binaries
     int prev_slot = -1;        // slot of the pass submitted before the one being queued
     float* d_trig = nullptr;
@@ -767,8 +767,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
         static const bool skip_window = getenv("MDH_SKIP_WINDOW") != nullptr;  // timing experiments only: results are wrong
-        if (skip_window) HIPCHK(hipMemsetAsync(c->d_bbits, 0, sizeof(u64) * (size_t)K * c->words, c->stream));
-        else launch_stack_threshold(c, g);
+        if (!skip_window) launch_stack_threshold(c, g);  // (nothing stored = all zero: the words are tagged)
         span_end(c, c->stream);
     } else {
         span_begin(c, KK_CLASSIC, c->stream);
@@ -1265,6 +1264,8 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
     HIPCHK(hipMemcpy(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
     // binaries of the previous position must not be taken for frames of the new one (the ring is tagged by frame number)
     if (c->d_act) HIPCHK(hipMemset(c->d_act, 0, sizeof(ActWord) * (size_t)c->R * c->words));
+    for (int si = 0; si < c->nslot; ++si)
+        if (c->slot[si].d_bbits) HIPCHK(hipMemset(c->slot[si].d_bbits, 0, sizeof(ActWord) * (size_t)c->Kmax * c->words));
     for (int si = 0; si < c->nslot; ++si) {
         Slot& sl = c->slot[si];
         if (sl.used && sl.d_dst && sl.d_nzlist) {

@@ -208,13 +208,27 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
     }
 }
 
+// Bit images that are almost entirely zero are kept SPARSE and TAGGED.
+// (1) The thresholded difference b of a pass ([K][H][WW], per slot): the window kernel stores only the words with set bits --
+// writing the zeros too made a quarter of its run time (mixed read / write HBM traffic, tools/hbm_read_probe.hip).
+// (2) The ring of closed binaries (`act`, one row per frame, R rows): k_morph_close stores only the words that
+// have lit pixels, each with the number of the frame it belongs to, and never clears anything.  A reader asks for
+// frame t and treats a word whose tag differs (never written, or left over from frame t - k*R) as zero.
+struct __attribute__((aligned(16))) ActWord {
+    u64 bits;
+    u64 tag;  // frame number t >= 1 (0 = never written)
+};
+__device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw, u64 t) {
+    const ActWord a = row[gw];
+    return a.tag == t ? a.bits : 0ull;
+}
 // ------------------------------------------------------------------------------------------------
 // a1 + a4 + a6 (pointwise part): b = (max - floor(sum/len) > T), bit-packed.
 // floor(s/len) < c  <=>  s < c*len for integer c, so no division is needed:
 //   b = (max > T) && (sum < (max - T) * len)
 // Generic-n version: one lane per pixel, n byte loads per pixel (the "algorithmic" (n+1) reads of SURVEY 8d).
 __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* const* __restrict__ ptrtab,
-                                                                 const int* __restrict__ thr_tab, u64* __restrict__ bbits,
+                                                                 const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                                  unsigned* __restrict__ blockcnt, PassGeom g) {
     const int i = blockIdx.y;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -239,7 +253,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* 
     const bool b = valid && (sum < c * len);
     const u64 m = __ballot(b);
     if (lane == 0) {
-        bbits[((size_t)i * g.H + y) * g.WW + w] = m;
+        if (m) bbits[((size_t)i * g.H + y) * g.WW + w] = ActWord{m, (u64)(g.t_base + 1 + i)};
         if (m) atomicAdd(&blockcnt[((size_t)i * ((g.H + MORPH_RB - 1) / MORPH_RB) + y / MORPH_RB) * g.WW + w], (unsigned)__popcll(m));
     }
 }
@@ -252,7 +266,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 template <int N>
 __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const* __restrict__ ptrtab,
-                                                            const int* __restrict__ thr_tab, u64* __restrict__ bbits,
+                                                            const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                             unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
     constexpr int U = N < 8 ? N : 8;  // frames fetched per load burst
     const int lane = threadIdx.x & 63;
@@ -340,7 +354,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
                         const u64 b2 = __ballot((e23.u & 0xFFFFu) != 0), b3 = __ballot(e23.u > 0xFFFFu);
                         if (lane < 4 && gw0 + lane < words) {
                             const u64 v = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-                            bbits[(size_t)i * words + gw0 + lane] = v;
+                            if (v) bbits[(size_t)i * words + gw0 + lane] = ActWord{v, (u64)(g.t_base + 1 + i)};
                             if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)((gw0 + lane) / g.WW / MORPH_RB) * g.WW + (gw0 + lane) % g.WW], (unsigned)__popcll(v));  // rare
                         }
                     }
@@ -358,14 +372,17 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_OCC
 #define WIDE_OCC
 #endif
+#ifndef WIDE_U16
+#define WIDE_U16 4  // frames per load burst of the 16-pixels-per-lane kernel (A/B builds: -DWIDE_U16=8)
+#endif
 template <int N, int PPL>
 __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
-                                                              const int* __restrict__ thr_tab, u64* __restrict__ bbits,
+                                                              const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                               unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
     constexpr int RW = PPL / 2;   // packed pair registers per window entry
     constexpr int DW = PPL / 4;   // dwords per load
     constexpr int LPW = 64 / PPL; // lanes per 64-pixel word
-    constexpr int U = PPL == 16 ? (N < 4 ? N : 4) : (N < 8 ? N : 8);
+    constexpr int U = PPL == 16 ? (N < WIDE_U16 ? N : WIDE_U16) : (N < 8 ? N : 8);
     typedef unsigned dvec __attribute__((ext_vector_type(DW)));
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
@@ -401,8 +418,14 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     };
     constexpr int GS = 4;                  // window slots per max group
     constexpr int NG = (N + GS - 1) / GS;  // groups
+    constexpr int GL = NG - 1;             // the last group; its last slot, N-1, is where the first frame of a block goes
+    constexpr int GSL = N - GL * GS;       // size of the last group
     PK win[N][RW];
-    u16x2 gmax[NG][RW];
+    // Sliding maximum in 3 packed max per frame instead of (group size - 1) + (NG - 1).  The window slots are filled
+    // cyclically; while group g is being refilled the maxima of the other groups do not change (oth), the part of g not
+    // yet overwritten only shrinks (suffix maxima, taken once when the refill starts: R_k = max(old_{k+1}.., oth)) and the
+    // part already overwritten only grows (running prefix maximum P): window max = max(P, R_k).
+    u16x2 gmax[NG][RW], oth[RW], pre[RW], suf[GS > 1 ? GS - 1 : 1][RW];
     // Window sums: two 16-bit fields per register, updated with plain 32-bit adds / subtracts (a field never carries or
     // borrows: 255 * (N + 1) < 2^16, and the value leaving the window is part of the sum).  v_add_u32 / v_sub_u32 issue at
     // twice the rate of the packed 16-bit forms on gfx950 (tools/valu_rate.hip).
@@ -418,13 +441,26 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
 #pragma unroll
     for (int r = 0; r < RW; ++r) win[N - 1][r].u = 0;
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
+    for (int r = 0; r < RW; ++r) {
+        // complete groups from the prologue; the state below is "about to fill slot N-1, the last slot of group GL"
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
+        for (int gi = 0; gi < GL; ++gi) {
             u16x2 m = win[gi * GS][r].v;
 #pragma unroll
-            for (int k = gi * GS + 1; k < (gi + 1) * GS && k < N; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
+            for (int k = gi * GS + 1; k < (gi + 1) * GS; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
             gmax[gi][r] = m;
+        }
+        if constexpr (GSL > 1) {
+            u16x2 m = win[GL * GS][r].v;
+#pragma unroll
+            for (int k = GL * GS + 1; k < N - 1; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
+            pre[r] = m;
+            if constexpr (NG > 1) {
+                u16x2 o = gmax[0][r];
+#pragma unroll
+                for (int h = 1; h < GL; ++h) o = __builtin_elementwise_max(o, gmax[h][r]);
+                oth[r] = o;
+            }
         }
     }
     const int e_max = g.K + N - 2;
@@ -469,20 +505,39 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[ub + u] * len) * 0x10001u;  // scalar unit
                         const u16x2 NLv = {nlen, nlen};
                         unsigned acc = 0;
-                        const int grp = slot / GS;  // the group of 4 window slots the new frame falls into (static after unrolling)
+                        // group / position of the slot the new frame goes to (all static after unrolling)
+                        const int grp = slot / GS, kpos = slot % GS;
+                        const int gsz = grp == GL ? GSL : GS;
 #pragma unroll
                         for (int r = 0; r < RW; ++r) {
                             sum[r] = sum[r] + a[r].u - win[slot][r].u;
+                            if (kpos == 0) {  // the refill of group grp starts: maxima of the other groups, suffix maxima of this one
+                                if constexpr (NG > 1) {
+                                    u16x2 o = gmax[grp == 0 ? 1 : 0][r];
+#pragma unroll
+                                    for (int h = 0; h < NG; ++h)
+                                        if (h != grp && h != (grp == 0 ? 1 : 0)) o = __builtin_elementwise_max(o, gmax[h][r]);
+                                    oth[r] = o;
+                                }
+                                if (gsz >= 2) {
+                                    u16x2 sfx = win[grp * GS + gsz - 1][r].v;
+                                    suf[gsz - 2][r] = NG > 1 ? __builtin_elementwise_max(sfx, oth[r]) : sfx;
+#pragma unroll
+                                    for (int kk = GS - 3; kk >= 0; --kk)
+                                        if (kk <= gsz - 3) {
+                                            sfx = __builtin_elementwise_max(win[grp * GS + kk + 1][r].v, sfx);
+                                            suf[kk][r] = NG > 1 ? __builtin_elementwise_max(sfx, oth[r]) : sfx;
+                                        }
+                                }
+                                pre[r] = a[r].v;
+                            } else {
+                                pre[r] = __builtin_elementwise_max(pre[r], a[r].v);
+                            }
                             win[slot][r] = a[r];
-                            // two-level max: only the group that changed is re-reduced, then the NG group maxima
-                            u16x2 m = win[grp * GS][r].v;
-#pragma unroll
-                            for (int k = grp * GS + 1; k < (grp + 1) * GS && k < N; ++k)
-                                m = __builtin_elementwise_max(m, win[k][r].v);
-                            gmax[grp][r] = m;
-                            m = gmax[0][r];
-#pragma unroll
-                            for (int k = 1; k < NG; ++k) m = __builtin_elementwise_max(m, gmax[k][r]);
+                            u16x2 m = pre[r];
+                            if (kpos < gsz - 1) m = __builtin_elementwise_max(m, suf[kpos][r]);
+                            else if (NG > 1) m = __builtin_elementwise_max(m, oth[r]);
+                            if (kpos == gsz - 1) gmax[grp][r] = pre[r];
                             // sum < (max - T) * len  <=>  bit 15 of sum + (max - T) * (-len) mod 2^16 (all terms < 2^15 for
                             // n <= 128); written as a multiply-add so that it maps to one v_pk_mad_u16
                             PK d, st;
@@ -506,11 +561,9 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
 #pragma unroll
                             for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
                         }
-                        if (q == 0 && gw < words) {
-                            // frame base as a scalar (SGPR pair) + the lane's word offset: no per-frame vector multiplies
-                            u64* frame_bits = bbits + (size_t)__builtin_amdgcn_readfirstlane(i) * (size_t)words;
-                            frame_bits[gw] = v;
-                            if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
+                        if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
+                            bbits[(size_t)i * words + gw] = ActWord{v, (u64)(g.t_base + 1 + i)};
+                            atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
                         }
                     }
                 }
@@ -549,17 +602,6 @@ __device__ __forceinline__ u128 load_win(const u64* __restrict__ row, int w, int
     return (u128)(l >> 61) | ((u128)c << 3) | ((u128)r << 67);
 }
 
-// The ring of closed binaries (`act`, one row per frame, R rows) is SPARSE: k_morph_close stores only the words that
-// have lit pixels, each with the number of the frame it belongs to, and never clears anything.  A reader asks for
-// frame t and treats a word whose tag differs (never written, or left over from frame t - k*R) as zero.
-struct __attribute__((aligned(16))) ActWord {
-    u64 bits;
-    u64 tag;  // frame number t >= 1 (0 = never written)
-};
-__device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw, u64 t) {
-    const ActWord a = row[gw];
-    return a.tag == t ? a.bits : 0ull;
-}
 // load_win on a row of a tagged frame; `row` points at word 0 of image row y
 __device__ __forceinline__ u128 load_win_act(const ActWord* __restrict__ row, int w, int WW, u64 t) {
     const u64 c = act_word(row, w, t);
@@ -640,7 +682,7 @@ __global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict
 }
 
 // One thread owns one listed block (a word column x a band of RB rows) and slides down it with 3-row pipelines.
-__global__ void __launch_bounds__(64) k_morph_close(const u64* __restrict__ bbits, const unsigned* __restrict__ worklist,
+__global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                     const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
                                                     unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
     RAISE_WAVE_PRIORITY();
@@ -653,7 +695,7 @@ __global__ void __launch_bounds__(64) k_morph_close(const u64* __restrict__ bbit
     const int band = tid / g.WW, w = tid - band * g.WW;
     const int y0 = band * MORPH_RB;
     const Win q = make_win(w, g.W);
-    const u64* src = bbits + (size_t)i * g.H * g.WW;
+    const ActWord* src = bbits + (size_t)i * g.H * g.WW;
     const long long t = g.t_base + 1 + i;
     ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
     u128 hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
@@ -665,7 +707,7 @@ __global__ void __launch_bounds__(64) k_morph_close(const u64* __restrict__ bbit
         const int yy = y0 - 3 + it;
         const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
         u128 hC0 = 0, hC1 = 0, mC = 0, dC = 0;
-        const u128 brow = load_win(src + (size_t)yc * g.WW, w, g.WW);
+        const u128 brow = load_win_act(src + (size_t)yc * g.WW, w, g.WW, (u64)t);
         const int ym = yy - 1;  // row whose median is complete now
         const int yd = yy - 2;
         // sparse images: when the new row and the whole pipeline are empty the stencils produce zeros

@@ -31,6 +31,25 @@ __global__ void __launch_bounds__(256) k_read_frames(const uint4* __restrict__ p
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
+// the window kernel's traffic without its arithmetic: the same loads (1 KB per wave per frame, 4 frames per burst, chunks of
+// `tc` frames along blockIdx.y) plus its stores (one u64 per 4 lanes per frame = 128 B per wave per frame)
+__global__ void __launch_bounds__(256) k_read_write_frames(const uint4* __restrict__ p, size_t frame_vec, int frames, int tc,
+                                                           unsigned long long* __restrict__ bits) {
+    const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= frame_vec) return;
+    const int f0 = blockIdx.y * tc, f1 = min(frames, f0 + tc);
+    unsigned acc = 0;
+    for (int f = f0; f + 3 < f1; f += 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = p[(size_t)(f + k) * frame_vec + chunk];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+            if ((threadIdx.x & 3) == 0) bits[(size_t)(f + k) * (frame_vec / 4) + chunk / 4] = acc;
+        }
+    }
+}
 int main() {
     const size_t frame = 1920 * 1080, frames = 1024, bytes = frame * frames, n = bytes / 16;
     uint4* d; unsigned* o;
@@ -47,5 +66,15 @@ int main() {
     hipEventRecord(a); for (int r = 0; r < 5; ++r) k_read_frames<<<(fv + 255) / 256, 256>>>(d, fv, (int)frames, o); hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("frame-strided read (1 KB per wave per frame, 4 frames in flight): %.3f ms/pass  %.2f TB/s\n", ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
+    unsigned long long* bits; hipMalloc(&bits, frames * (fv / 4) * 8);
+    for (int chunks : {1, 3, 8}) {
+        const int tc = (int)((frames + chunks - 1) / chunks);
+        k_read_write_frames<<<dim3((fv + 255) / 256, chunks), 256>>>(d, fv, (int)frames, tc, bits); hipDeviceSynchronize();
+        hipEventRecord(a); for (int r = 0; r < 5; ++r) k_read_write_frames<<<dim3((fv + 255) / 256, chunks), 256>>>(d, fv, (int)frames, tc, bits);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("frame-strided read + bit-plane write, %d chunk(s): %.3f ms/pass  %.2f TB/s read (+ %.0f MB written)\n", chunks, ms / 5,
+               bytes / (ms / 5 * 1e-3) / 1e12, frames * (fv / 4) * 8 / 1e6);
+    }
     return 0;
 }
