@@ -51,7 +51,7 @@ struct ProfSpan {
 };
 
 #define NSLOT_MAX 8  // slots allocated at most; ctx->nslot (default 6, MDH_SLOTS) passes may be in flight
-#define NHSET 2  // Hough buffer / stream sets available; MDH_HOUGH_SETS (default 1) of them are used
+#define NHSET 4  // Hough buffer / stream sets available; MDH_HOUGH_SETS (default 2) of them are used
 #define PACK_HEAD 8  // packed segments per frame (pass average) copied to the host without waiting for the counts
 
 // Everything that crosses the pixel-stage -> Hough boundary or is mirrored to the host, per in-flight pass.

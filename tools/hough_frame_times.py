@@ -7,9 +7,10 @@ import bench
 from metdetpy_amd import M3Detector, _lib
 from metdetpy_amd.synth import SkyStream
 
-H, W, n, B, uniq = 1080, 1920, 8, 1024, 256
+WL = os.environ.get("WL", "C2")
+H, W, n, B, uniq = (1080, 1920, 8, 1024, 256) if WL == "C2" else ((2160, 3840, 16, 256, 128) if WL == "C3" else (4320, 7680, 8, 64, 32))
 mask = np.ones((H, W), np.uint8)
-frames = SkyStream(H, W, bench.WORKLOADS["C2"]["seed"]).take(uniq)
+frames = SkyStream(H, W, bench.WORKLOADS[WL]["seed"]).take(uniq)
 det = M3Detector(1, n, mask, 10, bench.make_cfg(), None, max_batch=B)
 ctx = det._ctx
 pool = ctx.device_alloc(B * H * W)
