@@ -252,8 +252,10 @@ int mdh_collector_update_batch(mdh_collector* c, int K, int64_t frame0, int64_t 
 int mdh_collector_events(mdh_collector* c, mdh_target* out, int cap, double* centers, int cap_centers, int* n_centers);
 int mdh_collector_active(const mdh_collector* c);   /* series currently open (without the reference's sentinel) */
 
-/* Debug: with MDH_HOUGH_DEBUG=1 in the environment at mdh_create, the Hough kernel records 8 cycle counters per frame
- * of the last pass (lit pixels, list build, PPHT total, draws, mask checks, votes, trigger scan, line handling). */
+/* Debug: with MDH_HOUGH_DEBUG=1 in the environment at mdh_create, the Hough kernels record per frame of the last pass 8
+ * stamps (lit pixels, tier / list build, set-up, PPHT total, ...) and 8 phase totals of the four-wave kernel in shader
+ * cycles (draws + conflict scan, list exchange, mask checks, votes, keys + mailbox, trigger handling, line handling, groups).
+ * out: K*8 stamps followed by K*8 phase totals. */
 int mdh_debug_hough(mdh_ctx* ctx, long long* out, int K);
 
 /* Frames consumed so far (SlidingWindow.timer). */

@@ -329,7 +329,7 @@ static int create_impl(mdh_ctx* c) {
     }
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
-    if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 8));
+    if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 16));  // [K][8] stamps, then [K][8] phase cycle totals
     for (int si = 0; si < c->nslot; ++si) {
         Slot& s = c->slot[si];
         {
@@ -815,6 +815,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.serial = c->hough_serial;
     P.no_lds_acc = c->hough_global_acc;
     P.dbg = c->d_hdbg;
+    P.dbg_phase = c->d_hdbg ? c->d_hdbg + (size_t)c->Kmax * 8 : nullptr;
     P.mask_area = c->cfg.mask_area;
     P.dst_bits = sl.d_dst; P.work_bits = hs.d_work; P.rowcount = sl.d_rowcount; P.litcount = sl.d_litcount;
     P.accum = hs.d_accum; P.nz_orig = hs.d_nz_orig; P.nz_work = hs.d_nz_work; P.nz_cap = (long long)c->HW;
@@ -1339,6 +1340,7 @@ extern "C" int mdh_debug_hough(mdh_ctx* c, long long* out, int K) {
     if (!c || !c->d_hdbg || K > c->Kmax) return MDH_E_ARG;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, c->d_hdbg, sizeof(long long) * 8 * K, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out + (size_t)8 * K, c->d_hdbg + (size_t)c->Kmax * 8, sizeof(long long) * 8 * K, hipMemcpyDeviceToHost));
     return MDH_OK;
 }
 

@@ -1034,6 +1034,7 @@ struct HoughParams {
     double* out_gap;       // [K]
     const float* trig;     // [180][2] (cos, sin) as float32 of the float64 value
     long long* dbg;        // optional [K][8] cycle stamps (MDH_HOUGH_DEBUG=1), else null
+    long long* dbg_phase;  // optional [K][8] phase cycle totals of the four-wave kernel
     int list_cap;          // LDS point-list capacity of this launch (dwords)
     int cell_cap;          // LDS accumulator capacity of this launch (16-bit cells, even)
     int tier;              // 0: small-LDS launch, takes the frames that fit it; 1: big-LDS launch, takes the others;
@@ -1330,11 +1331,11 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
             }
             if (mine) list[my_idx] = tail;
             gn = g;
-#pragma unroll
-            for (int k = 0; k < PPHT_G; ++k)
-                if (k == g - 1)
-                    state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), k) << 32) |
-                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, k);
+            {  // the generator state after the g-th draw lives in lane g-1 (g is wave-uniform: one v_readlane pair)
+                const int src = __builtin_amdgcn_readfirstlane(g - 1);
+                state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), src) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, src);
+            }
         }
         count -= gn;
         ++C.groups;
@@ -1590,7 +1591,10 @@ struct Ppht4 {
     int dummy_base;
     unsigned* mbox;      // [0..7] hit masks [parity][wave], [8..11] keys, [12..15] flags
     bool touched_global;
+    bool timing;
+    long long ph[8];     // MDH_HOUGH_DEBUG: cycles per phase (draws, list, mask, votes, keys, trigger, line, groups)
 };
+#define PH_T(C, k, t0) do { if ((C).timing) { const long long t1_ = clock64(); (C).ph[k] += t1_ - (t0); (t0) = t1_; } } while (0)
 
 __device__ __forceinline__ bool work_bit4(const Ppht4& C, int x, int y) {
     return (ld_l2(&C.work[(size_t)y * C.P.WW + (x >> 6)]) >> (x & 63)) & 1;
@@ -1734,6 +1738,8 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
     int count = N;
     unsigned round = 0;
     while (count > 0) {
+        long long tph = C.timing ? clock64() : 0;
+        if (C.timing) C.ph[7] += 1;
         int gn = count < PPHT_G ? count : PPHT_G;
         u64 st = state, my_state = 0;
         unsigned my_rnd = 0;
@@ -1756,6 +1762,7 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
             if (in_grp && j < lane && v == my_idx) lim = lane < lim ? lane : lim;
         }
         const int g = min(gn, (int)row16_min_lane15((unsigned)lim));
+        PH_T(C, 0, tph);
         unsigned my_pt = 0, wr_val = 0;
         int wr_idx = -1;
         if (g == 0) {  // the first draw removes the last element itself: ordinary serial step
@@ -1772,21 +1779,23 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
                 wr_idx = my_idx;
             }
             gn = g;
-#pragma unroll
-            for (int k = 0; k < PPHT_G; ++k)
-                if (k == g - 1)
-                    state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), k) << 32) |
-                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, k);
+            {  // the generator state after the g-th draw lives in lane g-1 (g is wave-uniform: one v_readlane pair)
+                const int src = __builtin_amdgcn_readfirstlane(g - 1);
+                state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), src) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, src);
+            }
         }
         __syncthreads();  // every wave holds the drawn points; the list may change now
         if (C.wave == 0 && wr_idx >= 0) list[wr_idx] = wr_val;
         count -= gn;
         u64 pending = (1ull << gn) - 1;
         const int px = my_pt & 0xFFFF, py = my_pt >> 16;
+        PH_T(C, 1, tph);
         while (true) {
             bool alive = false;
             if ((pending >> lane) & 1) alive = work_bit4(C, px, py);
             const u64 am = __ballot(alive);
+            PH_T(C, 2, tph);
             unsigned hits = 0;
             unsigned keys[PPHT_G];
             if (am) {
@@ -1798,6 +1807,8 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
                         old[k] = vote4(C, pt & 0xFFFF, pt >> 16);
                     }
                 }
+                if (C.timing) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                PH_T(C, 3, tph);
 #pragma unroll
                 for (int k = 0; k < PPHT_G; ++k) {
                     keys[k] = 0;
@@ -1812,6 +1823,7 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
             const unsigned H = C.mbox[(round & 1) * 4] | C.mbox[(round & 1) * 4 + 1] | C.mbox[(round & 1) * 4 + 2] |
                                C.mbox[(round & 1) * 4 + 3];
             ++round;
+            PH_T(C, 4, tph);
             if (!H) break;
             const int trig = __builtin_ctz(H);
             // points after the trigger voted too early: take those votes back, they are re-examined below
@@ -1835,7 +1847,9 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
             if (lane == 0) C.mbox[8 + C.wave] = wmax;
             __syncthreads();
             const unsigned best = max(max(C.mbox[8], C.mbox[9]), max(C.mbox[10], C.mbox[11]));
+            PH_T(C, 5, tph);
             ppht4_line(C, tp & 0xFFFF, tp >> 16, 255 - (int)(best & 0xFF));  // ends with a barrier
+            PH_T(C, 6, tph);
             pending = later;
             if (!pending) break;
         }
@@ -1964,7 +1978,7 @@ __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
         for (int p = tid - 64; p < (cells_used + 1) / 2; p += 192) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
     }
     Ppht4 C{P, wrk, (unsigned*)wrk, P.accum + (size_t)i * NUM_ANGLE * P.numrho, 0.f, 0.f, tid, 0, -1, 0,
-            line_gap, i, 0, lane, wave, lds_cells, P.cell_cap / 2, mbox, false};
+            line_gap, i, 0, lane, wave, lds_cells, P.cell_cap / 2, mbox, false, P.dbg_phase != nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
     if (tid < NUM_ANGLE) {
         C.tc = P.trig[2 * tid];
         C.ts = P.trig[2 * tid + 1];
@@ -1982,6 +1996,8 @@ __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
         long long* d = P.dbg + (size_t)i * 8;
         d[0] = N; d[1] = P.tier; d[2] = w1 - w0; d[3] = wall_clock64() - w1; d[4] = C.found; d[5] = cells_used;
         d[6] = wall_clock64(); d[7] = w0;
+        if (P.dbg_phase)
+            for (int k = 0; k < 8; ++k) P.dbg_phase[(size_t)i * 8 + k] = C.ph[k];
     }
     // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
     const unsigned long long any_global = __ballot(C.touched_global);

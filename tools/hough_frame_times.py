@@ -19,9 +19,10 @@ for start in range(0, B, uniq):
 info = np.zeros(B, _lib.FRAME_INFO_DTYPE)
 for _ in range(3):
     ctx.process_batch_into(pool, B, True, info, None, None, None)
-dbg = np.zeros((B, 8), np.int64)
-rc = ctx.L.mdh_debug_hough(C.c_void_p(ctx.handle), dbg.ctypes.data_as(C.POINTER(C.c_longlong)), B)
+dbg2 = np.zeros((2, B, 8), np.int64)
+rc = ctx.L.mdh_debug_hough(C.c_void_p(ctx.handle), dbg2.ctypes.data_as(C.POINTER(C.c_longlong)), B)
 assert rc == 0
+dbg, ph = dbg2[0], dbg2[1]
 act = dbg[:, 0] > 0
 t = dbg[:, 3] / 100.0  # us
 print("frames with points", int(act.sum()), "of", B, " tiers:", {int(k): int((dbg[act, 1] == k).sum()) for k in np.unique(dbg[act, 1])})
@@ -38,3 +39,10 @@ for lo, hi in ((1, 50), (50, 200), (200, 500), (500, 1000), (1000, 4000), (4000,
     m = act & (dbg[:, 0] >= lo) & (dbg[:, 0] < hi)
     if m.any():
         print("N in [%d,%d): %d frames, mean ppht %.1f us, mean segs %.1f" % (lo, hi, m.sum(), t[m].mean(), dbg[m, 4].mean()))
+
+# phase totals of the four-wave kernel (shader cycles, thread 0's view), summed over the frames with points
+names = ["draws+conflicts", "list exchange", "mask check", "votes", "keys+mailbox", "trigger", "line", "groups"]
+tot = ph[act].sum(axis=0)
+cyc = tot[:7].sum()
+print("phase share of PPHT cycles:", {n: round(float(v) / cyc, 3) for n, v in zip(names[:7], tot[:7])}, " groups per frame: %.1f" % (tot[7] / act.sum()),
+      " points per group: %.2f" % (dbg[act, 0].sum() / max(tot[7], 1)), " cycles per group: %.0f" % (cyc / max(tot[7], 1)))
