@@ -43,14 +43,14 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=2048, help="frames per step (and frames resident in HBM per GPU)")
     ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames generated per GPU; the resident "
                     "batch repeats them (generation is NumPy on the host and would otherwise dominate the run time)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--parity-frames", type=int, default=64, help="frames of the stream compared against the CPU oracle "
+    ap.add_argument("--parity-frames", type=int, default=256, help="frames of the stream compared against the CPU oracle "
                     "after the timed region (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     return ap.parse_args()
@@ -106,7 +106,7 @@ def cpu_baseline(frames, n, mask, seconds):
 def parity_check(frames, n, mask, local, count):
     """Detection parity vs the CPU reference restatement (the metric's second half): a fresh GPU detector and the C
     port of the oracle see the first `count` frames of the stream; thresholds, lit counts, raw Hough segments (in
-    discovery order) and NMS output must be identical."""
+    discovery order) and NMS output must be identical, and so must the records the collector makes of them."""
     from metdetpy_amd import M3Detector
     from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
@@ -116,24 +116,48 @@ def parity_check(frames, n, mask, local, count):
     det.close()
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
     orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY)
-    bad, segs = [], 0
+    bad, segs, o_results = [], 0, []
     for i in range(count):
         orc.update(frames[i])
         o_raw = orc.detect()
+        o_results.append((np.zeros((0, 4), np.int32), np.zeros(0)))
         thr = orc.state()[0]
         ok = (int(info[i]["bi_threshold"]) == thr and int(info[i]["lit_count"]) == orc.lit_count
               and int(info[i]["n_raw"]) == orc.lines_num
               and np.array_equal(raw[i][:min(orc.lines_num, 512)], o_raw[:512]))
-        if ok and 0 < orc.lines_num <= 500:
+        if 0 < orc.lines_num <= 500:
             o_nms, o_prob = co.lineset_nms(o_raw)
+            o_results[i] = (o_nms, o_prob)
             k = int(info[i]["n_nms"])
-            ok = k == len(o_nms) and np.array_equal(nms[i][:k], o_nms) and np.array_equal(prob[i][:k], o_prob)
+            ok = ok and k == len(o_nms) and np.array_equal(nms[i][:k], o_nms) and np.array_equal(prob[i][:k], o_prob)
         segs += orc.lines_num
         if not ok:
             bad.append(i)
-    return {"frames_checked": count, "raw_segments_checked": segs, "mismatching_frames": bad,
-            "verdict": "identical" if not bad else "MISMATCH",
-            "checked": "bi_threshold, lit_count, raw Hough segments (order included), lineset_nms output vs oracle/metdet_oracle.c"}
+    # the records a collector makes of them (config/m3det_normal.json's meteor_cfg, re-check off): GPU results through the
+    # native collector one pass at a time, oracle results through the Python collector frame by frame
+    from metdetpy_amd.collector import MeteorCollector, NativeMeteorCollector
+    from metdetpy_amd.metstruct import CollectorCfg, MeteorCfg, RecheckSwitch, RuntimeParams
+    H, W = mask.shape
+    ccfg = CollectorCfg(MeteorCfg(15, 4, [0, 8], [2, 21], [0, 0.6], 0.5, 2048), RecheckSwitch(False), {})
+    rt = RuntimeParams(fps=float(n), exp_frame=1, eq_fps=float(n), eq_int_fps=n, exp_time=1.0 / n, runtime_size=[W, H],
+                       raw_size=[W, H], positive_category_list=["METEOR", "RED_SPRITE"])
+    gcol, ocol = NativeMeteorCollector(ccfg, rt), MeteorCollector(ccfg, rt)
+    gcol.update_batch(0, 0, info, nms, prob)
+    gcol.clear()
+    for i in range(count):
+        k = len(o_results[i][0])
+        if k or i % rt.eq_int_fps == 0:
+            cates = np.zeros((k, 10))
+            cates[:, -1] = o_results[i][1]
+            cates[:, 0] = 1 - o_results[i][1]
+            ocol.update(i, o_results[i][0], cates)
+    ocol.clear()
+    g_rec, o_rec = [r.to_dict() for r in gcol.met_exporter.meteor_list], [r.to_dict() for r in ocol.met_exporter.meteor_list]
+    rec_ok = g_rec == o_rec
+    return {"frames_checked": count, "raw_segments_checked": segs, "mismatching_frames": bad, "records": len(o_rec),
+            "records_identical": rec_ok, "verdict": "identical" if not bad and rec_ok else "MISMATCH",
+            "checked": "bi_threshold, lit_count, raw Hough segments (order included), lineset_nms output, collector records "
+                       "vs oracle/metdet_oracle.c"}
 
 
 def main():
