@@ -1590,6 +1590,7 @@ struct Ppht4 {
     unsigned* cells;
     int dummy_base;
     unsigned* mbox;      // [0..7] hit masks [parity][wave], [8..11] keys, [12..15] flags
+    unsigned* gbox;      // [0..15] points of the current group, [16] its size (written by wave 0)
     bool touched_global;
     bool timing;
     long long ph[8];     // MDH_HOUGH_DEBUG: cycles per phase (draws, list, mask, votes, keys, trigger, line, groups)
@@ -1737,10 +1738,17 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
     u64 state = 0xFFFFFFFFFFFFFFFFull;
     int count = N;
     unsigned round = 0;
+    // Only wave 0 draws: the visiting order is the same for everybody, and a single wave cannot issue faster than one
+    // instruction per ~5 cycles, so three more copies of the draw / conflict logic were three more waves competing for the
+    // CU's issue slots.  Wave 0 publishes the group (points and size) through LDS; it is also the only one that reads or
+    // writes the point list.
     while (count > 0) {
         long long tph = C.timing ? clock64() : 0;
         if (C.timing) C.ph[7] += 1;
-        int gn = count < PPHT_G ? count : PPHT_G;
+        int gn = 0;
+        unsigned my_pt = 0;
+      if (C.wave == 0) {
+        gn = count < PPHT_G ? count : PPHT_G;
         u64 st = state, my_state = 0;
         unsigned my_rnd = 0;
 #pragma unroll
@@ -1763,7 +1771,7 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
         }
         const int g = min(gn, (int)row16_min_lane15((unsigned)lim));
         PH_T(C, 0, tph);
-        unsigned my_pt = 0, wr_val = 0;
+        unsigned wr_val = 0;
         int wr_idx = -1;
         if (g == 0) {  // the first draw removes the last element itself: ordinary serial step
             state = rng_step(state);
@@ -1785,8 +1793,13 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
                         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, src);
             }
         }
-        __syncthreads();  // every wave holds the drawn points; the list may change now
-        if (C.wave == 0 && wr_idx >= 0) list[wr_idx] = wr_val;
+        if (wr_idx >= 0) list[wr_idx] = wr_val;  // (LDS operations of one wave complete in order: the reads above came first)
+        if (lane < PPHT_G) C.gbox[lane] = my_pt;
+        if (lane == 0) C.gbox[PPHT_G] = (unsigned)gn;
+      }
+        __syncthreads();  // the group is published
+        gn = __builtin_amdgcn_readfirstlane((int)C.gbox[PPHT_G]);
+        if (C.wave != 0) my_pt = C.gbox[lane & (PPHT_G - 1)];
         count -= gn;
         u64 pending = (1ull << gn) - 1;
         const int px = my_pt & 0xFFFF, py = my_pt >> 16;
@@ -1856,8 +1869,8 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
     }
 }
 
-// LDS: [ point list: list_cap | cells: cell_cap/2 | 256 dummy | 16 mailbox | 180*3 window table ]  (dwords)
-#define HOUGH4_EXTRA_DWORDS (256 + 16 + 3 * NUM_ANGLE)
+// LDS: [ point list: list_cap | cells: cell_cap/2 | 256 dummy | 16 mailbox | 180*3 window table | 32 group box ]  (dwords)
+#define HOUGH4_EXTRA_DWORDS (256 + 16 + 3 * NUM_ANGLE + 32)
 __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
     RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
@@ -1978,7 +1991,8 @@ __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
         for (int p = tid - 64; p < (cells_used + 1) / 2; p += 192) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
     }
     Ppht4 C{P, wrk, (unsigned*)wrk, P.accum + (size_t)i * NUM_ANGLE * P.numrho, 0.f, 0.f, tid, 0, -1, 0,
-            line_gap, i, 0, lane, wave, lds_cells, P.cell_cap / 2, mbox, false, P.dbg_phase != nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
+            line_gap, i, 0, lane, wave, lds_cells, P.cell_cap / 2, mbox, (unsigned*)(wtab + 3 * NUM_ANGLE), false, P.dbg_phase != nullptr,
+            {0, 0, 0, 0, 0, 0, 0, 0}};
     if (tid < NUM_ANGLE) {
         C.tc = P.trig[2 * tid];
         C.ts = P.trig[2 * tid + 1];
