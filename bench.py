@@ -166,11 +166,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    tdev = None
     if world > 1:
         import torch
         import torch.distributed as dist
+        # "nccl" is RCCL on ROCm.  MDH_BENCH_BACKEND=gloo (CPU tensors) exists to exercise the multi-rank path on a box with
+        # fewer GPUs than ranks: ranks then share devices round-robin.
+        backend = os.environ.get("MDH_BENCH_BACKEND", "nccl")
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            tdev = torch.device("cuda", local)
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            tdev = torch.device("cpu")
+            dist.init_process_group(backend)
     wl = WORKLOADS[a.workload]
     H, W, n = wl["H"], wl["W"], wl["n"]
     global SENSITIVITY
@@ -242,10 +252,10 @@ def main():
     ctx.profile_enable(False)
     if dist is not None:
         import torch
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_all = float(tmax.item())
-        counts = torch.tensor([segs, kept, lit], device="cuda", dtype=torch.int64)
+        counts = torch.tensor([segs, kept, lit], device=tdev, dtype=torch.int64)
         gathered = [torch.zeros_like(counts) for _ in range(world)]
         dist.all_gather(gathered, counts)  # the final detection gather (RCCL)
         tot = torch.stack(gathered).sum(0).tolist()

@@ -26,6 +26,9 @@ typedef unsigned __int128 u128;
 // critical path would stretch accordingly; at raised wave priority it keeps (almost) its stand-alone latency, and the
 // window kernel only loses the few slots those waves actually use.
 #define RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#ifndef HOUGH_WAVE_PRIO
+#define HOUGH_WAVE_PRIO 3  // A/B builds: -DHOUGH_WAVE_PRIO=0..3
+#endif
 
 struct PassGeom {
     int H, W, WW;       // frame size, words per bit row
@@ -1872,7 +1875,7 @@ __device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
 // LDS: [ point list: list_cap | cells: cell_cap/2 | 256 dummy | 16 mailbox | 180*3 window table | 32 group box ]  (dwords)
 #define HOUGH4_EXTRA_DWORDS (256 + 16 + 3 * NUM_ANGLE + 32)
 __global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
-    RAISE_WAVE_PRIORITY();
+    __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     unsigned* lds_list = lds_dyn;
     unsigned* lds_cells = lds_dyn + P.list_cap;
