@@ -126,7 +126,7 @@ int mdh_device_upload(mdh_ctx* ctx, void* dst_device, const void* src_host, uint
 /* Per-kernel timing with HIP events on the context's own stream (off by default).
  * names: MDH_NUM_KERNELS strings; ms / launches: accumulated since the last reset. */
 #define MDH_NUM_KERNELS 8
-int mdh_profile_enable(mdh_ctx* ctx, int on);
+int mdh_profile_enable(mdh_ctx* ctx, int on);   /* on = N > 0: every N-th pass is timed (1 = all); 0 = off */
 int mdh_profile_read(mdh_ctx* ctx, double* ms, int64_t* launches, int reset);
 const char* mdh_kernel_name(int k);
 

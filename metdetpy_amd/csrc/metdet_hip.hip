@@ -122,7 +122,7 @@ struct mdh_ctx {
     hipEvent_t ev_base = nullptr;  // MDH_HOST_LOG: origin of the GPU-side span times
     unsigned tag_lds = 0;  // MDH_TAG_PASS=1: dynamic LDS bytes that tag a pass's kernels in a rocprofv3 trace (1024 * (1 + pass % 3))
     int nhset = 2;
-    int nmain = 1;  // sets in use: with 2, the Hough stages of consecutive passes overlap (experiment switch MDH_HOUGH_SETS)
+    int nmain = 2;  // main streams in use (MDH_MAIN_STREAMS): with 2, the window kernel of pass p+1 ramps up while that of pass p drains
     int64_t pass_seq = 0;
     hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
     int64_t t = 0;  // frames submitted (SlidingWindow.timer)
@@ -171,7 +171,8 @@ struct mdh_ctx {
     bool hough_global_acc = false;  // MDH_HOUGH_GLOBAL_ACC=1: never use the LDS accumulator windows
     bool hough_one_wave = false;    // MDH_HOUGH_ONE_WAVE=1: one wave per frame instead of a 256-thread workgroup
     // profiling
-    bool prof = false;
+    bool prof = false;         // timing events around the kernels of the pass being queued
+    int prof_every = 0;        // 0: off; N: every N-th pass is timed (mdh_profile_enable)
     std::vector<ProfSpan>* cur_spans = nullptr;
     std::vector<hipEvent_t> ev_pool;  // recycled timing events
     double host_us[6] = {0};  // MDH_HOST_TRACE=1: submit, wait for ev_done, segment copy, nms + unpack, (spare)
@@ -547,6 +548,7 @@ static void spans_collect(mdh_ctx* c, Slot& sl) {
 }
 extern "C" int mdh_profile_enable(mdh_ctx* c, int on) {
     if (!c) return MDH_E_ARG;
+    c->prof_every = on > 0 ? on : 0;
     c->prof = on != 0;
     if (c->prof && g_host_log && !c->ev_base) {
         hipEventCreate(&c->ev_base);
@@ -967,10 +969,11 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     Slot& sl = c->slot[c->next_slot];
     if (sl.busy) { set_err("internal: slot still busy"); return MDH_E_STATE; }
     // the main stream may not overwrite this slot's buffers before the Hough stage that last read them is done
-    // MDH_MAIN_STREAMS=2 (experiment): consecutive passes alternate between two main streams, so the next window kernel
-    // fills the machine while the last workgroups of the previous one drain.  Measured slower: the post stages starve.
+    // Consecutive passes alternate between two main streams, so the next window kernel fills the machine while the last
+    // workgroups of the previous one drain (+4 % once the post stages had streams of their own; MDH_MAIN_STREAMS=1 for A/B).
     c->stream = c->mstream[c->pass_seq % c->nmain];
     if (sl.used) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    c->prof = c->prof_every > 0 && c->pass_seq % c->prof_every == 0;
     sl.K = K;
     sl.t_base = c->t;
     if (getenv("MDH_TAG_PASS")) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
