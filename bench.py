@@ -298,6 +298,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "stack_threshold", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                               "launches_in_flight": 2,  # consecutive passes alternate between two main streams: the durations overlap
+
                                "algorithmic_bytes_per_launch": alg_bytes}
             out["kernels_ms_per_step"] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}  # mean span per timed pass
         if world == 1 and a.cpu_seconds > 0:
