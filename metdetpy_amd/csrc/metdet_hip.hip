@@ -816,8 +816,11 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.fixed_gap = c->cfg.detector == MDH_DET_CLASSIC;
     P.serial = c->hough_serial;
     P.no_lds_acc = c->hough_global_acc;
-    P.dbg = c->d_hdbg;
-    P.dbg_phase = c->d_hdbg ? c->d_hdbg + (size_t)c->Kmax * 8 : nullptr;
+    // MDH_HOUGH_DEBUG_PASS=k: only the k-th pass records (to look at a pass in the middle of a pipelined run)
+    static const long long dbg_pass = getenv("MDH_HOUGH_DEBUG_PASS") ? atoll(getenv("MDH_HOUGH_DEBUG_PASS")) : -1;
+    const bool dbg_on = c->d_hdbg && (dbg_pass < 0 || c->pass_seq == dbg_pass);
+    P.dbg = dbg_on ? c->d_hdbg : nullptr;
+    P.dbg_phase = dbg_on ? c->d_hdbg + (size_t)c->Kmax * 8 : nullptr;
     P.mask_area = c->cfg.mask_area;
     P.dst_bits = sl.d_dst; P.work_bits = hs.d_work; P.rowcount = sl.d_rowcount; P.litcount = sl.d_litcount;
     P.accum = hs.d_accum; P.nz_orig = hs.d_nz_orig; P.nz_work = hs.d_nz_work; P.nz_cap = (long long)c->HW;
