@@ -1238,7 +1238,10 @@ extern "C" int mdh_band_skip(mdh_ctx* c) {
     if (!c->band_slot) { set_err("mdh_band_skip: call mdh_band_noise first"); return MDH_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = *c->band_slot;
-    // the frames are in the window (mdh_band_noise staged and retired them); nothing else happens for this pass
+    // the frames are in the window (mdh_band_noise staged and retired them); nothing else happens for this pass.
+    // k_pass_prepare (queued by mdh_band_noise) has cleared the dst words of the slot's previous pass; the scalar chain that
+    // would reset the slot's list counters does not run, so reset them here.
+    if (sl.d_nzcount) HIPCHK(hipMemsetAsync(sl.d_nzcount, 0, 2 * sizeof(unsigned), c->nstream));
     HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
     HIPCHK(hipEventRecord(sl.ev_done, c->nstream));
     slot_commit(c, sl);

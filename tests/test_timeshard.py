@@ -183,3 +183,37 @@ def test_seek_errors_and_restart():
     with pytest.raises(_lib.MetDetHipError, match="in flight"):
         det._ctx.seek(0)
     det.close()
+
+
+@pytest.mark.gpu
+def test_band_skip_between_real_passes():
+    """A skipped pass in the middle of a stream (its frames enter the window, no pixel stages run) must leave the slots it
+    touches clean: with a fixed threshold, every pass that starts a full pass after a skip equals the context that skipped
+    nothing (the pass right after a skip may differ in its first n-1 frames: the dynamic mask has no binaries for the
+    skipped frames)."""
+    from metdetpy_amd.bands import BandPlan, HipBandEngine
+    H, W, n, B = 128, 192, 4, 8
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case("busy", H, W, n, 14 * B, 9)
+    assert not cfg.binary.adaptive_bi_thre
+    plan = BandPlan(H, W, 1, select_std_roi(mask, cfg.binary.area))
+    full = HipBandEngine(plan, 0, n, cfg, float(mask.sum()), B, 0)
+    part = HipBandEngine(plan, 0, n, cfg, float(mask.sum()), B, 0)
+    skipped = {2, 3, 7, 12}
+    compared = lit = 0
+    for p in range(14):
+        chunk = frames[p * B:(p + 1) * B]
+        tot = full.noise(chunk)
+        planes_f, _ = full.pixels(tot)
+        assert np.array_equal(tot, part.noise(chunk))  # the noise window saw the same frames
+        if p in skipped:
+            part.skip()
+            continue
+        planes_p, _ = part.pixels(tot)
+        if p - 1 not in skipped:
+            assert np.array_equal(planes_f, planes_p), p
+            compared += 1
+            lit += int(np.count_nonzero(planes_f))
+    assert compared >= 6 and lit > 0
+    full.close()
+    part.close()
