@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--parity-frames", type=int, default=256, help="frames of the stream compared against the CPU oracle "
                     "after the timed region (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive rate; "
+                    "never the headline value, see DESIGN.md)")
     return ap.parse_args()
 
 
@@ -200,10 +202,17 @@ def main():
     frames = stream.take(uniq)
     det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=B)
     ctx = det._ctx
-    pool = ctx.device_alloc(B * H * W)
-    for start in range(0, B, uniq):  # resident batch = the unique frames repeated
-        cnt = min(uniq, B - start)
-        ctx.device_upload(pool + start * H * W, frames[:cnt])
+    if a.host_input:
+        import ctypes
+        pool = ctx.host_alloc(B * H * W)
+        for start in range(0, B, uniq):
+            cnt = min(uniq, B - start)
+            ctypes.memmove(pool + start * H * W, frames[:cnt].ctypes.data, cnt * H * W)
+    else:
+        pool = ctx.device_alloc(B * H * W)
+        for start in range(0, B, uniq):  # resident batch = the unique frames repeated
+            cnt = min(uniq, B - start)
+            ctx.device_upload(pool + start * H * W, frames[:cnt])
     info = np.zeros(B, _lib.FRAME_INFO_DTYPE)
     raw = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
     nms = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
@@ -224,7 +233,7 @@ def main():
         for _s in range(nsteps):
             if ctx.in_flight == ctx.max_in_flight:
                 collect()
-            ctx.submit(pool, B, True)
+            ctx.submit(pool, B, not a.host_input)
         while ctx.in_flight:
             collect()
 
@@ -278,7 +287,8 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_{SENSITIVITY} detector cfg, {B} frames/step resident in HBM, "
-                               f"one independent stream per GPU", "frame": [W, H], "window": n, "frames_per_step": B,
+                               f"one independent stream per GPU" + (" -- INPUT FROM PINNED HOST MEMORY (PCIe-inclusive)" if a.host_input else ""),
+                   "frame": [W, H], "window": n, "frames_per_step": B,
                    "parallelism": f"streams x{world}"},
         "detections": {"raw_segments": tot[0], "nms_segments": tot[1], "lit_pixels": tot[2]},
     }
@@ -307,7 +317,7 @@ def main():
         if world == 1 and a.parity_frames > 0:
             out["parity"] = parity_check(frames, n, mask, local, a.parity_frames)
         print(json.dumps(out), flush=True)
-    ctx.device_free(pool)
+    (ctx.host_free if a.host_input else ctx.device_free)(pool)
     det.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -122,6 +122,10 @@ int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, double* non
 void* mdh_device_alloc(mdh_ctx* ctx, uint64_t bytes);
 int mdh_device_free(mdh_ctx* ctx, void* ptr);
 int mdh_device_upload(mdh_ctx* ctx, void* dst_device, const void* src_host, uint64_t bytes);
+/* Pinned host memory for frames handed over with on_device = 0: the H2D copies of a pass then run asynchronously at PCIe
+ * speed (from pageable memory they are staged by the runtime). */
+void* mdh_host_alloc(mdh_ctx* ctx, uint64_t bytes);
+int mdh_host_free(mdh_ctx* ctx, void* ptr);
 
 /* Per-kernel timing with HIP events on the context's own stream (off by default).
  * names: MDH_NUM_KERNELS strings; ms / launches: accumulated since the last reset. */

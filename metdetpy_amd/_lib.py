@@ -61,7 +61,7 @@ EXPORTS = [
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
-    "mdh_collector_active", "mdh_pre_run_batch"
+    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free"
 ]
 
 _lib = None
@@ -98,6 +98,9 @@ def load():
     L.mdh_device_alloc.argtypes = [vp, u64]
     L.mdh_device_alloc.restype = vp
     L.mdh_device_free.argtypes = [vp, vp]
+    L.mdh_host_alloc.argtypes = [vp, u64]
+    L.mdh_host_alloc.restype = vp
+    L.mdh_host_free.argtypes = [vp, vp]
     L.mdh_device_upload.argtypes = [vp, vp, vp, u64]
     L.mdh_profile_enable.argtypes = [vp, i32]
     L.mdh_profile_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
@@ -246,6 +249,16 @@ class Context:
         if not p:
             raise MetDetHipError(f"mdh_device_alloc({nbytes}) failed: {last_error()}")
         return p
+
+    def host_alloc(self, nbytes: int) -> int:
+        """Pinned host memory (for frames submitted with on_device=False); returns the address."""
+        p = self.L.mdh_host_alloc(self.handle, int(nbytes))
+        if not p:
+            raise MetDetHipError(f"mdh_host_alloc({nbytes}) failed: {last_error()}")
+        return p
+
+    def host_free(self, ptr: int):
+        check(self.L.mdh_host_free(self.handle, ptr), "mdh_host_free")
 
     def device_free(self, ptr: int):
         check(self.L.mdh_device_free(self.handle, ptr), "mdh_device_free")

@@ -1369,6 +1369,22 @@ extern "C" int mdh_device_free(mdh_ctx* c, void* p) {
     HIPCHK(hipFree(p));
     return MDH_OK;
 }
+extern "C" void* mdh_host_alloc(mdh_ctx* c, uint64_t bytes) {
+    if (!c) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        set_err("mdh_host_alloc: hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+extern "C" int mdh_host_free(mdh_ctx* c, void* p) {
+    if (!c) return MDH_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipHostFree(p));
+    return MDH_OK;
+}
 extern "C" int mdh_device_upload(mdh_ctx* c, void* dst, const void* src, uint64_t bytes) {
     if (!c || !dst || !src) return MDH_E_ARG;
     HIPCHK(hipSetDevice(c->device));
