@@ -200,7 +200,17 @@ def main():
     stream = SkyStream(H, W, wl["seed"] + rank, mask01=None if mask.all() else mask)
     uniq = min(B, max(a.unique, 2 * n))
     frames = stream.take(uniq)
-    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=B)
+    det = None
+    while det is None:  # the buffers of a 2048-frame pass take ~130 GB at 1080p: halve the pass if the GPU cannot give that
+        try:
+            det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=B)
+        except _lib.MetDetHipError as e:
+            if B <= 64 or "hipMalloc" not in str(e):
+                raise
+            print(f"[bench] {e}; retrying with {B // 2} frames per pass", file=sys.stderr, flush=True)
+            B //= 2
+            uniq = min(uniq, B)
+            frames = frames[:uniq]
     ctx = det._ctx
     if a.host_input:
         import ctypes
