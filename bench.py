@@ -3,17 +3,27 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one native pass (mdh_submit_batch / mdh_collect_batch, several passes in flight) over a batch of `--batch` consecutive frames of a seeded synthetic
-night-sky stream that is already resident in HBM (a pool of `--batch` frames per GPU, cycled): update + detect incl.
-Hough and NMS, results on the host.  N > 1: one process per GPU (torchrun), one independent stream per GPU
-(BASELINE config C4), no data-path collective; RCCL only gathers the per-rank detection counts at the end.
-`value` = frames all ranks processed / max-over-ranks time.
+One "step" = one native pass (mdh_submit_batch / mdh_collect_batch, several passes in flight) over a batch of `--batch`
+consecutive frames of a seeded synthetic night-sky stream that is already resident in HBM: update + detect incl. Hough
+and NMS, results on the host.  N > 1: one process per GPU (torchrun), one independent stream per GPU (BASELINE config
+C4), no data-path collective; the collectives are the barrier around the timed region, the max-over-ranks time and the
+final gather of the detection counts.  `value` = frames all ranks processed / max-over-ranks time.
 
-Also on the JSON line:
-  roofline      dominant pixel kernel (stack_threshold): algorithmic HBM reads per launch ((n+1)*H*W per frame,
-                SURVEY.md 8d) / mean launch duration measured with HIP events on the library's own stream.
-  cpu_baseline  the C port of the CPU oracle (oracle/metdet_oracle.c, OpenMP) timed on this box's host cores over a
-                bounded sample of the same stream (rank 0, N = 1 only).
+The JSON line also carries (rank 0):
+  roofline      the dominant pixel kernel (stack_threshold), priced PHYSICALLY: the bytes one launch must move (every frame
+                byte once + the window carried into the launch + what it stores) over the launch durations measured live
+                with HIP events on the library's own stream -- inside the pipelined timed region (`frac`, what rocprofv3
+                --kernel-trace sees too) and with one pass in flight and nothing overlapping (`frac_standalone`).  SURVEY 8d's
+                "(n+1) reads per pixel" model is kept as `algorithmic_frac`: the kernel is time-blocked (each byte is fetched
+                once per launch, not n times), so that figure exceeds 1 by design and is not a bandwidth.
+  cpu_baseline  the CPU oracle timed on this box's host cores over a bounded sample of the same stream (N = 1 only): the
+                C port (oracle/metdet_oracle.c) at 1 thread and at the OpenMP team sizes tried, and the structure-faithful
+                NumPy oracle on one thread.
+  parity        GPU vs oracle on the first frames of the stream, down to the collector's records.
+
+Other timed entries:  --workload C3|C5|C1s|C1e,  --protocol per-frame (the reference's update()/detect() loop from host
+frames),  --mode bands|timeshard (ONE stream tiled into row bands / cut into time windows; N bands or windows on one
+device when WORLD_SIZE is 1),  --host-input (frames cross PCIe every pass).
 """
 import argparse
 import json
@@ -25,36 +35,45 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the library's streams need their own hardware queues (the HIP default is 4); must be set before HIP / torch start
+# the library's streams want their own hardware queues (the HIP default is 4); read when the HIP runtime starts
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s is what a streaming copy reaches)
 
 WORKLOADS = {
-    # name: (H, W, n, seed, use_mask)
-    "C2": dict(H=1080, W=1920, n=8, seed=20220413, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
-    "C3": dict(H=2160, W=3840, n=16, seed=20220414, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
-    "C1s": dict(H=540, W=960, n=8, seed=20220412, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
-    "C5": dict(H=4320, W=7680, n=8, seed=20220415, sensitivity="high",
+    "C2": dict(H=1080, W=1920, n=8, seed=20220413, batch=2048, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
+    "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=512, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
+    "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2048, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
+    "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=128, sensitivity="high",
                desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
+    "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=256, src=(2160, 3840),
+                desc="config-1 substitute: synthetic 3840x2160x3 BGR clip in HBM -> resize 960x540 + gray + mask-east (loader "
+                     "restatement on the GPU) -> detector -> native collector"),
 }
+STREAK_PERIOD = 50  # SkyStream default: one streak per 50 frames
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=None, help="timed passes (default: enough for >= 2 s, SURVEY 8d)")
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=2048, help="frames per step (and frames resident in HBM per GPU)")
-    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames generated per GPU; the resident "
-                    "batch repeats them (generation is NumPy on the host and would otherwise dominate the run time)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step (and frames resident in HBM per GPU)")
+    ap.add_argument("--unique", type=int, default=250, help="period of the synthetic stream in frames, a multiple of the streak "
+                    "period: the resident batch is frames[i %% unique], so no streak is cut where the stream wraps (0 = every "
+                    "resident frame distinct; generation is NumPy on the host and dominates the start-up time)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--mode", default="streams", choices=["streams", "bands", "timeshard"])
+    ap.add_argument("--protocol", default="batch", choices=["batch", "per-frame"])
+    ap.add_argument("--shards", type=int, default=8, help="--mode bands|timeshard with one process: bands / windows on this device")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--parity-frames", type=int, default=256, help="frames of the stream compared against the CPU oracle "
                     "after the timed region (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive rate; "
-                    "never the headline value, see DESIGN.md)")
+    ap.add_argument("--standalone-passes", type=int, default=12, help="passes run one at a time after the timed region to "
+                    "measure the non-overlapped duration of every kernel (0 = skip)")
+    ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive "
+                    "rate; never the headline value, see DESIGN.md)")
     return ap.parse_args()
 
 
@@ -68,41 +87,65 @@ def make_cfg():
 
 
 def load_mask(H, W):
-    """test/mask-east.jpg binarised by the loader rule (fixture committed as tests/golden/mask_east_*.npy)."""
+    """test/mask-east.jpg binarised by the loader rule (fixture committed as tests/golden/mask_east_*.npz)."""
     path = os.path.join(ROOT, "tests", "golden", f"mask_east_{W}x{H}.npz")
     if os.path.exists(path):
         return np.load(path)["mask"]
     return None
 
 
-def cpu_baseline(frames, n, mask, seconds):
-    """Time the C port of the oracle (update + detect up to raw Hough + NMS) on the host cores."""
-    from oracle import c_oracle as co
-    from metdetpy_amd.utils import select_std_roi
-    roi = select_std_roi(mask, 0.1)
-    # the port scales to ~16 threads on the GPU box's host (83 fps at 1080p; 32 threads are slower: the frame-sized
-    # loops are memory-bound and the PPHT is serial)
-    co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
-    det = co.CM3(n, mask, roi, sensitivity=SENSITIVITY)
-    threads = int(co.lib().om3_num_threads())
-    warm = min(2 * n, len(frames))
+def _time_detector(step, frames, warm, seconds, cap):
     for i in range(warm):
-        det.update(frames[i])
-        det.detect()
+        step(frames[i])
     done, t0 = 0, time.perf_counter()
     while True:
-        f = frames[(warm + done) % len(frames)]
-        det.update(f)
-        raw = det.detect()
-        if 0 < len(raw) <= 500:
-            co.lineset_nms(raw)
+        step(frames[(warm + done) % len(frames)])
         done += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or done >= 4 * len(frames):
-            break
-    return dict(value=done / dt, unit="frames/s", cores=threads, kind="port",
-                sample=f"{done} frames of the same stream after {warm} warm-up frames, oracle/metdet_oracle.c "
-                       f"(gcc -O3 -fopenmp, {threads} threads), host cpu_count={os.cpu_count()}")
+        if dt >= seconds or done >= cap:
+            return done, dt
+
+
+def cpu_baseline(frames, n, mask, seconds):
+    """Time the CPU oracle (update + detect up to raw Hough + NMS) on the host cores: the C port at 1 thread and at larger
+    OpenMP teams (the best is `value`), and the NumPy oracle -- structure-faithful to the reference: ring + np.max, second
+    ring for the dynamic mask -- on one thread."""
+    from oracle import c_oracle as co
+    from oracle import m3_oracle as mo
+    from metdetpy_amd.utils import select_std_roi
+    roi = select_std_roi(mask, 0.1)
+    avail = len(os.sched_getaffinity(0))
+    warm = min(2 * n, len(frames))
+    teams = sorted({1, min(16, avail), min(64, avail)})
+    share = seconds / (len(teams) + 1.5)
+    by_threads = {}
+    for th in teams:
+        co.lib().om3_set_threads(th)
+        det = co.CM3(n, mask, roi, sensitivity=SENSITIVITY)
+
+        def step(f, det=det):
+            det.update(f)
+            raw = det.detect()
+            if 0 < len(raw) <= 500:
+                co.lineset_nms(raw)
+
+        done, dt = _time_detector(step, frames, warm, share, 4 * len(frames))
+        by_threads[int(co.lib().om3_num_threads())] = dict(value=done / dt, frames=done)
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, sensitivity=SENSITIVITY)
+
+    def np_step(f):
+        orc.update(f)
+        orc.detect()
+
+    np_done, np_dt = _time_detector(np_step, frames, min(warm, n), 1.5 * share, 4 * len(frames))
+    best = max(by_threads, key=lambda k: by_threads[k]["value"])
+    return dict(value=by_threads[best]["value"], unit="frames/s", cores=best, kind="port",
+                sample=f"{by_threads[best]['frames']} frames of the same stream after {warm} warm-up frames, oracle/metdet_oracle.c "
+                       f"(gcc -O3 -fopenmp, {best} threads: the best of the teams tried), host cpu_count={os.cpu_count()}",
+                c_port_by_threads={str(k): v["value"] for k, v in by_threads.items()},
+                single_thread={"c_port": by_threads[min(by_threads)]["value"], "numpy_oracle": np_done / np_dt,
+                               "numpy_oracle_sample": f"{np_done} frames, oracle/m3_oracle.py (NumPy stages as the reference's, "
+                                                      "OpenCV-side ops and PPHT from the C port)"})
 
 
 def parity_check(frames, n, mask, local, count):
@@ -136,9 +179,10 @@ def parity_check(frames, n, mask, local, count):
         if not ok:
             bad.append(i)
     # the records a collector makes of them (config/m3det_normal.json's meteor_cfg, re-check off): GPU results through the
-    # native collector one pass at a time, oracle results through the Python collector frame by frame
-    from metdetpy_amd.collector import MeteorCollector, NativeMeteorCollector
+    # native collector one pass at a time, oracle results through the oracle-side Python collector frame by frame
+    from metdetpy_amd.collector import NativeMeteorCollector
     from metdetpy_amd.metstruct import CollectorCfg, MeteorCfg, RecheckSwitch, RuntimeParams
+    from oracle.collector_oracle import MeteorCollector
     H, W = mask.shape
     ccfg = CollectorCfg(MeteorCfg(15, 4, [0, 8], [2, 21], [0, 0.6], 0.5, 2048), RecheckSwitch(False), {})
     rt = RuntimeParams(fps=float(n), exp_frame=1, eq_fps=float(n), eq_int_fps=n, exp_time=1.0 / n, runtime_size=[W, H],
@@ -162,55 +206,123 @@ def parity_check(frames, n, mask, local, count):
                        "vs oracle/metdet_oracle.c"}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    tdev = None
-    if world > 1:
+class Dist:
+    """The three collectives of the timed harness.  torch.distributed is the launcher's own rendezvous (the driver starts
+    the ranks with torch.distributed.run); "nccl" = RCCL on ROCm.  MDH_BENCH_BACKEND=gloo (CPU tensors) exercises the
+    multi-rank path on a box with fewer GPUs than ranks: the ranks then share devices round-robin."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.d = None
+        self.tdev = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            backend = os.environ.get("MDH_BENCH_BACKEND", "nccl")
+            self.local = self.local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(self.local)
+            if backend == "nccl":
+                self.tdev = torch.device("cuda", self.local)
+                dist.init_process_group("nccl", device_id=self.tdev)
+            else:
+                self.tdev = torch.device("cpu")
+                dist.init_process_group(backend)
+            self.d = dist
+
+    def fence(self):
+        # the library has no work in flight between run() calls; the barrier aligns the ranks
+        if self.d is not None:
+            import torch
+            torch.cuda.synchronize()
+            self.d.barrier()
+            torch.cuda.synchronize()
+
+    def max_time_and_sum(self, dt, counts):
+        if self.d is None:
+            return dt, list(counts)
         import torch
-        import torch.distributed as dist
-        # "nccl" is RCCL on ROCm.  MDH_BENCH_BACKEND=gloo (CPU tensors) exists to exercise the multi-rank path on a box with
-        # fewer GPUs than ranks: ranks then share devices round-robin.
-        backend = os.environ.get("MDH_BENCH_BACKEND", "nccl")
-        local = local % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            tdev = torch.device("cuda", local)
-            dist.init_process_group("nccl", device_id=tdev)
-        else:
-            tdev = torch.device("cpu")
-            dist.init_process_group(backend)
-    wl = WORKLOADS[a.workload]
+        tmax = torch.tensor([dt], device=self.tdev, dtype=torch.float64)
+        self.d.all_reduce(tmax, op=self.d.ReduceOp.MAX)
+        c = torch.tensor(list(counts), device=self.tdev, dtype=torch.int64)
+        gathered = [torch.zeros_like(c) for _ in range(self.world)]
+        self.d.all_gather(gathered, c)  # the final detection gather (RCCL)
+        return float(tmax.item()), torch.stack(gathered).sum(0).tolist()
+
+    def close(self):
+        if self.d is not None:
+            self.d.destroy_process_group()
+
+
+def make_stream_frames(wl, rank, mask, B, unique):
+    """The frames one GPU keeps resident: a seeded continuous stream; with unique < B its first `unique` frames, a whole
+    number of streak periods, so that the stream is seamless where the resident batch repeats them."""
+    from metdetpy_amd.synth import SkyStream
     H, W, n = wl["H"], wl["W"], wl["n"]
-    global SENSITIVITY
-    SENSITIVITY = wl.get("sensitivity", "normal")
+    stream = SkyStream(H, W, wl["seed"] + rank, mask01=None if mask.all() else mask)
+    uniq = B if unique <= 0 else min(B, max(unique, 2 * n))
+    if uniq < B:
+        uniq = max(STREAK_PERIOD, uniq // STREAK_PERIOD * STREAK_PERIOD)
+    return stream.take(uniq)
+
+
+def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_step, workload):
+    """Physical roofline of the window kernel.  Bytes one launch MUST move: every frame of the pass once plus the n-1
+    frames of history its window starts from, per time chunk (the kernel is blocked over the frames: grid.y chunks each
+    re-read n-1 frames), plus what it stores (tagged words of the sparse difference image: measured, ~0.6 % of the reads)."""
+    out = {"bound": "hbm", "kernel": "stack_threshold", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    ms, launches = prof_pipe.get("stack_threshold", (0.0, 0))
+    if not launches:
+        return None
+    frame = H * W
+    words = H * ((W + 63) // 64)
+    waves = -(-words // 16) if W % 64 == 0 and n <= 8 else -(-words // 8)
+    nchunks = max(1, min(-(-4096 // waves), B // (2 * n)))
+    tc = -(-B // nchunks)
+    nchunks = -(-B // tc)
+    compulsory = frame * (B + nchunks * (n - 1))
+    avg_ms = ms / launches
+    out.update({
+        "achieved": compulsory / (avg_ms * 1e-3) / 1e9, "frac": compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "launch_ms": avg_ms, "launches": launches, "bytes_per_launch": compulsory, "frames_per_launch": B,
+        "bytes_model": f"H*W*(frames + chunks*(n-1)) = {frame}*({B}+{nchunks}*{n - 1}): each frame byte once per launch plus the "
+                       "window history per time chunk; stores (sparse tagged words) not counted",
+        "launch_ms_note": "mean duration of the window-kernel launches of the timed region (HIP events on the library's main "
+                          "stream, every 4th pass); the launches run inside the pipeline, next to the other stages of the "
+                          "neighbouring passes",
+        "frac_at_pipeline_pace": compulsory / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": (n + 1) * frame * B,
+        "algorithmic_frac": (n + 1) * frame * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_note": "SURVEY 8d's (n+1) reads per pixel per frame; the kernel keeps the window in registers and reads "
+                            "each byte once per launch, so this exceeds 1 by design and is not a bandwidth",
+    })
+    if prof_alone and prof_alone.get("stack_threshold", (0, 0))[1]:
+        a_ms = prof_alone["stack_threshold"][0] / prof_alone["stack_threshold"][1]
+        out["launch_ms_standalone"] = a_ms
+        out["frac_standalone"] = compulsory / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    traffic, src = None, None
+    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    if os.path.exists(tpath):  # rocprofv3 PMC passes of this workload (tools/profile_round.sh), scaled to this batch
+        t = json.load(open(tpath))
+        if t.get("stack_threshold_bytes_per_launch"):
+            traffic = int(t["stack_threshold_bytes_per_launch"] * B / t.get("frames_per_launch", B))
+            src = (f"profiles/pmc_traffic_{workload}.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
+                   f"passes of this command at {t.get('frames_per_launch', B)} frames per launch (tools/profile_round.sh), scaled to "
+                   "this batch -- NOT measured in this run")
+    out["traffic"] = traffic
+    out["traffic_source"] = src
+    return out
+
+
+def run_streams(a, D, wl, mask):
     from metdetpy_amd import M3Detector
     from metdetpy_amd import _lib
-    from metdetpy_amd.synth import SkyStream
-
-    mask = np.ones((H, W), np.uint8)
-    if a.workload == "C3":
-        m = load_mask(H, W)
-        if m is not None:
-            mask = m
+    H, W, n = wl["H"], wl["W"], wl["n"]
     B = a.batch
-    stream = SkyStream(H, W, wl["seed"] + rank, mask01=None if mask.all() else mask)
-    uniq = min(B, max(a.unique, 2 * n))
-    frames = stream.take(uniq)
-    det = None
-    while det is None:  # the buffers of a 2048-frame pass take ~130 GB at 1080p: halve the pass if the GPU cannot give that
-        try:
-            det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=B)
-        except _lib.MetDetHipError as e:
-            if B <= 64 or "hipMalloc" not in str(e):
-                raise
-            print(f"[bench] {e}; retrying with {B // 2} frames per pass", file=sys.stderr, flush=True)
-            B //= 2
-            uniq = min(uniq, B)
-            frames = frames[:uniq]
+    frames = make_stream_frames(wl, D.rank, mask, B, a.unique)
+    uniq = len(frames)
+    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=D.local, max_batch=B)
     ctx = det._ctx
     if a.host_input:
         import ctypes
@@ -220,14 +332,13 @@ def main():
             ctypes.memmove(pool + start * H * W, frames[:cnt].ctypes.data, cnt * H * W)
     else:
         pool = ctx.device_alloc(B * H * W)
-        for start in range(0, B, uniq):  # resident batch = the unique frames repeated
+        for start in range(0, B, uniq):  # resident batch = the stream's period repeated
             cnt = min(uniq, B - start)
             ctx.device_upload(pool + start * H * W, frames[:cnt])
     info = np.zeros(B, _lib.FRAME_INFO_DTYPE)
     raw = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
     nms = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
     prob = np.zeros((B, _lib.MDH_MAX_LINES), np.float64)
-
     tally = [0, 0, 0]
 
     def collect():
@@ -236,101 +347,155 @@ def main():
         tally[1] += int(info["n_nms"].sum())
         tally[2] += int(info["lit_count"].sum())
 
-    def run(nsteps):
+    def run(nsteps, depth=None):
         """nsteps passes, up to ctx.max_in_flight queued: later passes are submitted before earlier ones are collected,
         so the pixel stages of one pass overlap the Hough stage of the previous one and the host stays ahead of the
         GPU.  Every pass is fully collected before run() returns."""
+        depth = depth or ctx.max_in_flight
         for _s in range(nsteps):
-            if ctx.in_flight == ctx.max_in_flight:
+            if ctx.in_flight >= depth:
                 collect()
             ctx.submit(pool, B, not a.host_input)
         while ctx.in_flight:
             collect()
 
-    def fence():
-        # the library has no work in flight between run() calls; the barrier aligns the ranks
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
     if a.warmup:
         run(a.warmup)
+    steps = a.steps
+    if steps is None:  # >= 2 s of timed passes (SURVEY 8d), sized from a short probe
+        t0 = time.perf_counter()
+        run(8)
+        per = (time.perf_counter() - t0) / 8
+        steps = int(min(20000, max(50, 2.4 / max(per, 1e-5))))
     if not a.no_profile:
         ctx.profile_enable(4)  # every 4th pass carries timing events (they cost the pipeline a few per cent when on every pass)
         ctx.profile_read(reset=True)
     tally[:] = [0, 0, 0]
-    fence()
+    D.fence()
     t0 = time.perf_counter()
-    run(a.steps)
-    fence()
+    run(steps)
+    D.fence()
     segs, kept, lit = tally
     dt = time.perf_counter() - t0
     prof = ctx.profile_read(reset=True) if not a.no_profile else {}
     ctx.profile_enable(False)
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([dt], device=tdev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_all = float(tmax.item())
-        counts = torch.tensor([segs, kept, lit], device=tdev, dtype=torch.int64)
-        gathered = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(gathered, counts)  # the final detection gather (RCCL)
-        tot = torch.stack(gathered).sum(0).tolist()
+    prof_alone = {}
+    if not a.no_profile and a.standalone_passes > 0 and D.rank == 0:
+        run(2, depth=1)
+        ctx.profile_enable(1)
+        ctx.profile_read(reset=True)
+        run(a.standalone_passes, depth=1)  # one pass in flight: nothing overlaps, the spans are the kernels' own durations
+        prof_alone = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+    dt_all, tot = D.max_time_and_sum(dt, [segs, kept, lit])
+    res = dict(frames=steps * B * D.world, dt=dt_all, steps=steps, tot=tot, prof=prof, prof_alone=prof_alone, frames_sample=frames,
+               B=B, uniq=uniq)
+    (ctx.host_free if a.host_input else ctx.device_free)(pool)
+    det.close()
+    return res
+
+
+def run_per_frame(a, D, wl, mask):
+    """The reference's own loop (MetDetPy.py:185-202): detector.update(frame); detector.detect() per frame, frames in
+    host memory, results on the host before the next frame is handed over.  One step = one frame."""
+    from metdetpy_amd import M3Detector
+    H, W, n = wl["H"], wl["W"], wl["n"]
+    frames = make_stream_frames(wl, D.rank, mask, 300, a.unique)
+    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=D.local, max_batch=8)
+    tally = [0, 0, 0]
+    k = 0
+
+    def run(nsteps):
+        nonlocal k
+        for _ in range(nsteps):
+            det.update(frames[k % len(frames)])
+            lines, _pred = det.detect()
+            tally[0] += det.lines_num
+            tally[1] += len(lines)
+            k += 1
+
+    run(max(a.warmup, 2 * n))
+    steps = a.steps if a.steps is not None else 20000
+    tally[:] = [0, 0, 0]
+    D.fence()
+    t0 = time.perf_counter()
+    run(steps)
+    D.fence()
+    dt = time.perf_counter() - t0
+    dt_all, tot = D.max_time_and_sum(dt, tally)
+    det.close()
+    return dict(frames=steps * D.world, dt=dt_all, steps=steps, tot=tot, prof={}, prof_alone={}, frames_sample=frames, B=1,
+                uniq=len(frames))
+
+
+def main():
+    a = parse()
+    D = Dist()
+    wl = WORKLOADS[a.workload]
+    H, W, n = wl["H"], wl["W"], wl["n"]
+    global SENSITIVITY
+    SENSITIVITY = wl.get("sensitivity", "normal")
+    if a.batch is None:
+        a.batch = wl["batch"]
+    mask = np.ones((H, W), np.uint8)
+    if a.workload in ("C3", "C1e"):
+        m = load_mask(H, W)
+        if m is not None:
+            mask = m
+    extra = {}
+    if a.workload == "C1e":
+        import bench_modes
+        r = bench_modes.run_c1e(a, D, wl, mask, make_cfg())
+        extra = r.pop("extra", {})
+    elif a.mode != "streams":
+        import bench_modes
+        r = (bench_modes.run_bands if a.mode == "bands" else bench_modes.run_timeshard)(a, D, wl, mask, make_cfg())
+        extra = r.pop("extra", {})
+    elif a.protocol == "per-frame":
+        r = run_per_frame(a, D, wl, mask)
     else:
-        dt_all = dt
-        tot = [segs, kept, lit]
-    frames_total = a.steps * B * world
-    fps = frames_total / dt_all
+        r = run_streams(a, D, wl, mask)
+    fps = r["frames"] / r["dt"]
+    B = r["B"]
+    shape = {"streams": f"one independent stream per GPU, {B} frames/step resident in HBM",
+             "bands": f"ONE stream tiled into row bands, {B} frames/step", "timeshard": f"ONE stream cut into time windows, {B} frames/step"}[a.mode]
+    if a.protocol == "per-frame":
+        shape = "update(frame) / detect() per frame from host memory (the reference's loop), one frame per step"
     out = {
         "metric": "frames/sec at 1920x1080 (1/2/4/8 GPU) + detection parity vs CPU ref",
         "value": fps,
         "unit": "frames/s",
-        "n_gpus": world,
-        "steps": a.steps,
+        "n_gpus": D.world,
+        "steps": r["steps"],
         "warmup": a.warmup,
-        "ms_per_step": dt_all / a.steps * 1e3,
+        "ms_per_step": r["dt"] / r["steps"] * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if a.mode == "streams" else "strong",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_{SENSITIVITY} detector cfg, {B} frames/step resident in HBM, "
-                               f"one independent stream per GPU" + (" -- INPUT FROM PINNED HOST MEMORY (PCIe-inclusive)" if a.host_input else ""),
-                   "frame": [W, H], "window": n, "frames_per_step": B,
-                   "parallelism": f"streams x{world}"},
-        "detections": {"raw_segments": tot[0], "nms_segments": tot[1], "lit_pixels": tot[2]},
+        "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_{SENSITIVITY} detector cfg, {shape}"
+                               + (" -- INPUT FROM PINNED HOST MEMORY (PCIe-inclusive)" if a.host_input else ""),
+                   "frame": [W, H], "window": n, "frames_per_step": B, "stream_period_frames": r["uniq"],
+                   "parallelism": f"{a.mode} x{D.world}" if a.mode != "streams" else f"streams x{D.world}"},
+        "detections": {"raw_segments": r["tot"][0], "nms_segments": r["tot"][1], "lit_pixels": r["tot"][2]},
     }
-    if rank == 0:
-        if prof:
-            ms, launches = prof["stack_threshold"]
-            per_launch_frames = B  # one launch covers the whole pass (max_batch == batch)
-            alg_bytes = (n + 1) * H * W * per_launch_frames
-            avg_s = ms / max(launches, 1) * 1e-3
-            achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.workload}.json")
-            if os.path.exists(tpath):  # rocprofv3 PMC passes of this workload (tools/profile_round.sh), scaled to this batch
-                t = json.load(open(tpath))
-                if t.get("stack_threshold_bytes_per_launch"):
-                    traffic = int(t["stack_threshold_bytes_per_launch"] * B / t.get("frames_per_launch", B))
-            out["roofline"] = {"bound": "hbm", "kernel": "stack_threshold", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-                               "launches_in_flight": 2,  # consecutive passes alternate between two main streams: the durations overlap
-
-                               "algorithmic_bytes_per_launch": alg_bytes}
-            out["kernels_ms_per_step"] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}  # mean span per timed pass
-        if world == 1 and a.cpu_seconds > 0:
+    out.update(extra)
+    if D.rank == 0:
+        if r["prof"]:
+            rf = roofline(r["prof"], r["prof_alone"], H, W, n, B, out["ms_per_step"], a.workload)
+            if rf:
+                out["roofline"] = rf
+            out["kernels_ms_per_step"] = {k: v[0] / v[1] for k, v in r["prof"].items() if v[1]}  # mean span per timed pass
+            if r["prof_alone"]:
+                out["kernels_ms_standalone"] = {k: v[0] / v[1] for k, v in r["prof_alone"].items() if v[1]}
+        frames = r["frames_sample"]
+        if D.world == 1 and a.cpu_seconds > 0 and frames is not None:
             out["cpu_baseline"] = cpu_baseline(frames, n, mask, a.cpu_seconds)
-        if world == 1 and a.parity_frames > 0:
-            out["parity"] = parity_check(frames, n, mask, local, a.parity_frames)
+        if D.world == 1 and a.parity_frames > 0 and frames is not None and "parity" not in out:
+            out["parity"] = parity_check(frames, n, mask, D.local, a.parity_frames)
         print(json.dumps(out), flush=True)
-    (ctx.host_free if a.host_input else ctx.device_free)(pool)
-    det.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

@@ -40,9 +40,11 @@ def main():
             yield stream.next()
 
     t0 = time.perf_counter()
-    records, info = detect_stream(frames(), mask, det_cfg, col_cfg, rt, window_sec=1.0, batch=a.batch, native_collector=True)
+    records, info = detect_stream(frames(), mask, det_cfg, col_cfg, rt, window_sec=1.0, batch=a.batch)
     dt = time.perf_counter() - t0
-    doc = to_mdrf(records, [W, H], rt, desc="synthetic sky, metdetpy_amd")
+    from metdetpy_amd.metstruct import BasicInfo
+    doc = to_mdrf(records, BasicInfo("synthetic", "SkyStream", None, 0, int(a.frames / rt.fps * 1000), [W, H], [W, H], rt.exp_time,
+                                     a.frames, rt.fps, "synthetic sky, metdetpy_amd")).to_dict()
     print(json.dumps(doc, indent=1))
     print(f"{a.frames} frames of {W}x{H} in {dt:.1f} s (frame synthesis on the host included), {len(records)} records, "
           f"{int(info['n_raw'].sum())} raw segments", file=sys.stderr)

@@ -162,6 +162,10 @@ struct mdh_ctx {
     size_t xchg_words = 0;
     // update()/detect() protocol
     bool pending = false;
+    // A pass mutates host-side stream state (EMA schedule, history, ring positions) while it is being queued; if a HIP call
+    // fails half-way the context no longer describes the stream, so it refuses further work instead of producing silently
+    // wrong thresholds / windows.
+    bool poisoned = false;
     int last_slot = -1;        // slot of the most recently collected pass (mdh_get_binary)
     // switches
     bool force_generic = false;     // MDH_FORCE_GENERIC=1: use the n-reads kernel (A/B and parity testing)
@@ -453,9 +457,11 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         set_err("mdh_create: mask_area must be > 0");
         return nullptr;
     }
-    // The context uses up to ten streams that must progress independently; the HIP runtime multiplexes streams onto
+    // The context uses up to ten streams that should progress independently; the HIP runtime multiplexes streams onto
     // GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue serialise behind each other's event
-    // waits.  Only effective if the runtime is not initialised yet (otherwise set it in the environment).
+    // waits.  Correctness never depends on it (every dependency is an explicit event), only overlap does.  The variable is
+    // read when the runtime initialises, so this only takes effect when the library makes the process's first HIP call;
+    // hosts that touch HIP earlier export GPU_MAX_HW_QUEUES=12 themselves (bench.py does).
     setenv("GPU_MAX_HW_QUEUES", "12", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -833,7 +839,11 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     // Hough set before (two passes ago) has released its accumulators / point lists.
     HIPCHK(hipStreamWaitEvent(hstream[0], sl.ev_pix, 0));
     HIPCHK(hipStreamWaitEvent(hstream[1], sl.ev_pix, 0));
-    // (the set's previous user queued its work on these same streams, so its buffers are free by stream order)
+    // The set's previous user queued its LAST work (small-tier launch, packing, result copy) on hstream[0] only, so stream
+    // order frees the set's buffers for hstream[0] but not for hstream[1]: the big / global launches of this pass would
+    // otherwise write work / accumulator / point-list rows that the previous user's small-tier frames are still replaying.
+    if (hs.last_slot >= 0 && hs.last_slot != (int)(&sl - c->slot))
+        HIPCHK(hipStreamWaitEvent(hstream[1], c->slot[hs.last_slot].ev_done, 0));
     span_begin(c, KK_HOUGH, hstream[0]);
     static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr;  // timing experiments only: results are wrong
     if (skip_hough) {
@@ -994,6 +1004,17 @@ static void slot_commit(mdh_ctx* c, Slot& sl) {
     c->in_flight += 1;
 }
 
+static int poison(mdh_ctx* c, int rc) {
+    c->poisoned = true;
+    set_err(g_err + " -- the context's stream state is no longer consistent; destroy it");
+    return rc;
+}
+#define CHECK_POISON(c, who)                                                                             \
+    if ((c)->poisoned) {                                                                                 \
+        set_err(who ": an earlier call failed half-way through a pass; the context must be destroyed");   \
+        return MDH_E_STATE;                                                                              \
+    }
+
 static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
     Slot* sl = nullptr;
     int rc;
@@ -1001,11 +1022,12 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
     host_log("submit begin", c->pass_seq);
     if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
     // staging stream: pointer table (built from the history BEFORE this pass), history copies, noise / thresholds;
-    // main stream: pixel stages once the thresholds are there
-    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return rc;
-    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return rc;
-    if ((rc = run_noise(c, *sl, K)) != MDH_OK) return rc;
-    if ((rc = run_detect(c, *sl, K)) != MDH_OK) return rc;
+    // main stream: pixel stages once the thresholds are there.  stage_frames advances the EMA schedule and retire_frames
+    // the history: a failure from here on leaves the context inconsistent (poisoned).
+    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return poison(c, rc);
+    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return poison(c, rc);
+    if ((rc = run_noise(c, *sl, K)) != MDH_OK) return poison(c, rc);
+    if ((rc = run_detect(c, *sl, K)) != MDH_OK) return poison(c, rc);
     slot_commit(c, *sl);
     c->host_us[0] += now_us() - t0;
     host_log("submit end", c->pass_seq - 1);
@@ -1072,6 +1094,7 @@ extern "C" int mdh_submit_batch(mdh_ctx* c, const uint8_t* frames, int K, int on
     if (!c || !frames) { set_err("mdh_submit_batch: null argument"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_FULL) { set_err("mdh_submit_batch: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
     if (c->pending) { set_err("mdh_submit_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_submit_batch");
     HIPCHK(hipSetDevice(c->device));
     return submit_pass(c, frames, K, on_device);
 }
@@ -1089,13 +1112,14 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if (c->role != MDH_ROLE_FULL) { set_err("mdh_update: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
     if (c->pending) { set_err("mdh_update: previous frame not yet consumed by mdh_detect"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_update: collect the submitted passes first"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_update");
     HIPCHK(hipSetDevice(c->device));
     Slot* sl = nullptr;
     int rc;
     if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
-    if ((rc = stage_frames(c, *sl, frame, 1, 0)) != MDH_OK) return rc;
-    if ((rc = retire_frames(c, *sl, 1, 0)) != MDH_OK) return rc;
-    if ((rc = run_noise(c, *sl, 1)) != MDH_OK) return rc;
+    if ((rc = stage_frames(c, *sl, frame, 1, 0)) != MDH_OK) return poison(c, rc);
+    if ((rc = retire_frames(c, *sl, 1, 0)) != MDH_OK) return poison(c, rc);
+    if ((rc = run_noise(c, *sl, 1)) != MDH_OK) return poison(c, rc);
     // the caller may reuse `frame` after return (the reference copies it, utils.py:280)
     HIPCHK(hipStreamSynchronize(c->nstream));
     c->pending = true;
@@ -1105,13 +1129,14 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
 extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
     if (!c) { set_err("mdh_detect: null context"); return MDH_E_ARG; }
     if (!c->pending) { set_err("mdh_detect: call mdh_update first"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_detect");
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = c->slot[c->next_slot];
     int rc;
     c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr; c->d_bandflag = sl.d_bandflag; c->d_bbits = sl.d_bbits;
     c->h_ptrtab = sl.h_ptrtab;
     c->cur_spans = &sl.spans;
-    if ((rc = run_detect(c, sl, 1)) != MDH_OK) return rc;
+    if ((rc = run_detect(c, sl, 1)) != MDH_OK) return poison(c, rc);
     slot_commit(c, sl);
     c->pending = false;
     return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
@@ -1123,6 +1148,7 @@ extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int o
     if (c->role != MDH_ROLE_FULL) { set_err("mdh_process_batch: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
     if (c->pending) { set_err("mdh_process_batch: a frame from mdh_update is still pending"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_process_batch: collect the submitted passes first"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_process_batch");
     HIPCHK(hipSetDevice(c->device));
     // chunks of at most max_batch frames, up to nslot in flight: later chunks are queued before chunk j is collected
     int submitted = 0, collected = 0;
@@ -1159,13 +1185,14 @@ extern "C" int mdh_band_noise(mdh_ctx* c, const uint8_t* frames, int K, int on_d
     if (!c || !frames || !sums || !n_jobs) { set_err("mdh_band_noise: null argument"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_noise: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
     if (c->band_slot) { set_err("mdh_band_noise: the previous pass still waits for mdh_band_pixels"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_band_noise");
     HIPCHK(hipSetDevice(c->device));
     Slot* sl = nullptr;
     int rc, nj = 0;
     if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
-    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return rc;
-    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return rc;
-    if ((rc = noise_prepare(c, *sl, K, &nj)) != MDH_OK) return rc;
+    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return poison(c, rc);
+    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return poison(c, rc);
+    if ((rc = noise_prepare(c, *sl, K, &nj)) != MDH_OK) return poison(c, rc);
     if (nj) HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof(long long) * 2 * nj, hipMemcpyDeviceToHost, c->nstream));
     HIPCHK(hipStreamSynchronize(c->nstream));
     c->band_slot = sl;

@@ -81,9 +81,10 @@ class LineDetector(BaseDetector):
         self.stack_maxsize = int(window_sec * fps)
         if not 1 <= self.stack_maxsize <= _lib.MDH_MAX_WINDOW:
             raise ValueError(f"window of {self.stack_maxsize} frames unsupported (1..{_lib.MDH_MAX_WINDOW})")
-        if self.bi_cfg.sensitivity not in _lib.SENSITIVITY_ID:
-            raise KeyError(self.bi_cfg.sensitivity)
         if self.bi_cfg.adaptive_bi_thre:
+            # the reference reads the sensitivity only in the adaptive case (Detector.py:204-209)
+            if self.bi_cfg.sensitivity not in _lib.SENSITIVITY_ID:
+                raise KeyError(self.bi_cfg.sensitivity)
             self.std2thre = self.sensitivity_func[self.bi_cfg.sensitivity]
             self.bi_threshold = self.abs_sensitivity[self.bi_cfg.sensitivity]
         else:
@@ -97,7 +98,7 @@ class LineDetector(BaseDetector):
         c.detector = self._native_kind
         c.adaptive_bi_thre = int(bool(self.bi_cfg.adaptive_bi_thre))
         c.init_value = int(self.bi_cfg.init_value)
-        c.sensitivity = _lib.SENSITIVITY_ID[self.bi_cfg.sensitivity]
+        c.sensitivity = _lib.SENSITIVITY_ID.get(self.bi_cfg.sensitivity, _lib.SENSITIVITY_ID["normal"])
         c.interval = int(self.bi_cfg.interval)
         for k in range(4):
             c.roi[k] = int(std_roi[k])
@@ -215,6 +216,8 @@ class ClassicDetector(LineDetector):
 
     def _package(self, info, raw):
         n_raw = int(info["n_raw"])
+        if n_raw > _lib.MDH_MAX_LINES:  # the library keeps MDH_MAX_LINES segments per frame; never hand back a truncated set
+            raise RuntimeError("ClassicDetector: more than MDH_MAX_LINES segments in one frame")
         lines = raw[:n_raw] if n_raw else []
         cls_pred = np.zeros((n_raw, self.num_cls))
         cls_pred[:, 0] = 1
@@ -226,8 +229,6 @@ class ClassicDetector(LineDetector):
         info, raw, _, _ = self._ctx.detect()
         self._pending = False
         self._absorb_info(info)
-        if int(info["n_raw"]) > _lib.MDH_MAX_LINES:
-            raise RuntimeError("ClassicDetector: more than MDH_MAX_LINES segments in one frame")
         self.linesp_ext, cls_pred = self._package(info, raw)
         return self.linesp_ext, cls_pred
 

@@ -151,9 +151,30 @@ class MeteorCfg(DictAble):
 
 
 @dataclasses.dataclass
+class ModelCfg(DictAble):
+    """recheck_cfg.model as the presets carry it (metstruct.py:342-353).  Carried through to the MDRF document only: the YOLO
+    re-check itself is outside this path."""
+    name: str
+    weight_path: str
+    dtype: str
+    nms: bool
+    warmup: bool
+    pos_thre: float
+    nms_thre: float
+    multiscale_pred: int
+    multiscale_partition: int
+    providers_key: Optional[str] = "default"
+
+
+@dataclasses.dataclass
 class RecheckSwitch(DictAble):
-    """Only the switch of recheck_cfg is honoured: the YOLO recheck is outside this path (SURVEY 2 #9)."""
+    """recheck_cfg (metstruct.py:408-411).  Only the switch is honoured (and must be off): the YOLO recheck is outside this
+    path (SURVEY 2 #9); `model` is kept so that a preset survives a round trip into the MDRF document."""
     switch: bool = False
+    model: Optional[ModelCfg] = None
+
+
+RecheckCfg = RecheckSwitch
 
 
 @dataclasses.dataclass
@@ -161,6 +182,44 @@ class CollectorCfg(DictAble):
     meteor_cfg: MeteorCfg
     recheck_cfg: RecheckSwitch = dataclasses.field(default_factory=RecheckSwitch)
     positive_cfg: dict = dataclasses.field(default_factory=dict)
+
+
+@dataclasses.dataclass
+class LoaderCfg(DictAble):
+    """metstruct.py:329-339 (the loader itself is outside this path; the block travels into the MDRF document)."""
+    name: str
+    wrapper: str
+    resize: Union[list, int, str]
+    exp_time: Union[float, str]
+    merge_func: str
+    grayscale: bool
+    upper_bound: Optional[float] = None
+    continue_on_err: bool = False
+    hwaccel: Optional[str] = None
+
+
+@dataclasses.dataclass
+class MainDetectCfg(DictAble):
+    """A whole preset file, config/m3det_*.json (metstruct.py:421-425); keys the schema does not declare are dropped."""
+    loader: LoaderCfg
+    detector: DetectorCfg
+    collector: CollectorCfg
+
+
+@dataclasses.dataclass
+class BasicInfo(DictAble):
+    """metstruct.py:127-139."""
+    loader: str
+    video: str
+    mask: Optional[str]
+    start_time: int
+    end_time: int
+    resolution: list
+    runtime_resolution: list
+    exp_time: float
+    total_frames: int
+    fps: float
+    desc: Optional[str] = None
 
 
 @dataclasses.dataclass
@@ -210,3 +269,17 @@ class SingleMDRecord(DictAble):
         return cls(start_frame=min(t.start_frame for t in targets), start_time=min(t.start_time for t in targets),
                    end_time=max(t.last_activate_time for t in targets),
                    end_frame=max(t.last_activate_frame for t in targets), video_size=video_size, target=targets)
+
+
+@dataclasses.dataclass
+class MDRF(DictAble):
+    """The Meteor Detection Recording Format document `detect_video` returns and `MetDetPy.py` writes with
+    `json.dump(result.to_dict(), ...)` (metstruct.py:428-441, MetDetPy.py:245-250, 395-398)."""
+    version: str
+    basic_info: BasicInfo
+    config: Optional[MainDetectCfg]
+    type: str
+    anno_size: Optional[list]
+    results: list
+    performance: Optional[dict] = None
+

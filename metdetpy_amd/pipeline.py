@@ -8,22 +8,23 @@ from typing import Iterable, Optional
 
 import numpy as np
 
-from .collector import MeteorCollector, NativeMeteorCollector
+from .collector import MeteorCollector
 from .detector import M3Detector
-from .metstruct import BinaryCfg, CollectorCfg, RuntimeParams
+from .metstruct import MDRF, BasicInfo, BinaryCfg, CollectorCfg, MainDetectCfg, RuntimeParams
 from .utils import VERSION, get_num_class
 
 
 def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: BinaryCfg, collector_cfg: CollectorCfg,
                   rt: RuntimeParams, *, window_sec: float = 1.0, batch: int = 64, device: int = 0, logger=None,
-                  detector_cls=M3Detector, start_frame: int = 0, native_collector: bool = False):
+                  detector_cls=M3Detector, start_frame: int = 0, collector_cls=MeteorCollector):
     """Feed `frames` (each (H,W) uint8, one per exposure frame) through the detector and the collector exactly in the
     order the reference's loop does: collector.update(i, lines, cates) when the frame has lines, or on every
     eq_int_fps-th iteration (MetDetPy.py:200-202); collector.clear() at the end (MetDetPy.py:237).
-    With native_collector=True the result arrays of a pass go to the native collector in one call (same records; the
-    per-frame Python bookkeeping is what limits the loop otherwise).  Returns (records, per_frame_info)."""
+    The result arrays of a pass go to the (native) collector in one call.  `collector_cls` exists for the tests, which run their
+    Python restatement of the reference's collector through the same loop frame by frame.  Returns (records, per_frame_info)."""
     det = detector_cls(window_sec, rt.eq_fps, mask, get_num_class(), detector_cfg, logger, device=device, max_batch=batch)
-    col = (NativeMeteorCollector if native_collector else MeteorCollector)(collector_cfg, rt, None, logger)
+    col = collector_cls(collector_cfg, rt, None, logger)
+    native_collector = hasattr(col, "update_batch")
     infos = []
     it = 0
     buf = []
@@ -58,12 +59,11 @@ def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: 
     return col.met_exporter.meteor_list, (np.concatenate(infos) if infos else np.zeros(0))
 
 
-def to_mdrf(records, video_size, rt: RuntimeParams, desc: Optional[str] = None) -> dict:
-    """The `results` part of an MDRF document (metstruct.py:428-441) as plain dicts."""
-    return {"version": VERSION, "type": "prediction", "anno_size": list(video_size),
-            "basic_info": {"resolution": list(rt.raw_size), "runtime_resolution": list(rt.runtime_size), "fps": rt.fps,
-                           "exp_time": rt.exp_time, "desc": desc},
-            "results": [r.to_dict() for r in records]}
+def to_mdrf(records, basic_info: BasicInfo, cfg: Optional[MainDetectCfg] = None) -> MDRF:
+    """What `detect_video` returns (MetDetPy.py:245-250): `to_mdrf(...).to_dict()` is the document MetDetPy.py:395-398 writes,
+    key for key (version / basic_info / config / type / anno_size / results / performance)."""
+    return MDRF(version=VERSION, basic_info=basic_info, config=cfg, type="prediction", anno_size=basic_info.resolution,
+                results=list(records))
 
 
 def calculate_time_iou(a, b) -> float:

@@ -92,9 +92,9 @@ class TimeShard:
         self.rank, self.world, self.B = int(rank), int(world), int(max_batch)
         n = self.s.n
         self.start, self.end = chunk_bounds(self.total, self.world)[self.rank]
+        # The warm-up may reach into earlier ranks' chunks (the frames are only read), so a chunk may be shorter than the
+        # warm-up itself: every rank derives the same bounds from (total, world) and none can fail alone before a collective.
         self.warm = max(0, self.start - 2 * (n - 1))
-        if self.world > 1 and self.end - self.start < 2 * (n - 1) and self.end > self.start:
-            raise ValueError("chunks shorter than 2(n-1) frames: use fewer ranks for this stream")
         self.engine = engine(self.s.plan, 0, n, cfg, self.s.mask_area, self.B, device)
 
     def _chain(self):

@@ -7,7 +7,8 @@ import numpy as np
 
 from . import _lib
 
-VERSION = "V2.4.0-mi355x"
+VERSION = "V2.4.0"  # the MDRF / config format version this build is interchangeable with (utils.py:20)
+BUILD = "mi355x"
 PI = np.pi / 180.0
 
 # global/class_name.txt of the reference plus the two generated labels.  NOTE the reference's inconsistency

@@ -18,6 +18,9 @@ Fixtures
   g7_ema.json             EMA.update series                                             (utils.py:324-368)
   g8_exposure.json        rf_estimator / _rf_est_kernel / sigma_clip / init_exp_time on scripted frame-sum series
                           (videoloader.py:440-494, 796-870; utils.py:516-540)
+  g10_mdrf.json           the MDRF document detect_video returns (MetDetPy.py:245-250) as MDRF.to_dict() writes it
+                          (metstruct.py:105-111, 428-441): version / basic_info / config / type / anno_size / results /
+                          performance, for the reference's config/m3det_*.json presets and two scripted collector runs
 """
 import json
 import os
@@ -288,6 +291,53 @@ def main():
     g5.append({"name": "fourteen_lines_per_frame", "preset": "normal", "rt": rt25.__dict__, "total": 300,
                "script": [[fr, ln, ct] for fr, ln, ct in many], "records": recs, "log": rows})
     json.dump(g5, open(os.path.join(HERE, "g5_collector.json"), "w"))
+
+    # ---------------------------------------------------------------- G10: the MDRF envelope
+    import dataclasses
+    import typing
+
+    def build(tp, value):
+        # what dacite.from_dict does for these dataclasses (dacite itself is absent from this image): nested dataclasses by
+        # field, keys the dataclass does not declare are dropped
+        if dataclasses.is_dataclass(tp) and isinstance(value, dict):
+            hints = typing.get_type_hints(tp)
+            return tp(**{f.name: build(hints[f.name], value[f.name]) for f in dataclasses.fields(tp) if f.name in value})
+        if typing.get_origin(tp) is typing.Union:
+            for arg in typing.get_args(tp):
+                if dataclasses.is_dataclass(arg) and isinstance(value, dict):
+                    try:
+                        return build(arg, value)
+                    except TypeError:
+                        continue
+        return value
+
+    g10 = []
+    for preset, script_name in (("normal", "two_simultaneous"), ("high", "exp3_streak"), ("low", "low_preset")):
+        cfg_dict = json.load(open(os.path.join(REF, "config", f"m3det_{preset}.json"), encoding="utf-8"))
+        cfg = build(MS.MainDetectCfg, cfg_dict)
+        p_, rt, sc, total = scripts[script_name]
+        merged = {}
+        for fr, ln, ct in sc:
+            merged[fr] = (merged[fr][0] + ln, merged[fr][1] + ct) if fr in merged else (ln, ct)
+        sc = [(fr, ln, ct) for fr, (ln, ct) in sorted(merged.items())]
+        log = CaptureLog()
+        col = CO.MeteorCollector(collector_cfg(p_), rt, None, log)
+        by_frame = {fr: (ln, ct) for fr, ln, ct in sc}
+        for i in range(0, total, rt.exp_frame):
+            if i in by_frame:
+                col.update(i, lines=np.array(by_frame[i][0], dtype=np.int32).reshape(-1, 4), cates=np.array(by_frame[i][1], dtype=np.float64))
+            elif (i // rt.exp_frame) % rt.eq_int_fps == 0:
+                col.update(i, lines=[], cates=[])
+        col.clear()
+        info = MS.BasicInfo(loader=cfg.loader.name, video="synthetic.mp4", mask="mask-east.jpg" if preset != "low" else None,
+                            start_time=0, end_time=int(total / rt.fps * 1000), resolution=list(rt.raw_size),
+                            runtime_resolution=list(rt.runtime_size), exp_time=rt.exp_time, total_frames=total, fps=rt.fps,
+                            desc=None if preset == "normal" else f"{preset} preset")
+        doc = MS.MDRF(version=U.VERSION, basic_info=info, config=cfg, type="prediction", anno_size=info.resolution,
+                      results=col.met_exporter.meteor_list)
+        g10.append({"preset": preset, "script": script_name, "config_json": cfg_dict, "basic_info": info.to_dict(),
+                    "mdrf": doc.to_dict()})
+    json.dump(g10, open(os.path.join(HERE, "g10_mdrf.json"), "w"))
 
     # ---------------------------------------------------------------- G6
     g6 = {"frame2ts": [[f, fps, U.frame2ts(f, fps)] for f in (0, 1, 24, 25, 1499, 90000, 65536)

@@ -1,0 +1,136 @@
+"""BASELINE.json configs 3, 4 and 5 at their FULL sizes, HIP path (through the C-ABI) against the C port of the oracle.
+
+  config 3   3840x2160, 16-frame window, mask = test/mask-east.jpg binarised by the loader rule (fixture), m3det_normal
+  config 5   7680x4320, m3det_high thresholds: whole frame on one GPU, and tiled into 8 row bands (on one device here;
+             one band per GPU in production) against the whole-frame detector
+  config 4   `bench.py --gpus 2` launched the way the driver launches it (torch.distributed.run, one rank per GPU; two
+             ranks share the one GPU of the test box over gloo)
+
+Bar: bit-exact thresholds, lit counts, raw Hough segments in discovery order, lineset_nms output and probabilities.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from metdetpy_amd import M3Detector
+from metdetpy_amd.synth import SkyStream
+from metdetpy_amd.utils import select_std_roi
+from oracle import c_oracle as co
+from tests.helpers import binary_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def oracle_threads():
+    """The full-size frames want the whole OpenMP team of the C oracle (the small-frame tests cap it at 8)."""
+    co.lib().om3_set_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    yield
+    co.lib().om3_set_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
+
+
+def cm3_reference(frames, n, mask, sensitivity):
+    """[(thr, lit, n_raw, raw, nms, prob)] per frame from oracle/metdet_oracle.c."""
+    orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=sensitivity)
+    out = []
+    for f in frames:
+        orc.update(f)
+        raw = orc.detect()
+        nms, prob = (np.zeros((0, 4), np.int32), np.zeros(0))
+        if 0 < orc.lines_num <= 500:
+            nms, prob = co.lineset_nms(raw)
+        out.append((orc.state()[0], orc.lit_count, orc.lines_num, raw, nms, prob, orc.gap))
+    return out
+
+
+def assert_pass_equals(want, info, raw, nms, prob, base=0):
+    for i in range(len(info)):
+        thr, lit, n_raw, o_raw, o_nms, o_prob, gap = want[base + i]
+        t = base + i
+        assert int(info[i]["bi_threshold"]) == thr, f"frame {t}: threshold"
+        assert int(info[i]["lit_count"]) == lit, f"frame {t}: lit count"
+        assert float(info[i]["hough_gap"]) == gap, f"frame {t}: maxLineGap"
+        assert int(info[i]["n_raw"]) == n_raw, f"frame {t}: raw segment count {int(info[i]['n_raw'])} != {n_raw}"
+        assert np.array_equal(raw[i][:min(n_raw, 512)], o_raw[:512]), f"frame {t}: raw segments / discovery order"
+        k = int(info[i]["n_nms"])
+        assert k == len(o_nms), f"frame {t}: NMS count"
+        assert np.array_equal(nms[i][:k], o_nms) and np.array_equal(prob[i][:k], o_prob), f"frame {t}: NMS output"
+
+
+def test_config3_4k_window16_mask_east(golden_dir, oracle_threads):
+    """BASELINE config 3 at full size: 40 frames (2n warm-up + 8), two passes of 20 in flight."""
+    H, W, n = 2160, 3840, 16
+    mask = np.load(os.path.join(golden_dir, f"mask_east_{W}x{H}.npz"))["mask"]
+    assert mask.shape == (H, W) and 0 < mask.sum() < H * W
+    frames = SkyStream(H, W, 20220414, mask01=mask).take(40)
+    want = cm3_reference(frames, n, mask, "normal")
+    assert sum(w[2] for w in want) > 0 and max(w[1] for w in want) > 500, "the stream must exercise the Hough stage"
+    det = M3Detector(1, n, mask, 10, binary_cfg("normal"), None, max_batch=20)
+    assert tuple(det.stack.std_roi) == tuple(select_std_roi(mask, 0.1))
+    info, raw, nms, prob = det._ctx.process_batch(frames)
+    assert_pass_equals(want, info, raw, nms, prob)
+    det.close()
+
+
+def test_config5_8k_whole_frame_and_8_row_bands(oracle_threads):
+    """BASELINE config 5's frame (7680x4320, m3det_high): the whole frame on one GPU against the oracle, then the same
+    stream as 8 row bands (+ 4-row halos, noise-sum reduction, bit-plane exchange, Hough on the assembled planes)
+    against the whole-frame detector, field by field."""
+    from metdetpy_amd.bands import LocalBands
+    H, W, n, K = 4320, 7680, 8, 12
+    mask = np.ones((H, W), np.uint8)
+    frames = SkyStream(H, W, 20220415).take(K)
+    want = cm3_reference(frames, n, mask, "high")
+    assert sum(w[2] for w in want) > 0
+    cfg = binary_cfg("high")
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=K)
+    info, raw, nms, prob = det._ctx.process_batch(frames)
+    assert_pass_equals(want, info, raw, nms, prob)
+    wres, winfo = [], info
+    for i in range(K):
+        wres.append(det._package(info[i], raw[i], nms[i], prob[i])[1:])
+    dst_whole = det._ctx.get_binary(K - 1, 0)
+    det.close()
+    lb = LocalBands(1, n, mask, 10, cfg, 8, max_batch=K)
+    assert lb.s.plan.band_rows == 540
+    res, binfo = lb.detect_batch(frames)
+    for i in range(K):
+        assert np.array_equal(np.asarray(res[i][0]).reshape(-1, 4), np.asarray(wres[i][0]).reshape(-1, 4)), i
+        assert np.array_equal(res[i][1], wres[i][1]), i
+        for f in ("n_raw", "n_nms", "lit_count", "bi_threshold", "bi_threshold_float", "snr", "sigma", "dst_sum", "hough_gap"):
+            assert binfo[i][f] == winfo[i][f], (i, f, binfo[i][f], winfo[i][f])
+    for b, e in enumerate(lb.engines):  # the owned rows of every band's last binary are the whole frame's
+        d = lb.s.plan.bands[b]
+        sub = e.band.get_binary(-1, 0)
+        assert np.array_equal(sub[d["own0"] - d["sub0"]:d["own1"] - d["sub0"]], dst_whole[d["own0"]:d["own1"]]), b
+    lb.close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_config4_bench_two_ranks_as_the_driver_launches_it():
+    """`bench.py --gpus 2` under torch.distributed.run: barrier + max-over-ranks timing, the final gather of the
+    detection counts, ONE JSON line from rank 0 with n_gpus = 2 and the whole-job rate."""
+    env = dict(os.environ, MDH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch", "128", "--unique", "64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 6 * 128 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d, "the CPU baseline is timed at N = 1 only"
+    assert d["detections"]["raw_segments"] > 0 and d["config"]["parallelism"] == "streams x2"

@@ -4,8 +4,9 @@ records identical field for field, and the injected streaks are found under the 
 import numpy as np
 import pytest
 
-from metdetpy_amd.collector import MeteorCollector
+from oracle.collector_oracle import MeteorCollector
 from metdetpy_amd.metstruct import Box, CollectorCfg, MDTarget, MeteorCfg, RecheckSwitch, RuntimeParams
+from metdetpy_amd.metstruct import BasicInfo
 from metdetpy_amd.pipeline import calculate_area_iou, calculate_time_iou, detect_stream, to_mdrf
 from metdetpy_amd.synth import SkyStream
 from metdetpy_amd.utils import get_num_class
@@ -48,9 +49,11 @@ def test_stream_records_equal_oracle_pipeline_and_find_the_streaks():
     want = [r.to_dict() for r in col.met_exporter.meteor_list]
     got = [r.to_dict() for r in records]
     assert got == want
-    assert to_mdrf(records, [W * 2, H * 2], rt)["results"] == want
-    # the native collector fed one pass at a time gives the same records
-    records_n, info_n = detect_stream(frames, mask, cfg, ccfg, rt, batch=64, native_collector=True)
+    info_blk = BasicInfo("synthetic", "sky", None, 0, int(len(frames) / fps * 1000), [W * 2, H * 2], [W, H], rt.exp_time, len(frames), fps)
+    doc = to_mdrf(records, info_blk).to_dict()
+    assert doc["results"] == want and doc["anno_size"] == [W * 2, H * 2] and doc["type"] == "prediction"
+    # the oracle-side Python collector driven frame by frame through the same loop gives the same records
+    records_n, info_n = detect_stream(frames, mask, cfg, ccfg, rt, batch=64, collector_cls=MeteorCollector)
     assert [r.to_dict() for r in records_n] == want and np.array_equal(info_n["n_raw"], info["n_raw"])
     # every injected streak is matched by a positive record (evaluate.py rule)
     targets = [t for r in records for t in r.target if t.category == "METEOR" and t.score > 0.5]

@@ -10,7 +10,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from metdetpy_amd import _lib
-from metdetpy_amd.collector import MeteorCollector, NativeMeteorCollector
+from metdetpy_amd.collector import NativeMeteorCollector
+from oracle.collector_oracle import MeteorCollector
 from metdetpy_amd.metstruct import CollectorCfg, MeteorCfg, RecheckSwitch, RuntimeParams
 
 
