@@ -83,7 +83,7 @@ def test_config5_8k_whole_frame_and_8_row_bands(oracle_threads):
     stream as 8 row bands (+ 4-row halos, noise-sum reduction, bit-plane exchange, Hough on the assembled planes)
     against the whole-frame detector, field by field."""
     from metdetpy_amd.bands import LocalBands
-    H, W, n, K = 4320, 7680, 8, 12
+    H, W, n, K = 4320, 7680, 8, 16
     mask = np.ones((H, W), np.uint8)
     frames = SkyStream(H, W, 20220415).take(K)
     want = cm3_reference(frames, n, mask, "high")

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--batch", "128",
-                          "--cpu-seconds", "1", "--parity-frames", "48"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-seconds", "2", "--parity-frames", "48"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -27,7 +27,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches"] >= 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    # physical pricing: the bytes a launch must move (each frame byte once + the carried window) over the measured duration
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    assert 128 * 1080 * 1920 <= r["bytes_per_launch"] <= 1.5 * 128 * 1080 * 1920 and 0 < r["frac"] < 1
+    assert 0 < r["frac_standalone"] < 1 and r["launch_ms_standalone"] > 0 and 0 < r["frac_at_pipeline_pace"] < 1
+    assert r["algorithmic_bytes_per_launch"] == 9 * 128 * 1080 * 1920 and r["algorithmic_frac"] > r["frac"]
+    assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"] or r["traffic_source"] == "live"
+    assert set(d["kernels_ms_standalone"]) >= {"stack_threshold", "hough_ppht"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert c["single_thread"]["c_port"] > 0 and c["single_thread"]["numpy_oracle"] > 0 and "1" in c["c_port_by_threads"]
     assert d["parity"]["verdict"] == "identical" and d["parity"]["frames_checked"] == 48
