@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -100,11 +101,15 @@ struct Slot {
 // Hough-private buffers and streams.  Consecutive passes alternate between the sets, so the (latency-bound) Hough stage of
 // one pass overlaps the next pass's instead of queueing behind it.
 struct HoughSet {
-    hipStream_t stream[2] = {nullptr, nullptr};  // [0] small-LDS launch + result copies, [1] big-LDS launch
-    hipEvent_t ev_big = nullptr;
+    hipStream_t stream[2] = {nullptr, nullptr};  // [0] routing + small-LDS launch + result copies, [1] the other launches
+    hipEvent_t ev_big = nullptr, ev_cls = nullptr;
+    // Pooled buffers of the frames that cannot live in LDS alone (hybrid accumulator / mask: `pool` slots; global point lists
+    // of the one-wave kernel: `pool_list` slots).  A workgroup keeps one slot and walks through its share of the frames.
+    int pool = 0, pool_list = 0;
     u64* d_work = nullptr;
     int* d_accum = nullptr;
     unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
+    int *d_tier_list = nullptr, *d_tier_count = nullptr;  // [HOUGH_TIERS][Kmax], [HOUGH_TIERS]: frame routing of the pass in the set
     int last_slot = -1;  // slot of the pass that used the set last
 };
 
@@ -132,7 +137,10 @@ struct mdh_ctx {
     double coef_a = 0, coef_b = 0;
     int numrho = 0;
     // device buffers used on the main stream only
-    uint8_t* d_ring = nullptr;
+    uint8_t* d_ring = nullptr;   // frames that arrive from the HOST: R slots by frame number, allocated at the first such pass
+    uint8_t* d_hist = nullptr;   // frames submitted in device memory: only the window history (the last n-1 of a pass) is kept,
+    int R_hist = 0;              //   (nslot+1)(n-1) slots handed out by a running counter (see retire_frames)
+    int64_t hist_pos = 0;
     uint8_t* d_zero = nullptr;
     // aliases of the slot being queued (set by slot_begin)
     const uint8_t** d_ptrtab = nullptr;
@@ -147,6 +155,8 @@ struct mdh_ctx {
     ActWord* d_act = nullptr;  // [R][H][WW] tagged sparse ring of closed binaries
     int prev_slot = -1;        // slot of the pass submitted before the one being queued
     float* d_trig = nullptr;
+    const unsigned short* d_perm = nullptr;  // PPHT visiting-order tables (shared by every context on the device)
+    int lds_small = 80 * 1024, lds_large = 160 * 1024;  // dynamic LDS of the two three-wave PPHT launches (MDH_HOUGH_LDS_SMALL / _LARGE)
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     uint8_t* d_expand = nullptr;
     Slot slot[NSLOT_MAX];
@@ -228,7 +238,7 @@ static void free_all(mdh_ctx* c) {
                 c->host_us[3] / c->host_n);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* dev[] = {c->d_ring, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg};
+    void* dev[] = {c->d_ring, c->d_hist, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg};
     for (void* p : dev)
         if (p) hipFree(p);
     for (Slot& s : c->slot) {
@@ -250,10 +260,11 @@ static void free_all(mdh_ctx* c) {
     }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     for (HoughSet& h : c->hset) {
-        void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work};
+        void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work, h.d_tier_list, h.d_tier_count};
         for (void* p : hdev)
             if (p) hipFree(p);
         if (h.ev_big) hipEventDestroy(h.ev_big);
+        if (h.ev_cls) hipEventDestroy(h.ev_cls);
         for (hipStream_t q : h.stream)
             if (q) hipStreamDestroy(q);
     }
@@ -261,6 +272,36 @@ static void free_all(mdh_ctx* c) {
     for (hipStream_t q : st)
         if (q) hipStreamDestroy(q);
     delete c;
+}
+
+// PPHT visiting-order tables (k_perm_build): a pure function of cv::RNG's fixed seed, built once per device and process
+// (67 MB for lists of up to HOUGH_MAX_LIST points) and shared by every context.
+static std::mutex g_perm_mutex;
+static unsigned short* g_perm[64] = {nullptr};
+static int perm_table(int device, const unsigned short** out) {
+    std::lock_guard<std::mutex> lock(g_perm_mutex);
+    if (device < 0 || device >= 64) { set_err("perm_table: device index out of range"); return MDH_E_ARG; }
+    if (!g_perm[device]) {
+        const int n_max = HOUGH_MAX_LIST;
+        std::vector<unsigned> rnd(n_max);
+        uint64_t st = 0xFFFFFFFFFFFFFFFFull;  // cv::RNG rng((uint64)-1), hough.cpp
+        for (int k = 0; k < n_max; ++k) {
+            st = (uint64_t)(unsigned)st * 4164903690ull + (st >> 32);  // RNG::next(): multiply-with-carry
+            rnd[k] = (unsigned)st;
+        }
+        unsigned* d_rnd = nullptr;
+        unsigned short* d_perm = nullptr;
+        HIPCHK(hipMalloc((void**)&d_rnd, sizeof(unsigned) * n_max));
+        HIPCHK(hipMalloc((void**)&d_perm, sizeof(unsigned short) * ((size_t)n_max * (n_max + 1) / 2)));
+        HIPCHK(hipMemcpy(d_rnd, rnd.data(), sizeof(unsigned) * n_max, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_perm_build, dim3(n_max), dim3(64), 0, 0, d_rnd, d_perm, n_max);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(d_rnd));
+        g_perm[device] = d_perm;
+    }
+    *out = g_perm[device];
+    return MDH_OK;
 }
 
 static int create_impl(mdh_ctx* c) {
@@ -312,6 +353,7 @@ static int create_impl(mdh_ctx* c) {
         HIPCHK(make_stream(&h.stream[0], "MDH_PRIO_HOUGH"));
         HIPCHK(make_stream(&h.stream[1], "MDH_PRIO_HOUGH"));
         HIPCHK(hipEventCreateWithFlags(&h.ev_big, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h.ev_cls, hipEventDisableTiming));
     }
     const size_t K = c->Kmax, HW = c->HW, words = c->words;
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
@@ -320,18 +362,24 @@ static int create_impl(mdh_ctx* c) {
     // roles (row-band tiling): a BAND context runs no Hough stage, a HOUGH context no pixel stages
     const bool pix = c->role != MDH_ROLE_HOUGH, hough = c->role != MDH_ROLE_BAND;
     if (pix) {
-        TRY(dev_alloc(c->d_ring, (size_t)c->R * HW));
+        c->R_hist = (c->nslot + 1) * (c->n - 1);
+        if (c->R_hist) TRY(dev_alloc(c->d_hist, (size_t)c->R_hist * HW, false));
         TRY(dev_alloc(c->d_zero, HW));
         if (c->cfg.detector == MDH_DET_M3) TRY(dev_alloc(c->d_act, (size_t)c->R * words));
     }
     TRY(dev_alloc(c->d_state, 1));
     for (int hi = 0; hi < c->nhset && hough; ++hi) {
         HoughSet& h = c->hset[hi];
-        TRY(dev_alloc(h.d_work, K * words));
-        TRY(dev_alloc(h.d_accum, K * (size_t)NUM_ANGLE * c->numrho));
-        TRY(dev_alloc(h.d_nz_orig, K * HW, false));
-        TRY(dev_alloc(h.d_nz_work, K * HW, false));
+        h.pool = (int)std::min<size_t>(K, 64);
+        h.pool_list = (int)std::min<size_t>(K, 16);
+        TRY(dev_alloc(h.d_work, (size_t)h.pool * words));
+        TRY(dev_alloc(h.d_accum, (size_t)h.pool * NUM_ANGLE * c->numrho));
+        TRY(dev_alloc(h.d_nz_orig, (size_t)h.pool_list * HW, false));
+        TRY(dev_alloc(h.d_nz_work, (size_t)h.pool_list * HW, false));
+        TRY(dev_alloc(h.d_tier_list, (size_t)HOUGH_TIERS * K));
+        TRY(dev_alloc(h.d_tier_count, HOUGH_TIERS));
     }
+    if (hough) TRY(perm_table(c->device, &c->d_perm));
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 16));  // [K][8] stamps, then [K][8] phase cycle totals
@@ -390,9 +438,9 @@ static int create_impl(mdh_ctx* c) {
     }
 #undef TRY
     HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (8192 + 61440 / 2 + 64) * (int)sizeof(unsigned)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht4, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (8192 + 61440 / 2 + HOUGH4_EXTRA_DWORDS) * (int)sizeof(unsigned)));
+                               (HOUGH_MAX_LIST + 61440 / 2 + 64) * (int)sizeof(unsigned)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough3, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough3_hybrid, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
     const float theta = (float)(3.14159265358979323846 / 180.0);
@@ -495,6 +543,8 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->hough_global_acc = env_on("MDH_HOUGH_GLOBAL_ACC");
     c->hough_one_wave = env_on("MDH_HOUGH_ONE_WAVE") || c->hough_serial;
     if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
+    if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
+    if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
 
     if (create_impl(c) != MDH_OK) {
@@ -587,6 +637,7 @@ static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
 // Stage K frames (absolute timers t_base+1 .. t_base+K): build the pointer table [hist (n-1) | pass frames (K)].
 static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int on_device) {
     const int64_t t_base = sl.t_base;
+    if (!on_device && !c->d_ring) HIPCHK(hipMalloc((void**)&c->d_ring, (size_t)c->R * c->HW));  // first pass from host memory
     c->h_ptrtab = sl.h_ptrtab;
     for (int e = 0; e < c->n - 1; ++e) c->h_ptrtab[e] = c->hist[e];
     for (int i = 0; i < K; ++i) {
@@ -675,10 +726,13 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
     if (c->W % 64 != 0 || c->force_bytes) align = 1;
     for (int e = 0; e < c->n - 1 + g.K && align > 1; ++e)
         while (align > 1 && ((uintptr_t)c->h_ptrtab[e] & (align - 1))) align >>= 1;
-    if (align >= 16 && g.n >= 2 && g.n <= 8 && !c->force_ppl8) {
+    // 16 pixels per lane up to n = 16 (252 VGPRs at n = 16: still two waves per SIMD; 4K / n = 16: 1.35 -> 0.92 ms per 512 frames)
+    static const int wide16_max_n = getenv("MDH_WIDE16_MAXN") ? atoi(getenv("MDH_WIDE16_MAXN")) : 16;  // A/B switch
+    if (align >= 16 && g.n >= 2 && g.n <= std::min(16, wide16_max_n) && !c->force_ppl8) {
         switch (g.n) {
 #define W16_CASE(N) case N: launch_wide<N, 16>(c, g); return;
             W16_CASE(2) W16_CASE(3) W16_CASE(4) W16_CASE(5) W16_CASE(6) W16_CASE(7) W16_CASE(8)
+            W16_CASE(9) W16_CASE(10) W16_CASE(11) W16_CASE(12) W16_CASE(13) W16_CASE(14) W16_CASE(15) W16_CASE(16)
 #undef W16_CASE
         }
     }
@@ -814,7 +868,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
 static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
     hipStream_t* hstream = hs.stream;
-    HoughParams P;
+    HoughParams P{};
     P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
     P.threshold = c->cfg.hough_threshold;
     P.line_length = c->cfg.hough_min_len;  // cvRound(int) == int
@@ -832,42 +886,45 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.accum = hs.d_accum; P.nz_orig = hs.d_nz_orig; P.nz_work = hs.d_nz_work; P.nz_cap = (long long)c->HW;
     P.out_lines = sl.d_lines; P.out_nraw = sl.d_nraw; P.out_gap = sl.d_gap; P.trig = c->d_trig;
     P.bbox = sl.d_bbox;
-    P.big_list = 8192;
-    // Hough: a small-LDS launch (2 frames per CU) takes the frames whose point list and accumulator windows fit it, a
-    // big-LDS launch (1 frame per CU) takes the rest; both evaluate the same fit test from the lit count and bounding
-    // box, so they run side by side.  They start once this pass's pixel stages are done and the pass that used this
-    // Hough set before (two passes ago) has released its accumulators / point lists.
+    P.tier_list = hs.d_tier_list; P.tier_count = hs.d_tier_count; P.K = K;
+    P.lds_small = c->lds_small; P.lds_large = c->lds_large;
+    P.all_one_wave = c->hough_one_wave;
+    P.perm = c->d_perm;
+    P.list_cap = HOUGH_MAX_LIST; P.cell_cap = 61440;  // the one-wave kernel's LDS
+    // Routing first (k_hough_classify: adaptive gap, and which launch replays each frame), then the launches side by side:
+    // the small-LDS three-wave launch on stream [0]; the large-LDS launch, the hybrid launch (pooled global accumulator) and
+    // the one-wave launch (global point lists) on stream [1].  Every launch walks a device-built frame list, so an empty tier
+    // costs a launch of workgroups that leave at once.  The set's previous user queued its work on these same streams and
+    // stream [0] waited for its stream [1] before packing, so the pooled buffers and the lists are free by stream order.
     HIPCHK(hipStreamWaitEvent(hstream[0], sl.ev_pix, 0));
-    HIPCHK(hipStreamWaitEvent(hstream[1], sl.ev_pix, 0));
-    // The set's previous user queued its LAST work (small-tier launch, packing, result copy) on hstream[0] only, so stream
-    // order frees the set's buffers for hstream[0] but not for hstream[1]: the big / global launches of this pass would
-    // otherwise write work / accumulator / point-list rows that the previous user's small-tier frames are still replaying.
-    if (hs.last_slot >= 0 && hs.last_slot != (int)(&sl - c->slot))
-        HIPCHK(hipStreamWaitEvent(hstream[1], c->slot[hs.last_slot].ev_done, 0));
     span_begin(c, KK_HOUGH, hstream[0]);
     static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr;  // timing experiments only: results are wrong
     if (skip_hough) {
         HIPCHK(hipMemsetAsync(sl.d_nraw, 0, sizeof(int) * K, hstream[0]));
-        HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
-    } else if (c->hough_one_wave) {
-        P.small_list = 4096; P.small_cells = 32000;
-        P.tier = 1; P.list_cap = 8192; P.cell_cap = 61440;
-        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), hstream[1], P);
-        HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
-        P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
-        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned), hstream[0], P);
+        HIPCHK(hipEventRecord(hs.ev_big, hstream[0]));
     } else {
-        // four waves per frame; frames with more than big_list lit pixels go to the one-wave kernel's global-list path
-        P.small_list = 4096; P.small_cells = 31000;
-        P.tier = 1; P.list_cap = P.big_list; P.cell_cap = 61440;
-        hipLaunchKernelGGL(k_hough_ppht4, dim3(K), dim3(256), (P.list_cap + P.cell_cap / 2 + HOUGH4_EXTRA_DWORDS) * sizeof(unsigned),
+        HIPCHK(hipMemsetAsync(hs.d_tier_count, 0, sizeof(int) * HOUGH_TIERS, hstream[0]));
+        hipLaunchKernelGGL(k_hough_classify, dim3((K + 3) / 4), dim3(256), 0, hstream[0], P);
+        HIPCHK(hipEventRecord(hs.ev_cls, hstream[0]));
+        HIPCHK(hipStreamWaitEvent(hstream[1], hs.ev_cls, 0));
+        const int Kmax = c->Kmax;
+        auto tier = [&](int t) {
+            P.flist = hs.d_tier_list + (size_t)t * K;
+            P.fcount = hs.d_tier_count + t;
+        };
+        tier(1);
+        P.lds_bytes = c->lds_large;
+        hipLaunchKernelGGL(k_hough3, dim3(K), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        tier(2);
+        hipLaunchKernelGGL(k_hough3_hybrid, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        tier(3);
+        hipLaunchKernelGGL(k_hough_ppht, dim3(std::min(K, hs.pool_list)), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned),
                            hstream[1], P);
-        P.tier = 2; P.list_cap = 0; P.cell_cap = 0;  // global point list, global accumulator, 64 dummy dwords of LDS
-        hipLaunchKernelGGL(k_hough_ppht, dim3(K), dim3(64), (64 + 64) * sizeof(unsigned), hstream[1], P);
         HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
-        P.tier = 0; P.list_cap = P.small_list; P.cell_cap = P.small_cells;
-        hipLaunchKernelGGL(k_hough_ppht4, dim3(K), dim3(256), (P.list_cap + P.cell_cap / 2 + HOUGH4_EXTRA_DWORDS) * sizeof(unsigned),
-                           hstream[0], P);
+        tier(0);
+        P.lds_bytes = c->lds_small;
+        hipLaunchKernelGGL(k_hough3, dim3(K), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[0], P);
+        (void)Kmax;
     }
     HIPCHK(hipStreamWaitEvent(hstream[0], hs.ev_big, 0));
     span_end(c, hstream[0]);
@@ -891,43 +948,39 @@ static int run_detect(mdh_ctx* c, Slot& sl, int K) {
     return rc != MDH_OK ? rc : run_hough(c, sl, K);
 }
 
-// After a pass is queued: remember where the last n-1 frames live (copying caller-owned device frames into the ring).
+// After a pass is queued: remember where the last n-1 frames live.  Frames that came from the host already sit in the ring
+// (slot = frame number mod R).  Frames the caller owns in device memory are copied -- only the ones the next passes' windows
+// reach back to -- into the history buffer: slots are handed out by a running counter, and (nslot+1)(n-1) of them are enough,
+// because a frame leaves the history after n-1 newer copies and the nslot(n-1) copies that follow before its slot comes up
+// again take at least nslot passes, by which time every pass that could still read it has been collected.
 static int retire_frames(mdh_ctx* c, Slot& sl, int K, int on_device) {
     const int64_t t_base = sl.t_base;
     const int keep = c->n - 1;
     std::vector<const uint8_t*> nh(keep);
-    int run_i = -1, run_len = 0;  // pending run of pass frames to copy (contiguous in the caller's buffer and in the ring)
-    auto flush = [&]() -> int {
-        if (run_len > 0) {
-            uint8_t* rs = c->d_ring + (size_t)((t_base + run_i) % c->R) * c->HW;
-            HIPCHK(hipMemcpyAsync(rs, sl.h_ptrtab[keep + run_i], (size_t)run_len * c->HW, hipMemcpyDeviceToDevice, c->nstream));
-        }
-        run_len = 0;
-        return MDH_OK;
-    };
     for (int e = 0; e < keep; ++e) {
         // entry e of the new history = table entry K + e of this pass
         const int src = K + e;
         if (src < keep) {
             nh[e] = c->hist[src];
+        } else if (!on_device) {
+            nh[e] = c->d_ring + (size_t)((t_base + (src - keep)) % c->R) * c->HW;
         } else {
-            const int i = src - keep;
-            const int64_t ring_slot = (t_base + i) % c->R;
-            nh[e] = c->d_ring + (size_t)ring_slot * c->HW;
-            if (on_device) {
-                if (run_len > 0 && i == run_i + run_len && ring_slot != 0) {
-                    ++run_len;
-                } else {
-                    int rc = flush();
-                    if (rc != MDH_OK) return rc;
-                    run_i = i;
-                    run_len = 1;
-                }
-            }
+            nh[e] = nullptr;  // filled below
         }
     }
-    int rc = flush();
-    if (rc != MDH_OK) return rc;
+    if (on_device && keep > 0) {
+        const int first = std::max(0, K - keep);  // first pass frame that stays in the history
+        int i = first;
+        while (i < K) {  // contiguous in the caller's buffer; split where the history buffer wraps
+            const int64_t hs = c->hist_pos % c->R_hist;
+            const int run = (int)std::min<int64_t>(K - i, c->R_hist - hs);
+            HIPCHK(hipMemcpyAsync(c->d_hist + (size_t)hs * c->HW, sl.h_ptrtab[keep + i], (size_t)run * c->HW, hipMemcpyDeviceToDevice,
+                                  c->nstream));
+            for (int k = 0; k < run; ++k) nh[keep - (K - (i + k))] = c->d_hist + (size_t)(hs + k) * c->HW;
+            c->hist_pos += run;
+            i += run;
+        }
+    }
     c->hist.swap(nh);
     return MDH_OK;
 }

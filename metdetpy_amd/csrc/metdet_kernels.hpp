@@ -1025,12 +1025,12 @@ struct HoughParams {
     int no_lds_acc;        // 1 = keep the whole accumulator in global memory (A/B and parity testing)
     double mask_area;
     const u64* dst_bits;   // [K][H][WW] pristine
-    u64* work_bits;        // [K][H][WW] consumed
+    u64* work_bits;        // [slots][H][WW] working mask of the frames that cannot keep it in LDS (all-zero between frames)
     const int* rowcount;   // [K][H]
     const int* litcount;   // [K]
-    int* accum;            // [K][180*numrho], zero on entry and on exit
-    unsigned* nz_orig;     // [K][nz_cap] row-major list (kept for the clean-up)
-    unsigned* nz_work;     // [K][nz_cap] working list when it does not fit in LDS
+    int* accum;            // [slots][180*numrho], zero between frames
+    unsigned* nz_orig;     // [slots][nz_cap] row-major list (one-wave kernel; kept for the clean-up)
+    unsigned* nz_work;     // [slots][nz_cap] working list when it does not fit in LDS
     long long nz_cap;
     int* out_lines;        // [K][MAX_LINES][4]
     int* out_nraw;         // [K]
@@ -1038,12 +1038,18 @@ struct HoughParams {
     const float* trig;     // [180][2] (cos, sin) as float32 of the float64 value
     long long* dbg;        // optional [K][8] cycle stamps (MDH_HOUGH_DEBUG=1), else null
     long long* dbg_phase;  // optional [K][8] phase cycle totals of the four-wave kernel
-    int list_cap;          // LDS point-list capacity of this launch (dwords)
-    int cell_cap;          // LDS accumulator capacity of this launch (16-bit cells, even)
-    int tier;              // 0: small-LDS launch, takes the frames that fit it; 1: big-LDS launch, takes the others;
-                           // 2 (one-wave kernel only): just the frames with more points than big_list; -1: all
-    int small_list, small_cells;  // capacities of the small-LDS launch (the tier decision both launches make)
-    int big_list;          // point-list capacity of the big-LDS launch; frames beyond it use the one-wave global-list path
+    int list_cap;          // one-wave kernel: LDS point-list capacity (dwords)
+    int cell_cap;          // one-wave kernel: LDS accumulator capacity (16-bit cells, even)
+    // frame routing (k_hough_classify): every launch walks the frame list of its tier
+    const int* flist;      // frames of this launch's tier
+    const int* fcount;     // their number
+    int* tier_list;        // [HOUGH_TIERS][K] lists being built by the classifier
+    int* tier_count;       // [HOUGH_TIERS]
+    int K;                 // frames in the pass
+    int lds_small, lds_large;  // dynamic LDS bytes of the two three-wave launches (the classifier's fit test)
+    int all_one_wave;      // MDH_HOUGH_ONE_WAVE / MDH_HOUGH_SERIAL: every frame goes to the one-wave kernel
+    int lds_bytes;         // dynamic LDS bytes of this launch
+    const unsigned short* perm;  // visiting-order tables: the table of an N-point frame starts at N(N-1)/2
     const int* bbox;       // [K][4] {W-1 - min x, max x, H-1 - min y, max y} of the lit pixels
 };
 
@@ -1399,30 +1405,16 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
     }
 }
 
-__global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
-    RAISE_WAVE_PRIORITY();
+// One frame: `i` indexes the pass's per-frame arrays (planes, counts, results), `slot` the pooled global buffers (accumulator,
+// working mask, point lists) -- a workgroup keeps its slot for every frame it walks through.
+__device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsigned* lds_dyn) {
     // dynamic LDS: [ point list: list_cap dwords | accumulator cells: cell_cap/2 dwords | 64 dummy dwords ]
-    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     unsigned* lds_list = lds_dyn;
     unsigned* lds_cells = lds_dyn + P.list_cap;
-    const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = P.litcount[i];
     const long long c0 = P.dbg ? clock64() : 0;
-    // maxLineGap (Detector.py:342-344) -> cvRound
-    double gap = P.max_gap;
-    if (!P.fixed_gap) {
-        const double dst_sum = (double)N / P.mask_area * 100;
-        double gg = 1 - dst_sum / 0.05;
-        if (gg < 0) gg = 0;
-        gap = gg * P.max_gap;
-    }
-    const int line_gap = (int)rint(gap);
-    if (lane == 0) P.out_gap[i] = gap;
-    if (N == 0) {
-        if (lane == 0 && P.tier <= 0) P.out_nraw[i] = 0;
-        return;
-    }
+    const int line_gap = (int)rint(P.out_gap[i]);  // maxLineGap (k_hough_classify) -> cvRound
     // Accumulator windows: rho is monotone in x and in y for a fixed angle (rounded float products and sum), so over
     // the bounding box of the lit pixels its extremes are at the corners.  Window sizes decide which launch owns
     // the frame (both launches evaluate the same test) and whether the accumulator lives in LDS at all.
@@ -1443,12 +1435,6 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
             cells_needed += w_size[q];
         }
         for (int o = 32; o > 0; o >>= 1) cells_needed += __shfl_xor(cells_needed, o);
-    }
-    if (P.tier == 2) {
-        if (N <= P.big_list) return;  // handled by the four-wave launches
-    } else if (P.tier >= 0) {
-        const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
-        if ((P.tier == 0) != fits_small) return;  // the other launch owns this frame
     }
     // Which windows live in LDS: all of them if they fit; otherwise the smallest ones (the angles across the streak,
     // where the votes pile up), found by bisecting the size limit; the remaining angles use the global accumulator.
@@ -1483,8 +1469,8 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     }
     const size_t words = (size_t)P.H * P.WW;
     const u64* dst = P.dst_bits + (size_t)i * words;
-    u64* wrk = P.work_bits + (size_t)i * words;
-    unsigned* nzo = P.nz_orig + (size_t)i * P.nz_cap;
+    u64* wrk = P.work_bits + (size_t)slot * words;
+    unsigned* nzo = P.nz_orig + (size_t)slot * P.nz_cap;
     // row-major list of set pixels: wave scan over the per-row counts, rows emit their own bits
     int total = 0;
     for (int yb = 0; yb < P.H; yb += 64) {
@@ -1512,8 +1498,8 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     __threadfence_block();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long c1 = P.dbg ? clock64() : 0;
-    Ppht C{P, P.work_bits + (size_t)i * words, (unsigned*)(P.work_bits + (size_t)i * words),
-           P.accum + (size_t)i * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0, 0, 0, 0, 0, 0, P.dbg != nullptr,
+    Ppht C{P, wrk, (unsigned*)wrk,
+           P.accum + (size_t)slot * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0, 0, 0, 0, 0, 0, P.dbg != nullptr,
            lds_cells, P.cell_cap / 2, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, {-1, -1, -1}, false};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -1539,7 +1525,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
         else
             ppht_grouped(C, N, lds_list);
     } else {
-        unsigned* nzw = P.nz_work + (size_t)i * P.nz_cap;
+        unsigned* nzw = P.nz_work + (size_t)slot * P.nz_cap;
         for (int p = lane; p < N; p += 64) st_l2(&nzw[p], ld_l2(&nzo[p]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ppht_serial<false>(C, N, nzw);
@@ -1548,7 +1534,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     const long long c2 = P.dbg ? clock64() : 0;
     // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
     if (__any(C.touched_global)) {
-        int* acc = P.accum + (size_t)i * NUM_ANGLE * P.numrho;
+        int* acc = P.accum + (size_t)slot * NUM_ANGLE * P.numrho;
         for (int p = 0; p < N; ++p) {
             const unsigned pt = ld_l2(&nzo[p]);
             const int x = pt & 0xFFFF, y = pt >> 16;
@@ -1574,74 +1560,192 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
     }
 }
 
+// Frames the classifier sent to the one-wave replay (more points than an LDS list holds, or every frame under
+// MDH_HOUGH_ONE_WAVE / MDH_HOUGH_SERIAL): gridDim.x workgroups walk the tier's frame list, each with its own buffer slot.
+__global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
+    RAISE_WAVE_PRIORITY();
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int count = *P.fcount;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        ppht_one_wave_frame(P, P.flist[j], blockIdx.x, lds_dyn);
+        __threadfence();
+        __syncthreads();  // the next frame reuses the LDS and the slot's (clean again) global buffers
+    }
+}
+
 // ================================================================================================
-// Four-wave PPHT: the same exact replay, but one 256-thread workgroup per frame.  Thread t owns angle t (180 of
-// the 256 lanes), so a vote / un-vote is ONE rho + ONE LDS atomic per lane and the four SIMDs of the CU work on the
-// same point.  Everything that decides control flow (draws, swap-removes, mask bits, trigger) is computed identically
-// by every wave from the same data; what must happen once (list writes, mask clears, output) is done by wave 0; the
-// per-point "did any angle reach the threshold" and the arg-max cross the waves through a small LDS mailbox.
-// Barriers per group of <= 16 points: two (list reads | list writes + votes | decision).
-struct Ppht4 {
+// Frame routing.  One wave per frame: the adaptive maxLineGap (Detector.py:342-344), and which launch replays the frame:
+//   tier 0 / 1  three-wave kernel, everything in LDS (point list, working mask over the bounding box, all 180 rho windows),
+//               small / large dynamic LDS (2-3 frames per CU / one frame per CU)
+//   tier 2      three-wave kernel, hybrid: the rho windows that fit in LDS + a pooled global accumulator for the rest
+//   tier 3      one-wave kernel with a global point list (more than HOUGH_MAX_LIST points)
+//   none        fewer points than the vote threshold: no accumulator cell can reach it, so there is no segment
+#define HOUGH_TIERS 4
+#define HOUGH_MAX_LIST 8192
+#define HOUGH3_THREADS 192
+#define HOUGH3_FIXED_DWORDS 64  // mailboxes + scan scratch + line results
+
+// A line clears at most one pixel per step along its major axis, and only inside the bounding box of the lit pixels.
+__device__ __forceinline__ int hough3_uv_cap(int N, int bw, int bh) { return (min(N, max(bw, bh) + 2) + 3) & ~3; }
+__device__ __forceinline__ int hough3_lds_need(int N, int uv_cap, int cells, int mask_dwords) {
+    // [fixed | point list N | un-vote list | mask | cells + one dummy dword per thread]
+    return 4 * (HOUGH3_FIXED_DWORDS + ((N + 3) & ~3) + uv_cap + mask_dwords + (cells + 1) / 2 + HOUGH3_THREADS);
+}
+
+__global__ void __launch_bounds__(256) k_hough_classify(HoughParams P) {
+    RAISE_WAVE_PRIORITY();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= P.K) return;
+    const int N = P.litcount[i];
+    double gap = P.max_gap;
+    if (!P.fixed_gap) {
+        const double dst_sum = (double)N / P.mask_area * 100;
+        double gg = 1 - dst_sum / 0.05;
+        if (gg < 0) gg = 0;
+        gap = gg * P.max_gap;
+    }
+    if (lane == 0) P.out_gap[i] = gap;
+    if (N < P.threshold) {  // (threshold >= 1, so this covers the empty frame)
+        if (lane == 0) P.out_nraw[i] = 0;
+        return;
+    }
+    const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
+    int cells = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = lane + 64 * q;
+        if (n < NUM_ANGLE) {
+            const float c = P.trig[2 * n], sn = P.trig[2 * n + 1];
+            const int r00 = rho_bin(bx0, by0, c, sn, 0), r10 = rho_bin(bx1, by0, c, sn, 0);
+            const int r01 = rho_bin(bx0, by1, c, sn, 0), r11 = rho_bin(bx1, by1, c, sn, 0);
+            cells += max(max(r00, r10), max(r01, r11)) - min(min(r00, r10), min(r01, r11)) + 1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    if (lane != 0) return;
+    const int mask_dw = (by1 - by0 + 1) * ((bx1 >> 6) - (bx0 >> 6) + 1) * 2;
+    int tier;
+    if (N > HOUGH_MAX_LIST || P.all_one_wave) tier = 3;
+    else if (P.no_lds_acc) tier = 2;
+    else {
+        const int need = hough3_lds_need(N, hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1), cells, mask_dw);
+        tier = need <= P.lds_small ? 0 : (need <= P.lds_large ? 1 : 2);
+    }
+    P.tier_list[tier * P.K + atomicAdd(&P.tier_count[tier], 1)] = i;
+}
+
+// ================================================================================================
+// Three-wave PPHT: the same exact replay, one 192-thread workgroup per frame, thread t = angle t (180 of 192 lanes), so a
+// vote / un-vote is ONE rho + ONE LDS atomic per lane and three SIMDs of the CU work on the same point.
+//
+// What makes it fast (the four-wave kernel of round 1 spent ~10 k cycles per group of 7.5 points):
+//  * the VISITING ORDER is data-independent -- cv::RNG is seeded with the same constant for every call, and the swap-remove
+//    of the point list never looks at pixel data -- so for an N-point frame the k-th visited point is list[perm_N[k]] with a
+//    table computed once per process (k_perm_build).  No draws, no conflict analysis, no list writes in the kernel.
+//  * 64 points are examined per step: one load of the table, one of the list, one look at the working mask; dead points
+//    (cleared by an earlier segment: 3 of 4 in a streak) cost nothing more.
+//  * the live points of a step vote in sub-groups of 16 back to back; a cell belongs to exactly one thread, whose LDS
+//    atomics complete in program order, so every point sees exactly the sequential counts.  One barrier per sub-group (did any
+//    angle of any wave reach the threshold); on a hit the later votes are taken back, the line is processed and the rest of
+//    the step is re-examined against the updated mask -- identical to the one-point loop.
+//  * the working mask lives in LDS (bit plane over the bounding box of the lit pixels; outside of it nothing is lit).
+//  * a line: its two directions are walked by two waves at the same time; the cleared pixels are collected and ALL threads
+//    take their votes back in one sweep (un-votes commute).
+// Everything that decides control flow is computed identically by every wave from the same data.
+struct Hough3 {
     const HoughParams& P;
-    u64* work;
-    unsigned* work32;
-    int* acc;
-    float tc, ts;        // this thread's angle
-    int n;               // angle index (= thread id); n >= 180: no angle
-    int lo, span, off;   // its LDS window (span < 0: none)
-    int line_gap, frame, found, lane, wave;
+    float tc, ts;          // this thread's angle
+    unsigned vinc;         // 1 for a thread with an angle, 0 for the 12 spare lanes (their votes add nothing to a private cell)
+    int cbase;             // LDS cell of rho bin r (before the +half shift): r + cbase
+    bool in_lds;           // HYBRID: this angle's window lives in LDS
+    int* acc_row;          // HYBRID: this angle's row of the pooled global accumulator, shifted by half
     unsigned* cells;
-    int dummy_base;
-    unsigned* mbox;      // [0..7] hit masks [parity][wave], [8..11] keys, [12..15] flags
-    unsigned* gbox;      // [0..15] points of the current group, [16] its size (written by wave 0)
+    // working mask
+    bool mask_lds;
+    unsigned* lmask;       // [rows][mw] dwords over the bounding box
+    int by0, rows, cx0, mw;
+    u64* gmask;            // pooled global mask (whole frame) when the bounding box is too large
+    int WW;
+    int line_gap, frame, found, lane, wave, tid;
+    unsigned* fix;         // fixed LDS block: [0..7] hit mailbox (2 parities x 4), [8..11] keys, [12..23] line ends, [24] un-vote count, [32..] scan
+    unsigned* uv;
     bool touched_global;
-    bool timing;
-    long long ph[8];     // MDH_HOUGH_DEBUG: cycles per phase (draws, list, mask, votes, keys, trigger, line, groups)
+    bool timing;           // MDH_HOUGH_DEBUG: cycles per phase (thread 0's view)
+    long long ph[8];       // steps (table, list, mask), votes, hits + barrier, trigger (take back, arg-max), walk, clear, un-vote, lines
 };
-#define PH_T(C, k, t0) do { if ((C).timing) { const long long t1_ = clock64(); (C).ph[k] += t1_ - (t0); (t0) = t1_; } } while (0)
+#define H3_T(C, k, t0) do { if ((C).timing) { const long long t1_ = clock64(); (C).ph[k] += t1_ - (t0); (t0) = t1_; } } while (0)
 
-__device__ __forceinline__ bool work_bit4(const Ppht4& C, int x, int y) {
-    return (ld_l2(&C.work[(size_t)y * C.P.WW + (x >> 6)]) >> (x & 63)) & 1;
-}
-
-__device__ __forceinline__ int vote4(Ppht4& C, int x, int y) {
-    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts))) + C.P.half;
-    const unsigned d = (unsigned)(r - C.lo);
-    const bool inwin = C.span >= 0 && d <= (unsigned)C.span;
-    const int c = C.off + (int)d;
-    const int sh = (c & 1) * 16;
-    const unsigned o = atomicAdd(&C.cells[inwin ? (c >> 1) : C.dummy_base + (int)threadIdx.x], inwin ? (1u << sh) : 0u);
-    int old = inwin ? (int)((o >> sh) & 0xFFFFu) - CELL_BIAS : -KEY_BIAS - 1;
-    const bool outside = !inwin && C.n < NUM_ANGLE;
-    if (__any(outside)) {
-        if (outside) {
-            old = atomicAdd(&C.acc[(size_t)C.n * C.P.numrho + r], 1);
-            C.touched_global = true;
-        }
+template <bool HYBRID>
+__device__ __forceinline__ bool h3_bit(const Hough3& C, int x, int y) {
+    if (!HYBRID || C.mask_lds) {
+        const int ry = y - C.by0, cx = (x >> 5) - C.cx0;
+        const bool inb = (unsigned)ry < (unsigned)C.rows && (unsigned)cx < (unsigned)C.mw;
+        const unsigned v = C.lmask[inb ? ry * C.mw + cx : 0];
+        return inb && ((v >> (x & 31)) & 1);
     }
-    return old;
+    return (ld_l2(&C.gmask[(size_t)y * C.WW + (x >> 6)]) >> (x & 63)) & 1;
 }
-__device__ __forceinline__ void unvote4(Ppht4& C, int x, int y) {
-    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts))) + C.P.half;
-    const unsigned d = (unsigned)(r - C.lo);
-    const bool inwin = C.span >= 0 && d <= (unsigned)C.span;
-    const int c = C.off + (int)d;
-    atomicSub(&C.cells[inwin ? (c >> 1) : C.dummy_base + (int)threadIdx.x], inwin ? (1u << ((c & 1) * 16)) : 0u);
-    const bool outside = !inwin && C.n < NUM_ANGLE;
-    if (__any(outside)) {
-        if (outside) {
-            atomicSub(&C.acc[(size_t)C.n * C.P.numrho + r], 1);
-            C.touched_global = true;
-        }
+// clear the bit, return whether it was set
+template <bool HYBRID>
+__device__ __forceinline__ bool h3_clear(const Hough3& C, int x, int y) {
+    const unsigned bit = 1u << (x & 31);
+    if (!HYBRID || C.mask_lds) {
+        const int ry = y - C.by0, cx = (x >> 5) - C.cx0;
+        const bool inb = (unsigned)ry < (unsigned)C.rows && (unsigned)cx < (unsigned)C.mw;
+        if (!inb) return false;
+        return atomicAnd(&C.lmask[ry * C.mw + cx], ~bit) & bit;
     }
-}
-__device__ __forceinline__ unsigned key4(const Ppht4& C, int old) {
-    return ((unsigned)(old + 1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.n < 256 ? C.n : 255));
+    return atomicAnd(&((unsigned*)C.gmask)[((size_t)y * C.WW + (x >> 6)) * 2 + ((x >> 5) & 1)], ~bit) & bit;
 }
 
-// Line extraction, identical in every wave; wave 0 clears the mask bits.  Ends with a barrier, so mask reads that
-// follow see the clears.
-__device__ void ppht4_line(Ppht4& C, int x, int y, int bn) {
+// `inc` = 1 for a real vote, 0 for an empty slot of a sub-group (the votes of a sub-group are issued branch-free so that the
+// sixteen independent rho chains interleave; an empty slot adds nothing to the cell of point (0, 0))
+template <bool HYBRID>
+__device__ __forceinline__ int h3_vote(Hough3& C, int x, int y, unsigned inc) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+    if (!HYBRID || C.in_lds) {
+        const int c = r + C.cbase;
+        const int sh = (c & 1) * 16;
+        const unsigned o = atomicAdd(&C.cells[c >> 1], (C.vinc & inc) << sh);
+        return (int)((o >> sh) & 0xFFFFu) - CELL_BIAS;
+    }
+    C.touched_global = true;
+    return atomicAdd(&C.acc_row[r], (int)inc);
+}
+template <bool HYBRID>
+__device__ __forceinline__ void h3_unvote(Hough3& C, int x, int y) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+    if (!HYBRID || C.in_lds) {
+        const int c = r + C.cbase;
+        atomicSub(&C.cells[c >> 1], C.vinc << ((c & 1) * 16));
+    } else {
+        C.touched_global = true;
+        atomicSub(&C.acc_row[r], 1);
+    }
+}
+
+// exclusive scan over the workgroup (3 waves); `total` = sum over all threads.  Two barriers.
+__device__ __forceinline__ int h3_scan(int v, int& total, unsigned* scratch, int lane, int wave) {
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) scratch[wave] = (unsigned)incl;
+    __syncthreads();
+    const int s0 = (int)scratch[0], s1 = (int)scratch[1], s2 = (int)scratch[2];
+    total = s0 + s1 + s2;
+    const int base = wave == 0 ? 0 : (wave == 1 ? s0 : s0 + s1);
+    __syncthreads();
+    return base + incl - v;
+}
+
+// The point (x, y) reached the threshold at angle bn (hough.cpp, second half of the loop).  Wave k (k = 0, 1) walks direction
+// k; ends with a barrier after which every wave sees the cleared mask and the taken-back votes of ITS OWN cells.
+template <bool HYBRID>
+__device__ void h3_line(Hough3& C, int x, int y, int bn) {
     const HoughParams& P = C.P;
     const int lane = C.lane;
     const float a = -P.trig[2 * bn + 1], b = P.trig[2 * bn];
@@ -1658,9 +1762,13 @@ __device__ void ppht4_line(Ppht4& C, int x, int y, int bn) {
         dx0 = __float2int_rn(__fdiv_rn(__fmul_rn(a, 65536.f), fabsf(b)));
         x0 = (x0 << 16) + 32768;
     }
-    int end_step[2], end_x[2], end_y[2];
-    for (int k = 0; k < 2; ++k) {
-        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+    const int k = C.wave;  // direction of this wave (wave 2 has none)
+    const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+    unsigned* ends = C.fix + 12;  // [k][end_step, end_x, end_y]
+    long long tph = C.timing ? clock64() : 0;
+    if (C.timing) C.ph[7] += 1;
+    if (C.tid == 0) C.fix[24] = 0;  // un-vote list is empty (its last readers passed a barrier since)
+    if (k < 2) {
         int gap = 0, last_lit = 0;
         bool done = false;
         for (int s0 = 0; !done; s0 += 64) {
@@ -1669,9 +1777,10 @@ __device__ void ppht4_line(Ppht4& C, int x, int y, int bn) {
             const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
             const bool inside = j1 >= 0 && j1 < P.W && i1 >= 0 && i1 < P.H;
             bool lit = false;
-            if (inside) lit = work_bit4(C, j1, i1);
+            if (inside) lit = h3_bit<HYBRID>(C, j1, i1);
             const u64 mi = __ballot(inside), ml = __ballot(lit);
-            const int n_in = mi == ~0ull ? 64 : __builtin_ctzll(~mi);
+            // scan the 64 steps run by run (lit runs reset the gap, dark runs extend it) instead of bit by bit
+            const int n_in = mi == ~0ull ? 64 : __builtin_ctzll(~mi);  // steps before the image border
             int pos = 0;
             while (pos < n_in) {
                 const u64 rest = ml >> pos;
@@ -1690,348 +1799,338 @@ __device__ void ppht4_line(Ppht4& C, int x, int y, int bn) {
                     pos += run;
                 }
             }
-            if (!done && n_in < 64) done = true;
+            if (!done && n_in < 64) done = true;  // left the image
         }
-        end_step[k] = last_lit;
-        const int X = x0 + dx * last_lit, Y = y0 + dy * last_lit;
-        end_x[k] = xflag ? X : X >> 16;
-        end_y[k] = xflag ? Y >> 16 : Y;
+        if (lane == 0) {
+            const int X = x0 + dx * last_lit, Y = y0 + dy * last_lit;
+            ends[3 * k + 0] = (unsigned)last_lit;
+            ends[3 * k + 1] = (unsigned)(xflag ? X : X >> 16);
+            ends[3 * k + 2] = (unsigned)(xflag ? Y >> 16 : Y);
+        }
     }
-    const bool good = abs(end_x[1] - end_x[0]) >= P.line_length || abs(end_y[1] - end_y[0]) >= P.line_length;
-    for (int k = 0; k < 2; ++k) {
-        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-        for (int s0 = 0; s0 <= end_step[k]; s0 += 64) {
+    __syncthreads();
+    H3_T(C, 4, tph);
+    const int ex0 = (int)ends[1], ey0 = (int)ends[2], ex1 = (int)ends[4], ey1 = (int)ends[5];
+    const bool good = abs(ex1 - ex0) >= P.line_length || abs(ey1 - ey0) >= P.line_length;
+    if (k < 2) {
+        const int end_step = (int)ends[3 * k];
+        for (int s0 = 0; s0 <= end_step; s0 += 64) {
             const int s = s0 + lane;
             bool was = false;
-            int j1 = 0, i1 = 0;
-            if (s <= end_step[k]) {
+            unsigned pt = 0;
+            if (s <= end_step) {
                 const int X = x0 + dx * s, Y = y0 + dy * s;
-                j1 = xflag ? X : X >> 16;
-                i1 = xflag ? Y >> 16 : Y;
-                was = work_bit4(C, j1, i1);
+                const int j1 = xflag ? X : X >> 16, i1 = xflag ? Y >> 16 : Y;
+                was = h3_clear<HYBRID>(C, j1, i1);  // (step 0 belongs to both directions: the atomic gives it to one of them)
+                pt = ((unsigned)i1 << 16) | (unsigned)j1;
             }
-            u64 ms = __ballot(was);   // the same in every wave: nobody has cleared these pixels yet
-            __syncthreads();          // every wave has read the chunk
-            if (C.wave == 0 && was)
-                atomicAnd(&C.work32[((size_t)i1 * P.WW + (j1 >> 6)) * 2 + ((j1 >> 5) & 1)], ~(1u << (j1 & 31)));
             if (good) {
-                while (ms) {
-                    const int bb = __builtin_ctzll(ms);
-                    ms &= ms - 1;
-                    const int sb = s0 + bb;
-                    const int X = x0 + dx * sb, Y = y0 + dy * sb;
-                    unvote4(C, xflag ? X : X >> 16, xflag ? Y >> 16 : Y);
+                const u64 ms = __ballot(was);
+                if (ms) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&C.fix[24], (unsigned)__popcll(ms));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (was) C.uv[base + __popcll(ms & ((1ull << lane) - 1))] = pt;
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // the clears of this direction are done before anybody reads the mask again
+        if (HYBRID && !C.mask_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads();  // the mask is cleared, the un-vote list is complete
+    H3_T(C, 5, tph);
     if (good) {
-        if (C.found < MAX_LINES && threadIdx.x == 0) {
+        const int M = (int)C.fix[24];
+        int m = 0;
+        for (; m + 4 <= M; m += 4) {  // four points per LDS read (the list is 16-byte aligned)
+            const uint4 q = *(const uint4*)&C.uv[m];
+            h3_unvote<HYBRID>(C, q.x & 0xFFFF, q.x >> 16);
+            h3_unvote<HYBRID>(C, q.y & 0xFFFF, q.y >> 16);
+            h3_unvote<HYBRID>(C, q.z & 0xFFFF, q.z >> 16);
+            h3_unvote<HYBRID>(C, q.w & 0xFFFF, q.w >> 16);
+        }
+        for (; m < M; ++m) {
+            const unsigned q = C.uv[m];
+            h3_unvote<HYBRID>(C, q & 0xFFFF, q >> 16);
+        }
+        if (C.found < MAX_LINES && C.tid == 0) {
             int* o = P.out_lines + ((size_t)C.frame * MAX_LINES + C.found) * 4;
-            o[0] = end_x[0]; o[1] = end_y[0]; o[2] = end_x[1]; o[3] = end_y[1];
+            o[0] = ex0; o[1] = ey0; o[2] = ex1; o[3] = ey1;
         }
         ++C.found;
     }
+    H3_T(C, 6, tph);
 }
 
-__device__ void ppht4_grouped(Ppht4& C, int N, unsigned* list) {
+template <bool HYBRID>
+__device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
+    const HoughParams& P = C.P;
     const int lane = C.lane;
-    u64 state = 0xFFFFFFFFFFFFFFFFull;
-    int count = N;
+    const unsigned short* perm = P.perm + (size_t)N * (N - 1) / 2;
     unsigned round = 0;
-    // Only wave 0 draws: the visiting order is the same for everybody, and a single wave cannot issue faster than one
-    // instruction per ~5 cycles, so three more copies of the draw / conflict logic were three more waves competing for the
-    // CU's issue slots.  Wave 0 publishes the group (points and size) through LDS; it is also the only one that reads or
-    // writes the point list.
-    while (count > 0) {
+    int gsz = 16;
+    unsigned nxt = lane < N ? perm[lane] : 0;  // the table entries of the following step are fetched one step ahead
+    for (int k0 = 0; k0 < N; k0 += 64) {
         long long tph = C.timing ? clock64() : 0;
-        if (C.timing) C.ph[7] += 1;
-        int gn = 0;
-        unsigned my_pt = 0;
-      if (C.wave == 0) {
-        gn = count < PPHT_G ? count : PPHT_G;
-        u64 st = state, my_state = 0;
-        unsigned my_rnd = 0;
+        const int kk = k0 + lane;
+        const unsigned idx = nxt;
+        nxt = kk + 64 < N ? perm[kk + 64] : 0;
+        const unsigned pt = kk < N ? list[idx] : 0;
+        const int px = pt & 0xFFFF, py = pt >> 16;
+        u64 am = __ballot(kk < N && h3_bit<HYBRID>(C, px, py));
+        H3_T(C, 0, tph);
+        while (am) {
+            // sub-group: the first (up to) `gsz` live points of the step vote back to back.  Votes behind a trigger are wasted
+            // (taken back and repeated), and triggers come in bursts (the parallel lines of one streak), so the sub-group
+            // shrinks to 4 after a trigger and doubles with every quiet sub-group.
+            int old[16];
+            u64 rem = am;
+            const int gused = gsz <= 4 ? 4 : (gsz <= 8 ? 8 : 16);  // slots of this sub-group
+            if (gsz <= 4) {
 #pragma unroll
-        for (int k = 0; k < PPHT_G; ++k) {
-            if (k < gn) {
-                st = rng_step(st);
-                if (lane == k) {
-                    my_rnd = (unsigned)st;
-                    my_state = st;
+                for (int j = 0; j < 4; ++j) {
+                    const bool has = rem != 0;
+                    const int l = has ? __builtin_ctzll(rem) : 0;
+                    rem &= rem - 1;
+                    const int o = h3_vote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u);
+                    old[j] = has ? o : -KEY_BIAS - 1;
+                }
+#pragma unroll
+                for (int j = 4; j < 16; ++j) old[j] = -KEY_BIAS - 1;
+            } else if (gsz <= 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool has = rem != 0;
+                    const int l = has ? __builtin_ctzll(rem) : 0;
+                    rem &= rem - 1;
+                    const int o = h3_vote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u);
+                    old[j] = has ? o : -KEY_BIAS - 1;
+                }
+#pragma unroll
+                for (int j = 8; j < 16; ++j) old[j] = -KEY_BIAS - 1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool has = rem != 0;
+                    const int l = has ? __builtin_ctzll(rem) : 0;
+                    rem &= rem - 1;
+                    const int o = h3_vote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u);
+                    old[j] = has ? o : -KEY_BIAS - 1;
                 }
             }
-        }
-        const bool in_grp = lane < gn;
-        const int my_idx = in_grp ? (int)(my_rnd % (unsigned)(count - lane)) : -1 - lane;
-        int lim = in_grp ? count - 1 - my_idx : PPHT_G;
-#pragma unroll
-        for (int j = 0; j < PPHT_G - 1; ++j) {
-            const int v = __builtin_amdgcn_readlane(my_idx, j);
-            if (in_grp && j < lane && v == my_idx) lim = lane < lim ? lane : lim;
-        }
-        const int g = min(gn, (int)row16_min_lane15((unsigned)lim));
-        PH_T(C, 0, tph);
-        unsigned wr_val = 0;
-        int wr_idx = -1;
-        if (g == 0) {  // the first draw removes the last element itself: ordinary serial step
-            state = rng_step(state);
-            const int idx = (int)((unsigned)state % (unsigned)count);
-            my_pt = list[idx];
-            wr_val = list[count - 1];
-            if (lane == 0) wr_idx = idx;
-            gn = 1;
-        } else {
-            if (lane < g) {
-                my_pt = list[my_idx];
-                wr_val = list[count - 1 - lane];
-                wr_idx = my_idx;
-            }
-            gn = g;
-            {  // the generator state after the g-th draw lives in lane g-1 (g is wave-uniform: one v_readlane pair)
-                const int src = __builtin_amdgcn_readfirstlane(g - 1);
-                state = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(my_state >> 32), src) << 32) |
-                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_state, src);
-            }
-        }
-        if (wr_idx >= 0) list[wr_idx] = wr_val;  // (LDS operations of one wave complete in order: the reads above came first)
-        if (lane < PPHT_G) C.gbox[lane] = my_pt;
-        if (lane == 0) C.gbox[PPHT_G] = (unsigned)gn;
-      }
-        __syncthreads();  // the group is published
-        gn = __builtin_amdgcn_readfirstlane((int)C.gbox[PPHT_G]);
-        if (C.wave != 0) my_pt = C.gbox[lane & (PPHT_G - 1)];
-        count -= gn;
-        u64 pending = (1ull << gn) - 1;
-        const int px = my_pt & 0xFFFF, py = my_pt >> 16;
-        PH_T(C, 1, tph);
-        while (true) {
-            bool alive = false;
-            if ((pending >> lane) & 1) alive = work_bit4(C, px, py);
-            const u64 am = __ballot(alive);
-            PH_T(C, 2, tph);
+            if (C.timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            H3_T(C, 1, tph);
             unsigned hits = 0;
-            unsigned keys[PPHT_G];
-            if (am) {
-                int old[PPHT_G];
 #pragma unroll
-                for (int k = 0; k < PPHT_G; ++k) {
-                    if ((am >> k) & 1) {
-                        const unsigned pt = __builtin_amdgcn_readlane(my_pt, k);
-                        old[k] = vote4(C, pt & 0xFFFF, pt >> 16);
-                    }
-                }
-                if (C.timing) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                PH_T(C, 3, tph);
-#pragma unroll
-                for (int k = 0; k < PPHT_G; ++k) {
-                    keys[k] = 0;
-                    if ((am >> k) & 1) {
-                        keys[k] = key4(C, old[k]);
-                        if (__any(key_value(keys[k]) >= C.P.threshold)) hits |= 1u << k;
-                    }
-                }
-            }
-            if (lane == 0) C.mbox[(round & 1) * 4 + C.wave] = hits;
-            __syncthreads();  // also: the list writes above are visible to the next group's reads
-            const unsigned H = C.mbox[(round & 1) * 4] | C.mbox[(round & 1) * 4 + 1] | C.mbox[(round & 1) * 4 + 2] |
-                               C.mbox[(round & 1) * 4 + 3];
-            ++round;
-            PH_T(C, 4, tph);
-            if (!H) break;
-            const int trig = __builtin_ctz(H);
-            // points after the trigger voted too early: take those votes back, they are re-examined below
-            const u64 later = am & ~((2ull << trig) - 1);
-#pragma unroll
-            for (int k = 1; k < PPHT_G; ++k) {
-                if ((later >> k) & 1) {
-                    const unsigned pt = __builtin_amdgcn_readlane(my_pt, k);
-                    unvote4(C, pt & 0xFFFF, pt >> 16);
-                }
-            }
-            unsigned kt = 0, tp = 0;
-#pragma unroll
-            for (int k = 0; k < PPHT_G; ++k) {
-                if (k == trig) {
-                    kt = keys[k];
-                    tp = __builtin_amdgcn_readlane(my_pt, k);
-                }
-            }
-            const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(kt, 0);
-            if (lane == 0) C.mbox[8 + C.wave] = wmax;
+            for (int j = 0; j < 16; ++j)
+                if (__any(old[j] + 1 >= P.threshold)) hits |= 1u << j;
+            if (lane == 0) C.fix[(round & 1) * 4 + C.wave] = hits;
             __syncthreads();
-            const unsigned best = max(max(C.mbox[8], C.mbox[9]), max(C.mbox[10], C.mbox[11]));
-            PH_T(C, 5, tph);
-            ppht4_line(C, tp & 0xFFFF, tp >> 16, 255 - (int)(best & 0xFF));  // ends with a barrier
-            PH_T(C, 6, tph);
-            pending = later;
-            if (!pending) break;
+            const unsigned Hm = C.fix[(round & 1) * 4] | C.fix[(round & 1) * 4 + 1] | C.fix[(round & 1) * 4 + 2];
+            ++round;
+            H3_T(C, 2, tph);
+            if (!Hm) {
+                am = rem;
+                gsz = min(16, gsz * 2);
+                continue;
+            }
+            gsz = 4;
+            const int trig = __builtin_ctz(Hm);
+            // lane of the trigger point; the sub-group's points after it voted too early: take those votes back
+            u64 walk = am;
+            int tl = 0, kt = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (walk) {
+                    const int l = __builtin_ctzll(walk);
+                    walk &= walk - 1;
+                    if (j == trig) {
+                        tl = l;
+                        kt = old[j];
+                    } else if (j > trig && j < gused) {
+                        h3_unvote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l));
+                    }
+                }
+            }
+            const unsigned key = ((unsigned)(kt + 1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.tid < 256 ? C.tid : 255));
+            const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(C.vinc ? key : 0u, 0);
+            if (lane == 0) C.fix[8 + C.wave] = wmax;
+            __syncthreads();
+            const unsigned best = max(max(C.fix[8], C.fix[9]), C.fix[10]);
+            const int tx = __builtin_amdgcn_readlane(px, tl), ty = __builtin_amdgcn_readlane(py, tl);
+            H3_T(C, 3, tph);
+            h3_line<HYBRID>(C, tx, ty, 255 - (int)(best & 0xFF));  // ends with a barrier
+            if (C.timing) tph = clock64();
+            // the rest of the step against the updated mask
+            am = __ballot(kk < N && lane > tl && h3_bit<HYBRID>(C, px, py));
         }
     }
 }
 
-// LDS: [ point list: list_cap | cells: cell_cap/2 | 256 dummy | 16 mailbox | 180*3 window table | 32 group box ]  (dwords)
-#define HOUGH4_EXTRA_DWORDS (256 + 16 + 3 * NUM_ANGLE + 32)
-__global__ void __launch_bounds__(256) k_hough_ppht4(HoughParams P) {
-    __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
-    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
-    unsigned* lds_list = lds_dyn;
-    unsigned* lds_cells = lds_dyn + P.list_cap;
-    unsigned* mbox = lds_cells + P.cell_cap / 2 + 256;
-    int* wtab = (int*)(mbox + 16);
-    const int i = blockIdx.x;
+template <bool HYBRID>
+__device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = P.litcount[i];
     const long long w0 = P.dbg ? wall_clock64() : 0;
-    double gap = P.max_gap;
-    if (!P.fixed_gap) {
-        const double dst_sum = (double)N / P.mask_area * 100;
-        double gg = 1 - dst_sum / 0.05;
-        if (gg < 0) gg = 0;
-        gap = gg * P.max_gap;
+    unsigned* fix = lds;
+    unsigned* list = lds + HOUGH3_FIXED_DWORDS;
+    const int Np = (N + 3) & ~3;  // keeps the un-vote list and the mask 16-byte aligned
+    unsigned* uv = list + Np;
+    const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
+    const int uvc = hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1);
+    unsigned* lmask = uv + uvc;
+    const int wlo = bx0 >> 6, wpr = (bx1 >> 6) - wlo + 1, rows = by1 - by0 + 1;
+    const int mask_dw = rows * wpr * 2;
+    const int budget_dw = P.lds_bytes / 4 - HOUGH3_FIXED_DWORDS - Np - uvc - HOUGH3_THREADS;  // mask + cells
+    bool mask_lds = true;
+    if (HYBRID) mask_lds = mask_dw <= budget_dw / 4;  // a huge bounding box: the mask stays in global memory, the LDS goes to the cells
+    unsigned* cells = lmask + (mask_lds ? mask_dw : 0);
+    const int cell_cap = HYBRID ? (P.no_lds_acc ? 0 : 2 * (budget_dw - (mask_lds ? mask_dw : 0))) : 0x7FFFFFFF;
+    // ---- rho windows from the bounding box: rho is monotone in x and in y for a fixed angle, so its extremes are at the corners
+    int w_lo = 0, w_size = 0;
+    float tc = 0.f, ts = 0.f;
+    if (tid < NUM_ANGLE) {
+        tc = P.trig[2 * tid];
+        ts = P.trig[2 * tid + 1];
+        const int r00 = rho_bin(bx0, by0, tc, ts, 0), r10 = rho_bin(bx1, by0, tc, ts, 0);
+        const int r01 = rho_bin(bx0, by1, tc, ts, 0), r11 = rho_bin(bx1, by1, tc, ts, 0);
+        w_lo = min(min(r00, r10), min(r01, r11));
+        w_size = max(max(r00, r10), max(r01, r11)) - w_lo + 1;
     }
-    const int line_gap = (int)rint(gap);
-    if (tid == 0 && P.tier == 0) P.out_gap[i] = gap;
-    if (N == 0) {
-        if (tid == 0 && P.tier == 0) P.out_nraw[i] = 0;
-        return;
-    }
-    if (N > P.big_list) return;  // more points than any LDS list holds: the one-wave kernel's global-list path
-    // ---- wave 0: accumulator windows from the bounding box (see k_hough_ppht), published through LDS ----
-    if (wave == 0) {
-        int w_lo[3] = {0, 0, 0}, w_size[3] = {0, 0, 0};
-        int cells_needed = 0;
-        const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int n = lane + 64 * q;
-            if (n < NUM_ANGLE) {
-                const float c = P.trig[2 * n], sn = P.trig[2 * n + 1];
-                const int r00 = rho_bin(bx0, by0, c, sn, P.half), r10 = rho_bin(bx1, by0, c, sn, P.half);
-                const int r01 = rho_bin(bx0, by1, c, sn, P.half), r11 = rho_bin(bx1, by1, c, sn, P.half);
-                w_lo[q] = min(min(r00, r10), min(r01, r11));
-                w_size[q] = max(max(r00, r10), max(r01, r11)) - w_lo[q] + 1;
-            }
-            cells_needed += w_size[q];
-        }
-        for (int o = 32; o > 0; o >>= 1) cells_needed += __shfl_xor(cells_needed, o);
-        const bool fits_small = N <= P.small_list && cells_needed <= P.small_cells;
-        const bool mine = P.tier < 0 || ((P.tier == 0) == fits_small);
-        int limit = 0x7FFFFFFF;
-        if (mine && cells_needed > P.cell_cap) {
+    int placed = w_size, total = 0;
+    if (HYBRID) {
+        // the smallest windows first (the angles across the streak, where the votes pile up): largest size limit that fits
+        h3_scan(w_size, total, fix + 32, lane, wave);
+        if (total > cell_cap) {
             int lo = 0, hi = P.numrho;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                int sum = 0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) sum += w_size[q] <= mid ? w_size[q] : 0;
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                if (sum <= P.cell_cap) lo = mid; else hi = mid - 1;
+                int sum;
+                h3_scan(w_size <= mid ? w_size : 0, sum, fix + 32, lane, wave);
+                if (sum <= cell_cap) lo = mid; else hi = mid - 1;
             }
-            limit = lo;
-        }
-        int base = 0;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int n = lane + 64 * q;
-            const int size = (w_size[q] > 0 && w_size[q] <= limit && !P.no_lds_acc) ? w_size[q] : 0;
-            int incl = size;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int tt = __shfl_up(incl, d);
-                if (lane >= d) incl += tt;
-            }
-            if (n < NUM_ANGLE) {
-                wtab[3 * n + 0] = w_lo[q];
-                wtab[3 * n + 1] = size - 1;
-                wtab[3 * n + 2] = base + incl - size;
-            }
-            base += __shfl(incl, 63);
-        }
-        if (lane == 0) {
-            mbox[12] = mine ? 1u : 0u;
-            mbox[13] = (unsigned)base;
+            placed = w_size <= lo ? w_size : 0;
         }
     }
-    __syncthreads();
-    if (!mbox[12]) return;  // the other launch owns this frame
-    const int cells_used = (int)mbox[13];
+    const int off = h3_scan(placed, total, fix + 32, lane, wave);
+    const int cell_dw = (total + 1) / 2;
+    // ---- initialise: cells at the bias, one private zero cell per thread for the spare lanes, mailboxes
+    for (int p = tid; p < cell_dw; p += HOUGH3_THREADS) cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
+    cells[cell_dw + tid] = 0;
+    if (tid < HOUGH3_FIXED_DWORDS) fix[tid] = 0;
+    // ---- row-major point list + working mask from the words of the bounding box
     const size_t words = (size_t)P.H * P.WW;
     const u64* dst = P.dst_bits + (size_t)i * words;
-    u64* wrk = P.work_bits + (size_t)i * words;
-    unsigned* nzo = P.nz_orig + (size_t)i * P.nz_cap;
-    // ---- wave 0: row-major point list + working copy of the lit rows; the others initialise the cells ----
-    if (wave == 0) {
-        int total = 0;
-        for (int yb = 0; yb < P.H; yb += 64) {
-            const int y = yb + lane;
-            const int c = y < P.H ? P.rowcount[i * P.H + y] : 0;
-            int incl = c;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int tt = __shfl_up(incl, d);
-                if (lane >= d) incl += tt;
+    u64* gmask = P.work_bits + (size_t)slot * words;
+    const int TW = rows * wpr;
+    __syncthreads();
+    int run = 0;
+    for (int base = 0; base < TW; base += HOUGH3_THREADS) {
+        const int e = base + tid;
+        u64 word = 0;
+        int y = 0, w = 0;
+        if (e < TW) {
+            const int ry = e / wpr;
+            y = by0 + ry;
+            w = wlo + (e - ry * wpr);
+            word = dst[(size_t)y * P.WW + w];
+            if (mask_lds) {
+                lmask[2 * e] = (unsigned)word;
+                lmask[2 * e + 1] = (unsigned)(word >> 32);
+            } else if (word) {
+                gmask[(size_t)y * P.WW + w] = word;
             }
-            if (c > 0) {
-                int pos = total + incl - c;
-                for (int w = 0; w < P.WW; ++w) {
-                    u64 word = dst[(size_t)y * P.WW + w];
-                    wrk[(size_t)y * P.WW + w] = word;
-                    while (word) {
-                        const int bpos = __builtin_ctzll(word);
-                        word &= word - 1;
-                        const unsigned pt = ((unsigned)y << 16) | (unsigned)(w * 64 + bpos);
-                        nzo[pos] = pt;
-                        lds_list[pos] = pt;
-                        ++pos;
-                    }
-                }
-            }
-            total += __shfl(incl, 63);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        for (int p = tid - 64; p < (cells_used + 1) / 2; p += 192) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
+        int tot;
+        int pos = run + h3_scan(__popcll(word), tot, fix + 32, lane, wave);
+        while (word) {
+            const int bpos = __builtin_ctzll(word);
+            word &= word - 1;
+            list[pos++] = ((unsigned)y << 16) | (unsigned)(w * 64 + bpos);
+        }
+        run += tot;
     }
-    Ppht4 C{P, wrk, (unsigned*)wrk, P.accum + (size_t)i * NUM_ANGLE * P.numrho, 0.f, 0.f, tid, 0, -1, 0,
-            line_gap, i, 0, lane, wave, lds_cells, P.cell_cap / 2, mbox, (unsigned*)(wtab + 3 * NUM_ANGLE), false, P.dbg_phase != nullptr,
-            {0, 0, 0, 0, 0, 0, 0, 0}};
-    if (tid < NUM_ANGLE) {
-        C.tc = P.trig[2 * tid];
-        C.ts = P.trig[2 * tid + 1];
+    if (HYBRID && !mask_lds) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    Hough3 C{P, tc, ts, tid < NUM_ANGLE ? 1u : 0u, 0, true, nullptr, cells, mask_lds, lmask, by0, rows, 2 * wlo, 2 * wpr, gmask, P.WW,
+             (int)rint(P.out_gap[i]), i, 0, lane, wave, tid, fix, uv, false, P.dbg_phase != nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
     if (tid < NUM_ANGLE) {
-        C.lo = wtab[3 * tid];
-        C.span = wtab[3 * tid + 1];
-        C.off = wtab[3 * tid + 2];
+        C.in_lds = placed > 0;
+        C.cbase = off - w_lo;
+        if (HYBRID) C.acc_row = P.accum + (size_t)slot * NUM_ANGLE * P.numrho + (size_t)tid * P.numrho + P.half;
+    } else {
+        C.cbase = 2 * (cell_dw + tid);  // r is 0 for the spare lanes (tc = ts = 0): their private cell
     }
     const long long w1 = P.dbg ? wall_clock64() : 0;
-    ppht4_grouped(C, N, lds_list);
+    h3_replay<HYBRID>(C, N, list);
     if (tid == 0) P.out_nraw[i] = C.found;
     if (P.dbg && tid == 0) {  // MDH_HOUGH_DEBUG=1: points, tier, 100 MHz ticks (set-up, PPHT), segments, LDS cells
         long long* d = P.dbg + (size_t)i * 8;
-        d[0] = N; d[1] = P.tier; d[2] = w1 - w0; d[3] = wall_clock64() - w1; d[4] = C.found; d[5] = cells_used;
-        d[6] = wall_clock64(); d[7] = w0;
+        d[0] = N; d[1] = HYBRID ? 2 : (P.lds_bytes == P.lds_small ? 0 : 1); d[2] = w1 - w0; d[3] = wall_clock64() - w1; d[4] = C.found;
+        d[5] = total; d[6] = wall_clock64(); d[7] = w0;
         if (P.dbg_phase)
             for (int k = 0; k < 8; ++k) P.dbg_phase[(size_t)i * 8 + k] = C.ph[k];
     }
-    // leave the global accumulator all-zero: every cell ever touched belongs to some point of the original list
-    const unsigned long long any_global = __ballot(C.touched_global);
-    if (lane == 0) mbox[12 + wave] = any_global ? 1u : 0u;  // (mbox[12], [13] are no longer needed)
-    __syncthreads();
-    if (mbox[12] | mbox[13] | mbox[14] | mbox[15]) {
-        for (int p = 0; p < N; ++p) {
-            const unsigned pt = ld_l2(&nzo[p]);
-            const int x = pt & 0xFFFF, y = pt >> 16;
-            if (tid < NUM_ANGLE) {
-                const int r = rho_bin(x, y, C.tc, C.ts, P.half);
-                if (C.span < 0 || (unsigned)(r - C.lo) > (unsigned)C.span) C.acc[(size_t)tid * P.numrho + r] = 0;
+    if (HYBRID) {
+        // leave the pooled buffers all-zero: every accumulator cell ever touched belongs to some point of the list
+        __syncthreads();
+        if (tid < NUM_ANGLE && !C.in_lds) {
+            for (int p = 0; p < N; ++p) {
+                const unsigned pt = list[p];
+                C.acc_row[__float2int_rn(__fadd_rn(__fmul_rn((float)(pt & 0xFFFF), tc), __fmul_rn((float)(pt >> 16), ts)))] = 0;
             }
         }
+        if (!mask_lds) {
+            for (int e = tid; e < TW; e += HOUGH3_THREADS) {
+                const int ry = e / wpr;
+                const size_t g = (size_t)(by0 + ry) * P.WW + wlo + (e - ry * wpr);
+                if (dst[g]) gmask[g] = 0;
+            }
+        }
+        __threadfence();
     }
-    // the working mask is all-zero between passes: clear the rows that were copied in
-    for (int y = tid; y < P.H; y += 256)
-        if (P.rowcount[i * P.H + y] > 0)
-            for (int w = 0; w < P.WW; ++w) wrk[(size_t)y * P.WW + w] = 0;
+}
+
+// tiers 0 / 1: one workgroup per listed frame (grid = K; the workgroups beyond the list leave at once)
+__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3(HoughParams P) {
+    __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    if ((int)blockIdx.x >= *P.fcount) return;
+    hough3_frame<false>(P, P.flist[blockIdx.x], 0, lds_dyn);
+}
+// tier 2: gridDim.x workgroups walk the list, each with its own slot of the pooled accumulator / mask
+__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_hybrid(HoughParams P) {
+    __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int count = *P.fcount;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        hough3_frame<true>(P, P.flist[j], blockIdx.x, lds_dyn);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The visiting order of cv::HoughLinesP for an N-point list (hough.cpp: idx = rng.uniform(0, count); swap-remove), as a
+// table: perm_N[k] = row-major index of the k-th visited point.  rnd[] is the output sequence of cv::RNG(0xFFFFFFFFFFFFFFFF)
+// (host).  One workgroup per N; the shuffle itself is a serial chain run by one lane on an LDS copy.
+__global__ void __launch_bounds__(64) k_perm_build(const unsigned* __restrict__ rnd, unsigned short* __restrict__ perm, int n_max) {
+    __shared__ unsigned short a[HOUGH_MAX_LIST], ix[HOUGH_MAX_LIST];
+    const int N = blockIdx.x + 1;
+    if (N > n_max) return;
+    for (int k = threadIdx.x; k < N; k += 64) {
+        a[k] = (unsigned short)k;
+        ix[k] = (unsigned short)(rnd[k] % (unsigned)(N - k));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned short* out = perm + (size_t)N * (N - 1) / 2;
+        for (int k = 0; k < N; ++k) {
+            const int idx = ix[k];
+            const unsigned short v = a[idx];
+            a[idx] = a[N - 1 - k];
+            out[k] = v;
+        }
+    }
 }

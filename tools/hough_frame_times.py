@@ -8,14 +8,15 @@ from metdetpy_amd import M3Detector, _lib
 from metdetpy_amd.synth import SkyStream
 
 WL = os.environ.get("WL", "C2")
-H, W, n, B, uniq = (1080, 1920, 8, 1024, 256) if WL == "C2" else ((2160, 3840, 16, 256, 128) if WL == "C3" else (4320, 7680, 8, 64, 32))
+H, W, n, B, uniq = (1080, 1920, 8, 1024, 250) if WL == "C2" else ((2160, 3840, 16, 256, 100) if WL == "C3" else (4320, 7680, 8, 64, 50))
 mask = np.ones((H, W), np.uint8)
+bench.SENSITIVITY = bench.WORKLOADS[WL].get("sensitivity", "normal")
 frames = SkyStream(H, W, bench.WORKLOADS[WL]["seed"]).take(uniq)
 det = M3Detector(1, n, mask, 10, bench.make_cfg(), None, max_batch=B)
 ctx = det._ctx
 pool = ctx.device_alloc(B * H * W)
 for start in range(0, B, uniq):
-    ctx.device_upload(pool + start * H * W, frames)
+    ctx.device_upload(pool + start * H * W, frames[:min(uniq, B - start)])
 info = np.zeros(B, _lib.FRAME_INFO_DTYPE)
 for _ in range(3):
     ctx.process_batch_into(pool, B, True, info, None, None, None)
@@ -40,9 +41,10 @@ for lo, hi in ((1, 50), (50, 200), (200, 500), (500, 1000), (1000, 4000), (4000,
     if m.any():
         print("N in [%d,%d): %d frames, mean ppht %.1f us, mean segs %.1f" % (lo, hi, m.sum(), t[m].mean(), dbg[m, 4].mean()))
 
-# phase totals of the four-wave kernel (shader cycles, thread 0's view), summed over the frames with points
-names = ["draws+conflicts", "list exchange", "mask check", "votes", "keys+mailbox", "trigger", "line", "groups"]
+# phase totals of the three-wave kernel (shader cycles, thread 0's view), summed over the frames with points
+names = ["steps (table, list, mask)", "votes", "hits + barrier", "trigger (take back, arg-max)", "line walk", "line clear", "un-vote + emit", "lines"]
 tot = ph[act].sum(axis=0)
 cyc = tot[:7].sum()
-print("phase share of PPHT cycles:", {n: round(float(v) / cyc, 3) for n, v in zip(names[:7], tot[:7])}, " groups per frame: %.1f" % (tot[7] / act.sum()),
-      " points per group: %.2f" % (dbg[act, 0].sum() / max(tot[7], 1)), " cycles per group: %.0f" % (cyc / max(tot[7], 1)))
+if cyc > 0:
+    print("phase share of PPHT cycles:", {n: round(float(v) / cyc, 3) for n, v in zip(names[:7], tot[:7])}, " line events per frame: %.1f" % (tot[7] / act.sum()),
+          " cycles per frame: %.0f" % (cyc / act.sum()), " cycles per line event (walk+clear+un-vote): %.0f" % (tot[4:7].sum() / max(tot[7], 1)))
