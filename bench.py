@@ -400,8 +400,14 @@ def run_per_frame(a, D, wl, mask):
     host memory, results on the host before the next frame is handed over.  One step = one frame."""
     from metdetpy_amd import M3Detector
     H, W, n = wl["H"], wl["W"], wl["n"]
+    import ctypes
     frames = make_stream_frames(wl, D.rank, mask, 300, a.unique)
     det = M3Detector(1, n, mask, 10, make_cfg(), None, device=D.local, max_batch=8)
+    # the loader's frame buffers: pinned host memory (mdh_host_alloc), as a loader built for this detector would hand them over
+    pool = det._ctx.host_alloc(frames.nbytes)
+    ctypes.memmove(pool, frames.ctypes.data, frames.nbytes)
+    host_frames = frames
+    frames = np.ctypeslib.as_array((ctypes.c_uint8 * frames.nbytes).from_address(pool)).reshape(frames.shape)
     tally = [0, 0, 0]
     k = 0
 
@@ -423,9 +429,11 @@ def run_per_frame(a, D, wl, mask):
     D.fence()
     dt = time.perf_counter() - t0
     dt_all, tot = D.max_time_and_sum(dt, tally)
+    del frames
+    det._ctx.host_free(pool)
     det.close()
-    return dict(frames=steps * D.world, dt=dt_all, steps=steps, tot=tot, prof={}, prof_alone={}, frames_sample=frames, B=1,
-                uniq=len(frames))
+    return dict(frames=steps * D.world, dt=dt_all, steps=steps, tot=tot, prof={}, prof_alone={}, frames_sample=host_frames, B=1,
+                uniq=len(host_frames))
 
 
 def main():

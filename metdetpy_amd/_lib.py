@@ -166,6 +166,10 @@ class Context:
         self._raw1 = np.zeros((MDH_MAX_LINES, 4), np.int32)
         self._nms1 = np.zeros((MDH_MAX_LINES, 4), np.int32)
         self._prob1 = np.zeros(MDH_MAX_LINES, np.float64)
+        # the per-frame protocol is latency-bound: addresses are taken once, not per call
+        self._p1 = (self._info1.ctypes.data, self._raw1.ctypes.data, self._nms1.ctypes.data, self._prob1.ctypes.data)
+        self._empty4 = np.zeros((0, 4), np.int32)
+        self._empty1 = np.zeros(0, np.float64)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -181,16 +185,21 @@ class Context:
     def update(self, frame: np.ndarray):
         if frame.shape != (self.H, self.W) or frame.dtype != np.uint8:
             raise ValueError(f"frame must be uint8 {(self.H, self.W)}, got {frame.dtype} {frame.shape}")
-        f = np.ascontiguousarray(frame)
-        check(self.L.mdh_update(self.handle, f.ctypes.data), "mdh_update")
+        f = frame if frame.flags.c_contiguous else np.ascontiguousarray(frame)
+        rc = self.L.mdh_update(self.handle, f.__array_interface__["data"][0])
+        if rc:
+            check(rc, "mdh_update")
 
     def detect(self):
-        check(self.L.mdh_detect(self.handle, self._info1.ctypes.data, self._raw1.ctypes.data, self._nms1.ctypes.data,
-                                self._prob1.ctypes.data), "mdh_detect")
-        info = self._info1[0]
+        rc = self.L.mdh_detect(self.handle, *self._p1)
+        if rc:
+            check(rc, "mdh_detect")
+        info = self._info1[0].copy()
         nr = min(int(info["n_raw"]), MDH_MAX_LINES)
+        if nr == 0:
+            return info, self._empty4, self._empty4, self._empty1
         nn = int(info["n_nms"])
-        return info.copy(), self._raw1[:nr].copy(), self._nms1[:nn].copy(), self._prob1[:nn].copy()
+        return info, self._raw1[:nr].copy(), self._nms1[:nn].copy(), self._prob1[:nn].copy()
 
     def process_batch(self, frames, K=None, on_device=False):
         """frames: (K,H,W) uint8 ndarray (host) or an integer device pointer with K given."""

@@ -42,6 +42,11 @@ static void set_err(const std::string& s) { g_err = s; }
         }                                                                                              \
     } while (0)
 
+// Cross-stream ordering of a pass.  In "lean" mode (the per-frame protocol: one frame, results wanted at once) the whole pass is
+// queued on ONE stream, so the waits and the events they wait for are dropped; only the completion event remains.
+#define EV_WAIT(c, st, ev) do { if (!(c)->lean) HIPCHK(hipStreamWaitEvent(st, ev, 0)); } while (0)
+#define EV_REC(c, ev, st) do { if (!(c)->lean) HIPCHK(hipEventRecord(ev, st)); } while (0)
+
 enum KernelKind { KK_NOISE_SUMS = 0, KK_NOISE_FINAL, KK_STACK_THR, KK_MORPH, KK_DY_ALIVE, KK_DY_APPLY, KK_HOUGH, KK_CLASSIC };
 static const char* kKernelNames[MDH_NUM_KERNELS] = {"noise_sums", "noise_finalize", "stack_threshold", "morph_close",
                                                     "dy_alive",   "dy_sparse",      "hough_ppht",      "classic"};
@@ -172,6 +177,8 @@ struct mdh_ctx {
     size_t xchg_words = 0;
     // update()/detect() protocol
     bool pending = false;
+    bool lean = false;         // the pass being queued runs on the staging stream alone (mdh_update / mdh_detect)
+    hipEvent_t ev_copy = nullptr;  // lean mode: the caller's frame has been read
     // A pass mutates host-side stream state (EMA schedule, history, ring positions) while it is being queued; if a HIP call
     // fails half-way the context no longer describes the stream, so it refuses further work instead of producing silently
     // wrong thresholds / windows.
@@ -259,6 +266,7 @@ static void free_all(mdh_ctx* c) {
         }
     }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->ev_copy) hipEventDestroy(c->ev_copy);
     for (HoughSet& h : c->hset) {
         void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work, h.d_tier_list, h.d_tier_count};
         for (void* p : hdev)
@@ -348,6 +356,7 @@ static int create_impl(mdh_ctx* c) {
     HIPCHK(make_stream(&c->pstream[0], "MDH_PRIO_HOUGH"));
     HIPCHK(make_stream(&c->pstream[1], "MDH_PRIO_HOUGH"));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     for (int hi = 0; hi < c->nhset; ++hi) {
         HoughSet& h = c->hset[hi];
         HIPCHK(make_stream(&h.stream[0], "MDH_PRIO_HOUGH"));
@@ -441,6 +450,7 @@ static int create_impl(mdh_ctx* c) {
                                (HOUGH_MAX_LIST + 61440 / 2 + 64) * (int)sizeof(unsigned)));
     HIPCHK(hipFuncSetAttribute((const void*)k_hough3, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
     HIPCHK(hipFuncSetAttribute((const void*)k_hough3_hybrid, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough_single, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
     const float theta = (float)(3.14159265358979323846 / 180.0);
@@ -654,6 +664,7 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
                                   hipMemcpyHostToDevice, c->nstream));
             i += run;
         }
+        if (c->lean) HIPCHK(hipEventRecord(c->ev_copy, c->nstream));  // the caller's buffer has been read when this fires
     }
     // which frames are due for a noise sigma, and with which EMA momentum (host mirror of Detector.py:81-91, utils.py:360-368)
     const int n = c->n;
@@ -683,7 +694,13 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
         j.one_minus = 1 - m;
     }
     sl.nj = nj;
-    // pointer table and jobs in one copy
+    // pointer table and jobs in one copy (lean mode: on a side stream, next to the frame's 2 MB instead of behind them)
+    if (c->lean) {
+        HIPCHK(hipMemcpyAsync(sl.d_hdr, sl.h_hdr, sl.hdr_jobs_off + sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->cstream));
+        HIPCHK(hipEventRecord(sl.ev_k1, c->cstream));
+        HIPCHK(hipStreamWaitEvent(c->nstream, sl.ev_k1, 0));
+        return MDH_OK;
+    }
     HIPCHK(hipMemcpyAsync(sl.d_hdr, sl.h_hdr, sl.hdr_jobs_off + sizeof(NoiseJob) * nj, hipMemcpyHostToDevice, c->nstream));
     return MDH_OK;
 }
@@ -802,7 +819,7 @@ static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
                        sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(sl.ev_noise, c->nstream));
+    EV_REC(c, sl.ev_noise, c->nstream);
     return MDH_OK;
 }
 
@@ -824,8 +841,8 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // downstream of it -- morphology, dynamic mask, Hough, result packing -- is short or latency-bound and runs on the
     // pass's post streams, overlapping the window kernel of the following pass(es).
     // (the post streams are NOT the Hough streams: morphology of pass p must not queue behind the Hough stage of pass p-2)
-    hipStream_t post = c->pstream[c->pass_seq & 1];
-    HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_noise, 0));  // thresholds, pointer table, history copies, cleared counters
+    hipStream_t post = c->lean ? c->nstream : c->pstream[c->pass_seq & 1];
+    EV_WAIT(c, c->stream, sl.ev_noise);  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
         static const bool skip_window = getenv("MDH_SKIP_WINDOW") != nullptr;  // timing experiments only: results are wrong
@@ -836,8 +853,8 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, sl.d_planes, g);
         span_end(c, c->stream);
     }
-    HIPCHK(hipEventRecord(sl.ev_k1, c->stream));
-    HIPCHK(hipStreamWaitEvent(post, sl.ev_k1, 0));
+    EV_REC(c, sl.ev_k1, c->stream);
+    EV_WAIT(c, post, sl.ev_k1);
     // (dst of this slot is all-zero again: k_pass_prepare ran before ev_noise, which the window kernel waited for)
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_MORPH, post);
@@ -846,11 +863,11 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_nzcount + 1, c->d_act,
                            sl.d_nzlist, sl.d_nzcount, g);
         span_end(c, post);
-        HIPCHK(hipEventRecord(sl.ev_close, post));
+        EV_REC(c, sl.ev_close, post);
         // the dynamic mask looks n-1 frames back: the previous pass's binaries (written on another post stream when the
         // Hough sets alternate) must be in the ring; older passes are ordered by the streams themselves
         if (c->prev_slot >= 0 && c->prev_slot != (int)(&sl - c->slot))
-            HIPCHK(hipStreamWaitEvent(post, c->slot[c->prev_slot].ev_close, 0));
+            EV_WAIT(c, post, c->slot[c->prev_slot].ev_close);
         span_begin(c, KK_DY_APPLY, post);
         hipLaunchKernelGGL(k_dy_sparse, dim3(2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
                            sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
@@ -859,7 +876,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
                            sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
     }
-    HIPCHK(hipEventRecord(sl.ev_pix, post));
+    EV_REC(c, sl.ev_pix, post);
     return MDH_OK;
 }
 
@@ -867,7 +884,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
 // set run_pixels (or mdh_hough_planes) queued the slot's planes and counters on; starts after sl.ev_pix.
 static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t* hstream = hs.stream;
+    hipStream_t hstream[2] = {c->lean ? c->nstream : hs.stream[0], c->lean ? c->nstream : hs.stream[1]};
     HoughParams P{};
     P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
     P.threshold = c->cfg.hough_threshold;
@@ -887,7 +904,8 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.out_lines = sl.d_lines; P.out_nraw = sl.d_nraw; P.out_gap = sl.d_gap; P.trig = c->d_trig;
     P.bbox = sl.d_bbox;
     P.tier_list = hs.d_tier_list; P.tier_count = hs.d_tier_count; P.K = K;
-    P.lds_small = c->lds_small; P.lds_large = c->lds_large;
+    // (lean mode: one three-wave launch with the large LDS takes every frame that fits; an empty launch less in the chain)
+    P.lds_small = c->lean ? c->lds_large : c->lds_small; P.lds_large = c->lds_large;
     P.all_one_wave = c->hough_one_wave;
     P.perm = c->d_perm;
     P.list_cap = HOUGH_MAX_LIST; P.cell_cap = 61440;  // the one-wave kernel's LDS
@@ -896,17 +914,33 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     // the one-wave launch (global point lists) on stream [1].  Every launch walks a device-built frame list, so an empty tier
     // costs a launch of workgroups that leave at once.  The set's previous user queued its work on these same streams and
     // stream [0] waited for its stream [1] before packing, so the pooled buffers and the lists are free by stream order.
-    HIPCHK(hipStreamWaitEvent(hstream[0], sl.ev_pix, 0));
+    EV_WAIT(c, hstream[0], sl.ev_pix);
     span_begin(c, KK_HOUGH, hstream[0]);
     static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr;  // timing experiments only: results are wrong
+    if (c->lean && K == 1 && !skip_hough) {
+        // the per-frame protocol: routing + replay + packing in one launch (k_hough_single), then the one result copy
+        P.lds_small = P.lds_large;
+        P.lds_bytes = P.lds_large;
+        hipLaunchKernelGGL(k_hough_single, dim3(1), dim3(HOUGH3_THREADS), std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned)),
+                           hstream[0], P, (int4*)sl.d_packed, sl.d_off, sl.d_litcopy);
+        span_end(c, hstream[0]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sl.h_res, sl.d_res, sl.res_lines_off + sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K,
+                              hipMemcpyDeviceToHost, hstream[0]));
+        HIPCHK(hipEventRecord(sl.ev_done, hstream[0]));
+        hs.last_slot = (int)(&sl - c->slot);
+        c->prev_slot = (int)(&sl - c->slot);
+        c->pass_seq += 1;
+        return MDH_OK;
+    }
     if (skip_hough) {
         HIPCHK(hipMemsetAsync(sl.d_nraw, 0, sizeof(int) * K, hstream[0]));
-        HIPCHK(hipEventRecord(hs.ev_big, hstream[0]));
+        EV_REC(c, hs.ev_big, hstream[0]);
     } else {
         HIPCHK(hipMemsetAsync(hs.d_tier_count, 0, sizeof(int) * HOUGH_TIERS, hstream[0]));
         hipLaunchKernelGGL(k_hough_classify, dim3((K + 3) / 4), dim3(256), 0, hstream[0], P);
-        HIPCHK(hipEventRecord(hs.ev_cls, hstream[0]));
-        HIPCHK(hipStreamWaitEvent(hstream[1], hs.ev_cls, 0));
+        EV_REC(c, hs.ev_cls, hstream[0]);
+        EV_WAIT(c, hstream[1], hs.ev_cls);
         const int Kmax = c->Kmax;
         auto tier = [&](int t) {
             P.flist = hs.d_tier_list + (size_t)t * K;
@@ -914,19 +948,21 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         };
         tier(1);
         P.lds_bytes = c->lds_large;
-        hipLaunchKernelGGL(k_hough3, dim3(K), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        static const int grid_l = getenv("MDH_HOUGH_GRID_LARGE") ? atoi(getenv("MDH_HOUGH_GRID_LARGE")) : 256;
+        static const int grid_s = getenv("MDH_HOUGH_GRID_SMALL") ? atoi(getenv("MDH_HOUGH_GRID_SMALL")) : 1024;
+        if (!c->lean) hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_l)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
         tier(2);
         hipLaunchKernelGGL(k_hough3_hybrid, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
         tier(3);
         hipLaunchKernelGGL(k_hough_ppht, dim3(std::min(K, hs.pool_list)), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned),
                            hstream[1], P);
-        HIPCHK(hipEventRecord(hs.ev_big, hstream[1]));
+        EV_REC(c, hs.ev_big, hstream[1]);
         tier(0);
-        P.lds_bytes = c->lds_small;
-        hipLaunchKernelGGL(k_hough3, dim3(K), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[0], P);
+        P.lds_bytes = P.lds_small;
+        hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_s)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[0], P);
         (void)Kmax;
     }
-    HIPCHK(hipStreamWaitEvent(hstream[0], hs.ev_big, 0));
+    EV_WAIT(c, hstream[0], hs.ev_big);
     span_end(c, hstream[0]);
     HIPCHK(hipGetLastError());
     // pack the segments and send the head of the packed array along with the scalars; collect_pass fetches the rest only
@@ -1160,6 +1196,10 @@ extern "C" int mdh_collect_batch(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_
     return rc == MDH_OK ? K : rc;
 }
 
+// The reference's per-frame protocol (MetDetPy.py:197-198).  mdh_update queues the WHOLE pass of the frame -- copy, noise /
+// threshold chain, pixel stages, Hough, result copy -- on one stream without a single cross-stream dependency, and returns
+// as soon as the caller's buffer has been read (the reference copies it, utils.py:280; while the 2 MB travel over PCIe the
+// host has queued everything else); mdh_detect waits for the pass and hands out the results.
 extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if (!c || !frame) { set_err("mdh_update: null argument"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_FULL) { set_err("mdh_update: not a MDH_ROLE_FULL context"); return MDH_E_STATE; }
@@ -1170,11 +1210,16 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     Slot* sl = nullptr;
     int rc;
     if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
-    if ((rc = stage_frames(c, *sl, frame, 1, 0)) != MDH_OK) return poison(c, rc);
-    if ((rc = retire_frames(c, *sl, 1, 0)) != MDH_OK) return poison(c, rc);
-    if ((rc = run_noise(c, *sl, 1)) != MDH_OK) return poison(c, rc);
-    // the caller may reuse `frame` after return (the reference copies it, utils.py:280)
-    HIPCHK(hipStreamSynchronize(c->nstream));
+    c->lean = true;
+    c->stream = c->nstream;
+    rc = stage_frames(c, *sl, frame, 1, 0);
+    if (rc == MDH_OK) rc = retire_frames(c, *sl, 1, 0);
+    if (rc == MDH_OK) rc = run_noise(c, *sl, 1);
+    if (rc == MDH_OK) rc = run_detect(c, *sl, 1);
+    c->lean = false;
+    if (rc != MDH_OK) return poison(c, rc);
+    slot_commit(c, *sl);
+    HIPCHK(hipEventSynchronize(c->ev_copy));  // the caller may reuse `frame` after return
     c->pending = true;
     return MDH_OK;
 }
@@ -1184,13 +1229,6 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
     if (!c->pending) { set_err("mdh_detect: call mdh_update first"); return MDH_E_STATE; }
     CHECK_POISON(c, "mdh_detect");
     HIPCHK(hipSetDevice(c->device));
-    Slot& sl = c->slot[c->next_slot];
-    int rc;
-    c->d_ptrtab = sl.d_ptrtab; c->d_thr = sl.d_thr; c->d_bandflag = sl.d_bandflag; c->d_bbits = sl.d_bbits;
-    c->h_ptrtab = sl.h_ptrtab;
-    c->cur_spans = &sl.spans;
-    if ((rc = run_detect(c, sl, 1)) != MDH_OK) return poison(c, rc);
-    slot_commit(c, sl);
     c->pending = false;
     return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
 }

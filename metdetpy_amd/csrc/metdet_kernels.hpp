@@ -1519,7 +1519,7 @@ __device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsig
     }
     if (N <= P.list_cap) {
         for (int p = lane; p < N; p += 64) lds_list[p] = ld_l2(&nzo[p]);
-        __syncthreads();
+        __threadfence_block();  // one wave: its LDS operations execute in order
         if (P.serial)
             ppht_serial<true>(C, N, lds_list);
         else
@@ -1592,11 +1592,8 @@ __device__ __forceinline__ int hough3_lds_need(int N, int uv_cap, int cells, int
     return 4 * (HOUGH3_FIXED_DWORDS + ((N + 3) & ~3) + uv_cap + mask_dwords + (cells + 1) / 2 + HOUGH3_THREADS);
 }
 
-__global__ void __launch_bounds__(256) k_hough_classify(HoughParams P) {
-    RAISE_WAVE_PRIORITY();
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (i >= P.K) return;
+// One wave per frame.  Returns the tier (-1: nothing to replay).
+__device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
     const int N = P.litcount[i];
     double gap = P.max_gap;
     if (!P.fixed_gap) {
@@ -1608,7 +1605,7 @@ __global__ void __launch_bounds__(256) k_hough_classify(HoughParams P) {
     if (lane == 0) P.out_gap[i] = gap;
     if (N < P.threshold) {  // (threshold >= 1, so this covers the empty frame)
         if (lane == 0) P.out_nraw[i] = 0;
-        return;
+        return -1;
     }
     const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
     int cells = 0;
@@ -1623,16 +1620,20 @@ __global__ void __launch_bounds__(256) k_hough_classify(HoughParams P) {
         }
     }
     for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
-    if (lane != 0) return;
     const int mask_dw = (by1 - by0 + 1) * ((bx1 >> 6) - (bx0 >> 6) + 1) * 2;
-    int tier;
-    if (N > HOUGH_MAX_LIST || P.all_one_wave) tier = 3;
-    else if (P.no_lds_acc) tier = 2;
-    else {
-        const int need = hough3_lds_need(N, hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1), cells, mask_dw);
-        tier = need <= P.lds_small ? 0 : (need <= P.lds_large ? 1 : 2);
-    }
-    P.tier_list[tier * P.K + atomicAdd(&P.tier_count[tier], 1)] = i;
+    if (N > HOUGH_MAX_LIST || P.all_one_wave) return 3;
+    if (P.no_lds_acc) return 2;
+    const int need = hough3_lds_need(N, hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1), cells, mask_dw);
+    return need <= P.lds_small ? 0 : (need <= P.lds_large ? 1 : 2);
+}
+
+__global__ void __launch_bounds__(256) k_hough_classify(HoughParams P) {
+    RAISE_WAVE_PRIORITY();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= P.K) return;
+    const int tier = hough_classify_frame(P, i, lane);
+    if (tier >= 0 && lane == 0) P.tier_list[tier * P.K + atomicAdd(&P.tier_count[tier], 1)] = i;
 }
 
 // ================================================================================================
@@ -1701,17 +1702,25 @@ __device__ __forceinline__ bool h3_clear(const Hough3& C, int x, int y) {
 
 // `inc` = 1 for a real vote, 0 for an empty slot of a sub-group (the votes of a sub-group are issued branch-free so that the
 // sixteen independent rho chains interleave; an empty slot adds nothing to the cell of point (0, 0))
+// The vote is split in two so that the atomics of a sub-group are all in flight before the first returned count is looked at.
 template <bool HYBRID>
-__device__ __forceinline__ int h3_vote(Hough3& C, int x, int y, unsigned inc) {
+__device__ __forceinline__ unsigned h3_vote_issue(Hough3& C, int x, int y, unsigned inc, int& sh) {
     const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
     if (!HYBRID || C.in_lds) {
         const int c = r + C.cbase;
-        const int sh = (c & 1) * 16;
-        const unsigned o = atomicAdd(&C.cells[c >> 1], (C.vinc & inc) << sh);
-        return (int)((o >> sh) & 0xFFFFu) - CELL_BIAS;
+        sh = (c & 1) * 16;
+        return atomicAdd(&C.cells[c >> 1], (C.vinc & inc) << sh);
     }
-    C.touched_global = true;
-    return atomicAdd(&C.acc_row[r], (int)inc);
+    sh = -1;
+    return (unsigned)atomicAdd(&C.acc_row[r], (int)inc);
+}
+template <bool HYBRID>
+__device__ __forceinline__ int h3_vote_value(unsigned o, int sh) {
+    if (HYBRID && sh < 0) return (int)o;
+    return (int)((o >> sh) & 0xFFFFu) - CELL_BIAS;
+}
+__device__ __forceinline__ u64 h3_uniform(u64 v) {  // the value is wave-uniform: tell the compiler (keeps it in SGPRs)
+    return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
 template <bool HYBRID>
 __device__ __forceinline__ void h3_unvote(Hough3& C, int x, int y) {
@@ -1766,7 +1775,7 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
     unsigned* ends = C.fix + 12;  // [k][end_step, end_x, end_y]
     long long tph = C.timing ? clock64() : 0;
-    if (C.timing) C.ph[7] += 1;
+    if (C.timing) C.ph[7] += 1;  // [15:0] line events, [39:16] vote slots issued, [63:40] sub-groups
     if (C.tid == 0) C.fix[24] = 0;  // un-vote list is empty (its last readers passed a barrier since)
     if (k < 2) {
         int gap = 0, last_lit = 0;
@@ -1810,10 +1819,11 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     }
     __syncthreads();
     H3_T(C, 4, tph);
-    const int ex0 = (int)ends[1], ey0 = (int)ends[2], ex1 = (int)ends[4], ey1 = (int)ends[5];
+    const int ex0 = __builtin_amdgcn_readfirstlane((int)ends[1]), ey0 = __builtin_amdgcn_readfirstlane((int)ends[2]);
+    const int ex1 = __builtin_amdgcn_readfirstlane((int)ends[4]), ey1 = __builtin_amdgcn_readfirstlane((int)ends[5]);
     const bool good = abs(ex1 - ex0) >= P.line_length || abs(ey1 - ey0) >= P.line_length;
     if (k < 2) {
-        const int end_step = (int)ends[3 * k];
+        const int end_step = __builtin_amdgcn_readfirstlane((int)ends[3 * k]);
         for (int s0 = 0; s0 <= end_step; s0 += 64) {
             const int s = s0 + lane;
             bool was = false;
@@ -1839,7 +1849,7 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     __syncthreads();  // the mask is cleared, the un-vote list is complete
     H3_T(C, 5, tph);
     if (good) {
-        const int M = (int)C.fix[24];
+        const int M = __builtin_amdgcn_readfirstlane((int)C.fix[24]);
         int m = 0;
         for (; m + 4 <= M; m += 4) {  // four points per LDS read (the list is 16-byte aligned)
             const uint4 q = *(const uint4*)&C.uv[m];
@@ -1883,38 +1893,28 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
             // (taken back and repeated), and triggers come in bursts (the parallel lines of one streak), so the sub-group
             // shrinks to 4 after a trigger and doubles with every quiet sub-group.
             int old[16];
+            am = h3_uniform(am);
             u64 rem = am;
             const int gused = gsz <= 4 ? 4 : (gsz <= 8 ? 8 : 16);  // slots of this sub-group
-            if (gsz <= 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool has = rem != 0;
-                    const int l = has ? __builtin_ctzll(rem) : 0;
-                    rem &= rem - 1;
-                    const int o = h3_vote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u);
-                    old[j] = has ? o : -KEY_BIAS - 1;
-                }
-#pragma unroll
-                for (int j = 4; j < 16; ++j) old[j] = -KEY_BIAS - 1;
-            } else if (gsz <= 8) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool has = rem != 0;
-                    const int l = has ? __builtin_ctzll(rem) : 0;
-                    rem &= rem - 1;
-                    const int o = h3_vote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u);
-                    old[j] = has ? o : -KEY_BIAS - 1;
-                }
-#pragma unroll
-                for (int j = 8; j < 16; ++j) old[j] = -KEY_BIAS - 1;
-            } else {
+            if (C.timing) C.ph[7] += ((long long)min(gused, (int)__popcll(am)) << 16) + (1ll << 40);
+            {
+                unsigned raw[16];
+                int shv[16];
+                u64 hasm = 0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const bool has = rem != 0;
-                    const int l = has ? __builtin_ctzll(rem) : 0;
-                    rem &= rem - 1;
-                    const int o = h3_vote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u);
-                    old[j] = has ? o : -KEY_BIAS - 1;
+                    if (j < gused) {  // (gused is wave-uniform: 4, 8 or 16 slots)
+                        const bool has = rem != 0;
+                        const int l = has ? __builtin_ctzll(rem) : 0;
+                        rem &= rem - 1;
+                        hasm |= (u64)(has ? 1 : 0) << j;
+                        raw[j] = h3_vote_issue<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u, shv[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    old[j] = -KEY_BIAS - 1;
+                    if (j < gused && ((hasm >> j) & 1)) old[j] = h3_vote_value<HYBRID>(raw[j], shv[j]);
                 }
             }
             if (C.timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1925,7 +1925,8 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
                 if (__any(old[j] + 1 >= P.threshold)) hits |= 1u << j;
             if (lane == 0) C.fix[(round & 1) * 4 + C.wave] = hits;
             __syncthreads();
-            const unsigned Hm = C.fix[(round & 1) * 4] | C.fix[(round & 1) * 4 + 1] | C.fix[(round & 1) * 4 + 2];
+            const unsigned Hm = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)(C.fix[(round & 1) * 4] | C.fix[(round & 1) * 4 + 1] | C.fix[(round & 1) * 4 + 2]));
             ++round;
             H3_T(C, 2, tph);
             if (!Hm) {
@@ -1955,7 +1956,7 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
             const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(C.vinc ? key : 0u, 0);
             if (lane == 0) C.fix[8 + C.wave] = wmax;
             __syncthreads();
-            const unsigned best = max(max(C.fix[8], C.fix[9]), C.fix[10]);
+            const unsigned best = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(C.fix[8], C.fix[9]), C.fix[10]));
             const int tx = __builtin_amdgcn_readlane(px, tl), ty = __builtin_amdgcn_readlane(py, tl);
             H3_T(C, 3, tph);
             h3_line<HYBRID>(C, tx, ty, 255 - (int)(best & 0xFF));  // ends with a barrier
@@ -2093,12 +2094,16 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     }
 }
 
-// tiers 0 / 1: one workgroup per listed frame (grid = K; the workgroups beyond the list leave at once)
+// tiers 0 / 1: a machine-sized grid walks the tier's frame list (a pass has thousands of frames and most of them carry no
+// streak: one workgroup per frame would be thousands of workgroups that leave at once, each waiting for its LDS first)
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3(HoughParams P) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
-    if ((int)blockIdx.x >= *P.fcount) return;
-    hough3_frame<false>(P, P.flist[blockIdx.x], 0, lds_dyn);
+    const int count = *P.fcount;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        hough3_frame<false>(P, P.flist[j], 0, lds_dyn);
+        __syncthreads();
+    }
 }
 // tier 2: gridDim.x workgroups walk the list, each with its own slot of the pooled accumulator / mask
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_hybrid(HoughParams P) {
@@ -2108,6 +2113,34 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_hybrid(HoughParams P)
     for (int j = blockIdx.x; j < count; j += gridDim.x) {
         hough3_frame<true>(P, P.flist[j], blockIdx.x, lds_dyn);
         __syncthreads();
+    }
+}
+
+// The per-frame protocol (one frame, results wanted at once): routing, replay (whatever the tier) and result packing of
+// frame 0 in ONE launch -- a pass of one frame is a chain of dependent commands, and every command saved is ~5 us of latency.
+__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, int4* __restrict__ packed, int* __restrict__ off,
+                                                                  int* __restrict__ litcopy) {
+    __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int tier = hough_classify_frame(P, 0, tid);
+        if (tid == 0) lds_dyn[0] = (unsigned)(tier + 1);
+    }
+    __syncthreads();
+    const int tier = (int)lds_dyn[0] - 1;
+    __syncthreads();
+    if (tier == 0 || tier == 1) hough3_frame<false>(P, 0, 0, lds_dyn);
+    else if (tier == 2) hough3_frame<true>(P, 0, 0, lds_dyn);
+    else if (tier == 3 && tid < 64) ppht_one_wave_frame(P, 0, 0, lds_dyn);
+    __threadfence();
+    __syncthreads();
+    const int cnt = min((int)ld_l2((const unsigned*)&P.out_nraw[0]), MAX_LINES);
+    for (int q = tid; q < cnt; q += HOUGH3_THREADS) packed[q] = ((const int4*)P.out_lines)[q];
+    if (tid == 0) {
+        off[0] = 0;
+        off[1] = cnt;
+        litcopy[0] = P.litcount[0];
     }
 }
 

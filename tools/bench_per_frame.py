@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The reference's own protocol, one frame at a time from host memory: detector.update(frame); detector.detect()
-(MetDetPy.py:197-198).  Every call is a host round trip (H2D copy of the frame, ~10 launches, D2H of the results)."""
+"""The reference's own protocol, one frame at a time: detector.update(frame); detector.detect() (MetDetPy.py:197-198), frames in
+pinned host memory.  Prints the rate, the host-side split (update / detect) and the per-stage GPU spans of a frame's pass."""
+import ctypes
 import json
 import os
 import sys
@@ -16,20 +17,41 @@ from metdetpy_amd.synth import SkyStream
 
 def main():
     H, W, n = 1080, 1920, 8
-    frames = SkyStream(H, W, bench.WORKLOADS["C2"]["seed"]).take(300)
+    frames = SkyStream(H, W, bench.WORKLOADS["C2"]["seed"]).take(250)
     det = M3Detector(1, n, np.ones((H, W), np.uint8), 10, bench.make_cfg(), None, max_batch=8)
-    for f in frames[:40]:
+    ctx = det._ctx
+    pool = ctx.host_alloc(frames.nbytes)
+    ctypes.memmove(pool, frames.ctypes.data, frames.nbytes)
+    pinned = np.ctypeslib.as_array((ctypes.c_uint8 * frames.nbytes).from_address(pool)).reshape(frames.shape)
+    for f in pinned[:40]:
         det.update(f)
         det.detect()
-    t0 = time.perf_counter()
-    segs = 0
-    for f in frames[40:]:
-        det.update(f)
-        lines, _ = det.detect()
-        segs += len(lines)
-    dt = time.perf_counter() - t0
-    print(json.dumps({"protocol": "update(frame) / detect() per frame, host frames", "frame": [W, H], "frames_per_s": (len(frames) - 40) / dt,
-                      "ms_per_frame": dt / (len(frames) - 40) * 1e3, "segments": segs}))
+    out = {}
+    for label, prof in (("plain", False), ("with_stage_events", True)):
+        if prof:
+            ctx.profile_enable(1)
+            ctx.profile_read(True)
+        tu = td = 0.0
+        segs = 0
+        N = 3000
+        t0 = time.perf_counter()
+        for k in range(N):
+            f = pinned[k % len(pinned)]
+            a = time.perf_counter()
+            det.update(f)
+            b = time.perf_counter()
+            lines, _ = det.detect()
+            td += time.perf_counter() - b
+            tu += b - a
+            segs += len(lines)
+        dt = time.perf_counter() - t0
+        out[label] = {"frames_per_s": N / dt, "us_per_frame": dt / N * 1e6, "update_us": tu / N * 1e6, "detect_us": td / N * 1e6, "segments": segs}
+        if prof:
+            out[label]["gpu_span_us"] = {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in ctx.profile_read(True).items() if v[1]}
+            ctx.profile_enable(False)
+    print(json.dumps({"protocol": "update(frame) / detect() per frame, frames in pinned host memory", "frame": [W, H], **out}))
+    del pinned
+    ctx.host_free(pool)
     det.close()
 
 

@@ -43,8 +43,12 @@ for lo, hi in ((1, 50), (50, 200), (200, 500), (500, 1000), (1000, 4000), (4000,
 
 # phase totals of the three-wave kernel (shader cycles, thread 0's view), summed over the frames with points
 names = ["steps (table, list, mask)", "votes", "hits + barrier", "trigger (take back, arg-max)", "line walk", "line clear", "un-vote + emit", "lines"]
+cnt = ph[:, 7].copy()
+ph[:, 7] = cnt & 0xFFFF
+votes, subs = (cnt >> 16) & 0xFFFFFF, cnt >> 40
 tot = ph[act].sum(axis=0)
 cyc = tot[:7].sum()
+print("per frame: votes %.1f  sub-groups %.1f  steps of 64 points %.1f" % (votes[act].mean(), subs[act].mean(), np.ceil(dbg[act, 0] / 64).mean()))
 if cyc > 0:
     print("phase share of PPHT cycles:", {n: round(float(v) / cyc, 3) for n, v in zip(names[:7], tot[:7])}, " line events per frame: %.1f" % (tot[7] / act.sum()),
           " cycles per frame: %.0f" % (cyc / act.sum()), " cycles per line event (walk+clear+un-vote): %.0f" % (tot[4:7].sum() / max(tot[7], 1)))
