@@ -12,7 +12,6 @@ native call (identical results), which is what the throughput numbers are measur
 """
 from __future__ import annotations
 
-import collections
 from abc import ABCMeta, abstractmethod
 from typing import Any, Optional
 
@@ -21,12 +20,10 @@ import numpy as np
 from . import _lib
 from .metstruct import BinaryCfg
 from .utils import select_std_roi
+from .visu import DrawRectVisu, ImgVisuAttrs, SquareColorPair, TextColorPair, TextVisu
 
 NUM_LINES_TOOMUCH = 500
 DEFAULT_INIT_VALUE = 5
-
-VisuItem = collections.namedtuple("VisuItem", ["kind", "name", "attrs"])
-
 
 class BaseDetector(metaclass=ABCMeta):
     """update(frame) / detect() / visu()  (Detector.py:130-157)."""
@@ -189,18 +186,29 @@ class M3Detector(LineDetector):
         return out, info
 
     def visu(self):
-        """Same item names as the reference's visu list (Detector.py:394-448); rendering is out of scope."""
-        x1, y1, x2, y2 = self.stack.std_roi
-        return [
-            VisuItem("img", "mix_bg", dict(img=self.dst // 255, weight=0.5, color="yellow")),
-            VisuItem("text", "std_value", dict(text=f"STD:{self.stack.snr:.4f}")),
-            VisuItem("text", "bi_value",
-                     dict(text=f"Bi_Threshold: {self.bi_threshold} (rounded from {self.bi_threshold_float:.4f})")),
-            VisuItem("text", "lines_num", dict(text=f"Line num: {self.lines_num} (filtered: {self.filtered_line_num})")),
-            VisuItem("text", "area_ratio", dict(text=f"Diff Area: {self.dst_sum:.2f}%")),
-            VisuItem("text", "lines_warning", dict(text="WARNING: TOO MANY LINES!" if self.lines_num > 10 else "")),
-            VisuItem("rect", "std_roi_area", dict(dot_pair=([y1, x1], [y2, x2]), color="purple")),
-        ]
+        """The records of Detector.py:394-448, field for field (tests/golden/g11_visu.json holds what the reference returned).
+        `dst` is fetched from the GPU here, on demand: the per-frame loop never pays for it unless the visualiser runs."""
+        return visu_records(self.dst, self.stack, self.bi_threshold, self.bi_threshold_float, self.lines_num, self.filtered_line_num,
+                            self.dst_sum)
+
+
+def visu_records(dst, stack, bi_threshold, bi_threshold_float, lines_num, filtered_line_num, dst_sum):
+    x1, y1, x2, y2 = [-1] * 4
+    if getattr(stack, "std_roi", None):
+        x1, y1, x2, y2 = stack.std_roi
+
+    def text(name, body, color="green"):
+        return TextVisu(name, position="left-top", color=color, text_list=[TextColorPair(text=body)])
+
+    return [
+        ImgVisuAttrs("mix_bg", img=dst // 255, weight=0.5, color="yellow"),
+        text("std_value", f"STD:{stack.snr:.4f}"),
+        text("bi_value", f"Bi_Threshold: {bi_threshold} (rounded from {bi_threshold_float:.4f})"),
+        text("lines_num", f"Line num: {lines_num} (filtered: {filtered_line_num})"),
+        text("area_ratio", f"Diff Area: {dst_sum:.2f}%"),
+        text("lines_warning", "WARNING: TOO MANY LINES!" if lines_num > 10 else "", color="red"),
+        DrawRectVisu("std_roi_area", pair_list=[SquareColorPair(dot_pair=([y1, x1], [y2, x2]))], color="purple"),
+    ]
 
 
 class ClassicDetector(LineDetector):

@@ -18,6 +18,8 @@ Fixtures
   g7_ema.json             EMA.update series                                             (utils.py:324-368)
   g8_exposure.json        rf_estimator / _rf_est_kernel / sigma_clip / init_exp_time on scripted frame-sum series
                           (videoloader.py:440-494, 796-870; utils.py:516-540)
+  g11_visu.json           M3Detector.visu(): the attribute records handed to the visual manager (Detector.py:394-448,
+                          metvisu.py:74-260), as dataclasses.asdict, for scripted detector states
   g10_mdrf.json           the MDRF document detect_video returns (MetDetPy.py:245-250) as MDRF.to_dict() writes it
                           (metstruct.py:105-111, 428-441): version / basic_info / config / type / anno_size / results /
                           performance, for the reference's config/m3det_*.json presets and two scripted collector runs
@@ -338,6 +340,33 @@ def main():
         g10.append({"preset": preset, "script": script_name, "config_json": cfg_dict, "basic_info": info.to_dict(),
                     "mdrf": doc.to_dict()})
     json.dump(g10, open(os.path.join(HERE, "g10_mdrf.json"), "w"))
+
+    # ---------------------------------------------------------------- G11: visu() attribute records
+    g11 = []
+    for seed, (h, w), roi_on in ((1, (27, 48), True), (2, (54, 96), True), (3, (20, 20), False)):
+        rng = np.random.default_rng(seed)
+        mask = np.ones((h, w), np.uint8)
+        det = D.M3Detector(window_sec=1, fps=4, mask=mask, num_cls=U.get_num_class(),
+                           cfg=MS.BinaryCfg(MS.BinaryCoreCfg(True, 7, "normal", 0.1, 2), MS.HoughLineCfg(10, 10, 10), MS.DynamicCfg(True, 5)),
+                           logger=None)
+        state = dict(dst=((rng.random((h, w)) < 0.05) * 255).astype(np.uint8), snr=float(rng.uniform(0.5, 3)), bi_threshold=int(rng.integers(3, 12)),
+                     bi_threshold_float=float(rng.uniform(3, 12)), lines_num=int(rng.integers(0, 30)), filtered_line_num=int(rng.integers(0, 5)),
+                     dst_sum=float(rng.uniform(0, 0.2)))
+        det.dst = state["dst"]
+        det.stack.noise_ema.cur_value = state["snr"]
+        for k in ("bi_threshold", "bi_threshold_float", "lines_num", "filtered_line_num", "dst_sum"):
+            setattr(det, k, state[k])
+        if not roi_on:
+            det.stack.std_roi = None
+        recs = []
+        for item in det.visu():
+            d = dataclasses.asdict(item)
+            if d.get("img") is not None:
+                d["img"] = np.asarray(d["img"]).tolist()
+            recs.append({"class": type(item).__name__, "fields": d})
+        state["dst"] = state["dst"].tolist()
+        g11.append({"shape": [h, w], "std_roi": list(det.stack.std_roi) if roi_on else None, "state": state, "visu": recs})
+    json.dump(g11, open(os.path.join(HERE, "g11_visu.json"), "w"))
 
     # ---------------------------------------------------------------- G6
     g6 = {"frame2ts": [[f, fps, U.frame2ts(f, fps)] for f in (0, 1, 24, 25, 1499, 90000, 65536)

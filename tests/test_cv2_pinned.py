@@ -1,0 +1,229 @@
+"""The OpenCV side of the hot path against what OpenCV itself returned (tests/golden/g9_cv2_*.npz, written by tools/pin_cv2.py
+on a machine where `cv2` imports).  This image has no cv2 and the reference holds no vectors for these operators, so until
+somebody runs that script once every test here SKIPS with the literal reason "PARITY UNPINNED"; the day the files exist the CPU
+oracle (NumPy and C) and -- under -m gpu -- the HIP path are checked against them bit for bit, with nothing else to change.
+
+The plumbing is not left untested meanwhile: `test_pin_script_round_trip` feeds tools/pin_cv2.py a stand-in module built from
+the oracle and runs the very same checks on what it wrote."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import m3_oracle as mo
+from tests import cv2_cases as cases
+from tests.helpers import binary_cfg, oracle_kwargs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+REASON = ("PARITY UNPINNED: tests/golden/g9_cv2_{}.npz is absent -- run `python tools/pin_cv2.py{}` once on a machine where cv2 "
+          "imports (opencv-python >= 4.9)")
+
+
+def pinned(tag, directory=None):
+    path = os.path.join(directory or os.path.join(ROOT, "tests", "golden"), f"g9_cv2_{tag}.npz")
+    if not os.path.exists(path):
+        pytest.skip(REASON.format(tag, " --reference <MetDetPy checkout>" if tag == "m3" else ""))
+    return np.load(path)
+
+
+# ---- the checks (shared by the real fixtures and the round-trip test) --------------------------------------------------------
+def check_stencil(z, median3, close3, erode3, dilate3):
+    n = 0
+    prev = None
+    for name, img in cases.stencil_inputs():
+        if name.startswith("gray"):
+            assert np.array_equal(median3(img), z[f"{name}/median3"]), name
+            for t in cases.THRESHOLDS:
+                assert np.array_equal(mo.threshold_binary(img, t), z[f"{name}/thr{t}"]), (name, t)
+            if prev is not None and prev.shape == img.shape:
+                assert np.array_equal(mo.absdiff(prev, img), z[f"{name}/absdiff_prev"]), name
+            prev = img
+        else:
+            assert np.array_equal(close3(img), z[f"{name}/close3"]), name
+            assert np.array_equal(erode3(img), z[f"{name}/erode3"]), name
+            assert np.array_equal(dilate3(img), z[f"{name}/dilate3"]), name
+            assert np.array_equal(median3(img), z[f"{name}/median3"]), name
+        n += 1
+    return n
+
+
+def check_hough(z, hough_fn, names=None):
+    n = 0
+    for name, img in cases.hough_inputs():
+        if names and name not in names:
+            continue
+        for (thr, min_len, gap) in cases.HOUGH_PARAMS:
+            want = z[f"{name}/t{thr}_l{min_len}_g{gap}"]
+            got = hough_fn(img, thr, min_len, gap)
+            assert np.array_equal(np.asarray(got).reshape(-1, 4), want), (name, thr, min_len, gap, len(got), len(want))
+            n += 1
+    return n
+
+
+def check_color(z, gray_fn, resize_fn):
+    for name, img in cases.color_inputs():
+        g = gray_fn(img)
+        assert np.array_equal(g, z[f"{name}/gray"]), name
+        for (w, h) in cases.RESIZES[img.shape[:2]]:
+            r = resize_fn(img, (w, h))
+            assert np.array_equal(r, z[f"{name}/resize_{w}x{h}"]), (name, w, h)
+            assert np.array_equal(resize_fn(g, (w, h)), z[f"{name}/resize_gray_{w}x{h}"]), (name, w, h)
+            assert np.array_equal(gray_fn(r), z[f"{name}/gray_of_resize_{w}x{h}"]), (name, w, h)
+
+
+def m3_series(z, tag, sens, step):
+    """Drive `step(frame) -> (lines, cls_pred, bi_threshold, lines_num, dst_sum, dst or None)` over the seeded stream."""
+    from metdetpy_amd.synth import SkyStream
+    S = cases.M3_STREAM
+    stream = SkyStream(S["H"], S["W"], S["seed"], speed=S["speed"], streak_period=S["streak_period"])
+    for t in range(S["frames"]):
+        lines, pred, thr, nraw, dst_sum, dst = step(stream.next())
+        key = f"{tag}_{sens}/{t}"
+        assert np.array_equal(np.asarray(lines, np.int32).reshape(-1, 4), z[f"{key}/lines"]), (key, "lines")
+        assert np.array_equal(np.asarray(pred, np.float64).reshape(len(z[f"{key}/lines"]), -1), z[f"{key}/cls_pred"]), (key, "cls_pred")
+        sc = z[f"{key}/scalars"]
+        assert thr == sc[0] and nraw == sc[1], (key, thr, nraw, sc)
+        if tag == "m3":
+            assert dst_sum == sc[2], (key, dst_sum, sc[2])
+        if dst is not None and f"{key}/dst" in z:
+            assert np.array_equal(np.packbits(dst > 0, axis=1), z[f"{key}/dst"]), (key, "dst")
+
+
+# ---- CPU: the oracle against OpenCV -----------------------------------------------------------------------------------------
+def test_oracle_stencils_equal_cv2():
+    z = pinned("stencil")
+    check_stencil(z, mo.median_blur3, mo.morph_close3, mo.erode3, mo.dilate3)
+    check_stencil(z, co.median3, lambda im: co.erode3(co.dilate3(im)), co.erode3, co.dilate3)
+
+
+def test_oracle_hough_lines_p_equals_cv2():
+    z = pinned("hough")
+    check_hough(z, lambda im, thr, ml, gap: co.hough_lines_p(im, 1, np.pi / 180.0, thr, ml, gap))
+    check_hough(z, lambda im, thr, ml, gap: mo.hough_lines_p(im, 1, np.pi / 180.0, thr, ml, gap), names={"fan", "dashed", "borders", "single", "one_row"})
+
+
+def test_oracle_cvtcolor_and_resize_equal_cv2():
+    check_color(pinned("color"), mo.bgr_to_gray, mo.resize_linear)
+
+
+@pytest.mark.parametrize("sens", cases.M3_STREAM["sensitivities"])
+def test_oracle_m3_detector_equals_reference(sens):
+    z = pinned("m3")
+    S = cases.M3_STREAM
+    mask = np.ones((S["H"], S["W"]), np.uint8)
+    orc = mo.M3Oracle(S["n"], mask, hough_fn=co.hough_lines_p, **oracle_kwargs(binary_cfg(sens)))
+
+    def step(f):
+        orc.update(f)
+        lines, pred = orc.detect()
+        return lines, pred, orc.bi_threshold, orc.lines_num, orc.dst_sum, orc.dst
+
+    m3_series(z, "m3", sens, step)
+
+
+# ---- the script's file format, exercised without OpenCV ----------------------------------------------------------------------
+def oracle_backed_cv2():
+    """A stand-in with the handful of cv2 entry points tools/pin_cv2.py uses, answering with the oracle."""
+    m = types.ModuleType("cv2_stand_in")
+    m.__version__ = "stand-in (oracle)"
+    m.MORPH_RECT, m.MORPH_CLOSE, m.THRESH_BINARY, m.COLOR_BGR2GRAY, m.INTER_LINEAR = 0, 3, 0, 6, 1
+    m.getStructuringElement = lambda shape, ksize: np.ones(ksize[::-1], np.uint8)
+    m.medianBlur = lambda img, k: co.median3(img)
+    m.threshold = lambda img, t, maxval, kind: (float(t), mo.threshold_binary(img, t, maxval))
+    m.morphologyEx = lambda img, op, k: mo.morph_close3(img)
+    m.erode = lambda img, k: co.erode3(img)
+    m.dilate = lambda img, k: co.dilate3(img)
+    m.absdiff = mo.absdiff
+    m.cvtColor = lambda img, code: mo.bgr_to_gray(img)
+    m.resize = lambda img, dsize, interpolation=None: mo.resize_linear(img, dsize)
+
+    def hough(img, rho, theta, thr, minLineLength=0, maxLineGap=0):
+        r = co.hough_lines_p(img, rho, theta, thr, minLineLength, maxLineGap)
+        return None if len(r) == 0 else r.reshape(-1, 1, 4)
+
+    m.HoughLinesP = hough
+    return m
+
+
+def test_pin_script_round_trip(tmp_path):
+    import pin_cv2
+    written = pin_cv2.generate(str(tmp_path), oracle_backed_cv2())
+    assert written == ["g9_cv2_stencil.npz", "g9_cv2_hough.npz", "g9_cv2_color.npz"]
+    assert check_stencil(pinned("stencil", str(tmp_path)), mo.median_blur3, mo.morph_close3, mo.erode3, mo.dilate3) == len(cases.stencil_inputs())
+    assert check_hough(pinned("hough", str(tmp_path)), lambda im, thr, ml, gap: co.hough_lines_p(im, 1, np.pi / 180.0, thr, ml, gap)) == \
+        len(cases.hough_inputs()) * len(cases.HOUGH_PARAMS)
+    check_color(pinned("color", str(tmp_path)), mo.bgr_to_gray, mo.resize_linear)
+
+
+def test_unpinned_fixture_skips_with_the_literal_reason(tmp_path):
+    with pytest.raises(pytest.skip.Exception, match="PARITY UNPINNED"):
+        pinned("hough", str(tmp_path))
+
+
+# ---- GPU: the HIP path against OpenCV ----------------------------------------------------------------------------------------
+def hip_hough(im, thr, min_len, gap):
+    """The Hough stage alone through mdh_hough_planes; mask_area is made huge so that the adaptive gap stays at max_gap."""
+    from metdetpy_amd.bands import BandPlan, HipBandEngine
+    from tests.band_oracle_engine import pack_rows
+    H, W = im.shape
+    plan = BandPlan(H, W, 1, (0, 0, H, W))
+    eng = HipBandEngine(plan, 0, 2, binary_cfg(hough=(thr, int(round(min_len)), int(mo.cv_round(gap)))), 1e15, 1, 0)
+    info, raw, _nms, _prob = eng.hough_stage(pack_rows(im, plan.WW)[None, None], 1)
+    eng.close()
+    return raw[0, :int(info[0]["n_raw"])]
+
+
+@pytest.mark.gpu
+def test_hip_hough_stage_equals_cv2():
+    check_hough(pinned("hough"), hip_hough)
+
+
+@pytest.mark.gpu
+def test_hip_preprocessing_equals_cv2():
+    from metdetpy_amd.imgproc import Preprocessor
+    z = pinned("color")
+    for name, img in cases.color_inputs():
+        p = Preprocessor(img.shape[:2])
+        assert np.array_equal(p(img), z[f"{name}/gray"]), name
+        p.close()
+        for (w, h) in cases.RESIZES[img.shape[:2]]:
+            p = Preprocessor(img.shape[:2], (w, h))
+            assert np.array_equal(p(img), z[f"{name}/gray_of_resize_{w}x{h}"]), (name, w, h)
+            p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sens", cases.M3_STREAM["sensitivities"])
+def test_hip_m3_detector_equals_reference(sens):
+    from metdetpy_amd import M3Detector
+    z = pinned("m3")
+    S = cases.M3_STREAM
+    det = M3Detector(1, S["n"], np.ones((S["H"], S["W"]), np.uint8), 10, binary_cfg(sens), None)
+
+    def step(f):
+        det.update(f)
+        lines, pred = det.detect()
+        return lines, pred, det.bi_threshold, det.lines_num, det.dst_sum, det.dst
+
+    m3_series(z, "m3", sens, step)
+    det.close()
+
+
+@pytest.mark.gpu
+def test_hip_round_trip_through_the_stand_in(tmp_path):
+    """Until the real fixtures exist: the GPU checks run against files written through the oracle-backed stand-in, so that the
+    consuming code above is exercised on the MI355X box too."""
+    import pin_cv2
+    from metdetpy_amd.imgproc import Preprocessor
+    pin_cv2.generate(str(tmp_path), oracle_backed_cv2())
+    assert check_hough(pinned("hough", str(tmp_path)), hip_hough, names={"fan", "dashed", "streaks", "segments", "single", "empty"}) > 0
+    z = pinned("color", str(tmp_path))
+    name, img = cases.color_inputs()[2]
+    for (w, h) in cases.RESIZES[img.shape[:2]]:
+        p = Preprocessor(img.shape[:2], (w, h))
+        assert np.array_equal(p(img), z[f"{name}/gray_of_resize_{w}x{h}"]), (name, w, h)
+        p.close()
