@@ -122,6 +122,8 @@ int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, double* non
 void* mdh_device_alloc(mdh_ctx* ctx, uint64_t bytes);
 int mdh_device_free(mdh_ctx* ctx, void* ptr);
 int mdh_device_upload(mdh_ctx* ctx, void* dst_device, const void* src_host, uint64_t bytes);
+/* device-to-device copy between buffers of this context's GPU (the single-process stand-in of the bit-plane exchange) */
+int mdh_device_copy(mdh_ctx* ctx, void* dst_device, const void* src_device, uint64_t bytes);
 /* Pinned host memory for frames handed over with on_device = 0: the H2D copies of a pass then run asynchronously at PCIe
  * speed (from pageable memory they are staged by the runtime). */
 void* mdh_host_alloc(mdh_ctx* ctx, uint64_t bytes);

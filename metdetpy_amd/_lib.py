@@ -61,7 +61,7 @@ EXPORTS = [
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
-    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free"
+    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy"
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def load():
     L.mdh_host_alloc.restype = vp
     L.mdh_host_free.argtypes = [vp, vp]
     L.mdh_device_upload.argtypes = [vp, vp, vp, u64]
+    L.mdh_device_copy.argtypes = [vp, vp, vp, u64]
     L.mdh_profile_enable.argtypes = [vp, i32]
     L.mdh_profile_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
     L.mdh_kernel_name.argtypes = [i32]
@@ -276,6 +277,9 @@ class Context:
         a = np.ascontiguousarray(arr)
         check(self.L.mdh_device_upload(self.handle, dptr, a.ctypes.data, a.nbytes), "mdh_device_upload")
 
+    def device_copy(self, dst: int, src: int, nbytes: int):
+        check(self.L.mdh_device_copy(self.handle, int(dst), int(src), int(nbytes)), "mdh_device_copy")
+
     def profile_enable(self, on=True):
         check(self.L.mdh_profile_enable(self.handle, int(on)), "mdh_profile_enable")
 
@@ -290,6 +294,7 @@ class Context:
         """Step 1: stage K sub-image frames, return this band's share of the noise sums (2*n_jobs int64)."""
         if on_device:
             ptr = int(frames)
+            assert K is not None
         else:
             if frames.ndim != 3 or frames.shape[1:] != (self.H, self.W) or frames.dtype != np.uint8:
                 raise ValueError(f"frames must be uint8 (K,{self.H},{self.W})")

@@ -90,8 +90,8 @@ class HipBandEngine:
         self.kp_max = -(-int(max_batch) // plan.nbands)
         self.hough = _lib.Context(plan.H, plan.W, 1, base(_lib.MDH_ROLE_HOUGH, (0, 0, 0, 0), self.kp_max), device=device)
 
-    def noise(self, sub_frames):
-        return self.band.band_noise(sub_frames)
+    def noise(self, sub_frames, K=None, on_device=False):
+        return self.band.band_noise(sub_frames, K=K, on_device=on_device)
 
     def pixels(self, sums_total, out=None):
         d = self.plan.bands[self.b]
@@ -176,7 +176,49 @@ class LocalBands:
                 results[i] = _package(self.s.num_cls, hi[j], raw[j], nms[j], prob[j])
         return results, info
 
+    def detect_batch_device(self, sub_ptrs, K: int):
+        """The same three steps with everything resident in HBM: sub_ptrs[b] = device pointer of band b's rows of the K frames
+        ((K, rows_b, W) u8, as `plan.crop` cuts them).  The bit planes go band -> exchange buffer -> Hough context through
+        device-to-device copies (what the all-to-all moves over xGMI when every band has a GPU of its own)."""
+        p = self.s.plan
+        N = p.nbands
+        kp = -(-K // N)
+        if getattr(self, "_xchg_kp", 0) < kp:
+            self._free_xchg()
+            piece = kp * p.band_rows * p.WW * 8
+            ctx = self.engines[0].band
+            self._send = [ctx.device_alloc(N * piece) for _ in range(N)]
+            self._recv = [ctx.device_alloc(N * piece) for _ in range(N)]
+            self._xchg_kp = kp
+        piece = self._xchg_kp * p.band_rows * p.WW * 8
+        parts = [e.noise(sub_ptrs[b], K=K, on_device=True) for b, e in enumerate(self.engines)]
+        total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]
+        thr = [e.pixels(total, out=self._send[b])[1] for b, e in enumerate(self.engines)]
+        ctx = self.engines[0].band
+        live = kp * p.band_rows * p.WW * 8
+        for r in range(N):
+            for b in range(N):
+                ctx.device_copy(self._recv[r] + b * live, self._send[b] + r * live, live)
+        info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
+        results = [None] * K
+        for r, e in enumerate(self.engines):
+            mine = len(range(r, K, N))
+            if mine == 0:
+                continue
+            hi, raw, nms, prob = e.hough_stage(self._recv[r], kp, on_device=True)
+            for j in range(mine):
+                i = j * N + r
+                info[i] = _merge_info(thr[0][i], hi[j])
+                results[i] = _package(self.s.num_cls, hi[j], raw[j], nms[j], prob[j])
+        return results, info
+
+    def _free_xchg(self):
+        for ptr in getattr(self, "_send", []) + getattr(self, "_recv", []):
+            self.engines[0].band.device_free(ptr)
+        self._send, self._recv, self._xchg_kp = [], [], 0
+
     def close(self):
+        self._free_xchg()
         for e in self.engines:
             e.close()
 
@@ -223,14 +265,15 @@ class BandedM3Detector:
         return self._send[:, :kp].contiguous() if kp != self._send.shape[1] else self._send, \
             self._recv[:, :kp].contiguous() if kp != self._recv.shape[1] else self._recv
 
-    def detect_batch(self, sub_frames: np.ndarray):
+    def detect_batch(self, sub_frames, K=None, on_device=False):
+        """sub_frames: this rank's rows of K frames, a (K, rows, W) u8 array -- or a device pointer to them with K given."""
         import torch
         p, N, r = self.plan, self.world, self.rank
-        K = len(sub_frames)
+        K = len(sub_frames) if not on_device else int(K)
         if K > self.max_batch:
             raise ValueError("K exceeds max_batch")
         kp = -(-K // N)
-        total = self._allreduce_sums(self.engine.noise(sub_frames))
+        total = self._allreduce_sums(self.engine.noise(sub_frames, K=K, on_device=on_device))
         if self.dist is None:
             sent, thr_info = self.engine.pixels(total)
             recv, on_dev = sent, False  # world == 1: the send layout of one band IS the receive layout

@@ -1487,6 +1487,12 @@ extern "C" int mdh_device_free(mdh_ctx* c, void* p) {
     HIPCHK(hipFree(p));
     return MDH_OK;
 }
+extern "C" int mdh_device_copy(mdh_ctx* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c || !dst || !src) return MDH_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return MDH_OK;
+}
 extern "C" void* mdh_host_alloc(mdh_ctx* c, uint64_t bytes) {
     if (!c) return nullptr;
     void* p = nullptr;

@@ -58,8 +58,12 @@ def check_hough(z, hough_fn, names=None):
             continue
         for (thr, min_len, gap) in cases.HOUGH_PARAMS:
             want = z[f"{name}/t{thr}_l{min_len}_g{gap}"]
-            got = hough_fn(img, thr, min_len, gap)
-            assert np.array_equal(np.asarray(got).reshape(-1, 4), want), (name, thr, min_len, gap, len(got), len(want))
+            got = np.asarray(hough_fn(img, thr, min_len, gap)).reshape(-1, 4)
+            cap = getattr(hough_fn, "cap", None)  # the library keeps MDH_MAX_LINES segments per frame and reports the full count
+            if cap is not None and len(want) > cap:
+                assert hough_fn.last_count == len(want) and np.array_equal(got[:cap], want[:cap]), (name, thr, min_len, gap)
+            else:
+                assert np.array_equal(got, want), (name, thr, min_len, gap, len(got), len(want))
             n += 1
     return n
 
@@ -174,7 +178,11 @@ def hip_hough(im, thr, min_len, gap):
     eng = HipBandEngine(plan, 0, 2, binary_cfg(hough=(thr, int(round(min_len)), int(mo.cv_round(gap)))), 1e15, 1, 0)
     info, raw, _nms, _prob = eng.hough_stage(pack_rows(im, plan.WW)[None, None], 1)
     eng.close()
-    return raw[0, :int(info[0]["n_raw"])]
+    hip_hough.last_count = int(info[0]["n_raw"])
+    return raw[0, :min(hip_hough.last_count, hip_hough.cap)]
+
+
+hip_hough.cap = 512
 
 
 @pytest.mark.gpu

@@ -38,3 +38,36 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert c["single_thread"]["c_port"] > 0 and c["single_thread"]["numpy_oracle"] > 0 and "1" in c["c_port_by_threads"]
     assert d["parity"]["verdict"] == "identical" and d["parity"]["frames_checked"] == 48
+
+
+def _run(args, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_per_frame_protocol_entry():
+    d = _run(["--protocol", "per-frame", "--steps", "300", "--cpu-seconds", "0", "--parity-frames", "32"])
+    assert d["config"]["frames_per_step"] == 1 and "update(frame) / detect()" in d["config"]["workload"]
+    assert d["value"] > 1000 and d["parity"]["verdict"] == "identical" and d["detections"]["raw_segments"] > 0
+
+
+def test_bench_row_band_mode_on_one_device():
+    d = _run(["--mode", "bands", "--workload", "C1s", "--shards", "4", "--batch", "32", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"])
+    assert d["scaling"] == "strong" and d["bands"]["bands"] == 4 and d["config"]["parallelism"] == "bands x1"
+    assert d["parity"]["verdict"] == "identical" and d["steps"] == 3 and d["value"] > 0
+
+
+def test_bench_time_window_mode_on_one_device():
+    d = _run(["--mode", "timeshard", "--workload", "C1s", "--shards", "3", "--batch", "32", "--steps", "4", "--cpu-seconds", "0"])
+    assert d["scaling"] == "strong" and d["timeshard"]["windows"] == 3 and d["timeshard"]["frames"] == 128
+    assert d["parity"]["verdict"] == "identical" and d["detections"]["raw_segments"] > 0
+
+
+def test_bench_config1_end_to_end_workload():
+    d = _run(["--workload", "C1e", "--batch", "32", "--steps", "4", "--warmup", "1", "--unique", "32", "--cpu-seconds", "0", "--parity-frames", "24"])
+    assert "BGR" in d["config"]["workload"] and d["config"]["frame"] == [960, 540]
+    assert d["parity"]["verdict"] == "identical" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["detections"]["raw_segments"] > 0
