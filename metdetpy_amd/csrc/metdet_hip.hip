@@ -99,6 +99,7 @@ struct Slot {
     std::vector<ProfSpan> spans;
     // the pass occupying the slot
     bool busy = false, used = false;
+    bool host_complete = false;  // the pass wrote its whole result block into host memory itself (k_hough_single)
     int K = 0;
     int64_t t_base = 0;
 };
@@ -131,7 +132,7 @@ struct mdh_ctx {
     HoughSet hset[NHSET];
     hipEvent_t ev_base = nullptr;  // MDH_HOST_LOG: origin of the GPU-side span times
     unsigned tag_lds = 0;  // MDH_TAG_PASS=1: dynamic LDS bytes that tag a pass's kernels in a rocprofv3 trace (1024 * (1 + pass % 3))
-    int nhset = 2;
+    int nhset = 1;  // (one set since the three-wave PPHT: the stage is short, and every extra stream costs the command processor)
     int nmain = 2;  // main streams in use (MDH_MAIN_STREAMS): with 2, the window kernel of pass p+1 ramps up while that of pass p drains
     int64_t pass_seq = 0;
     hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
@@ -379,7 +380,7 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_state, 1));
     for (int hi = 0; hi < c->nhset && hough; ++hi) {
         HoughSet& h = c->hset[hi];
-        h.pool = (int)std::min<size_t>(K, 64);
+        h.pool = (int)std::min<size_t>(K, 256);  // one hybrid workgroup per CU (it takes the whole LDS)
         h.pool_list = (int)std::min<size_t>(K, 16);
         TRY(dev_alloc(h.d_work, (size_t)h.pool * words));
         TRY(dev_alloc(h.d_accum, (size_t)h.pool * NUM_ANGLE * c->numrho));
@@ -451,6 +452,7 @@ static int create_impl(mdh_ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)k_hough3, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
     HIPCHK(hipFuncSetAttribute((const void*)k_hough3_hybrid, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
     HIPCHK(hipFuncSetAttribute((const void*)k_hough_single, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
     const float theta = (float)(3.14159265358979323846 / 180.0);
@@ -552,6 +554,10 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     c->hough_serial = env_on("MDH_HOUGH_SERIAL");
     c->hough_global_acc = env_on("MDH_HOUGH_GLOBAL_ACC");
     c->hough_one_wave = env_on("MDH_HOUGH_ONE_WAVE") || c->hough_serial;
+    // Hough buffer / stream sets: one is enough while a pass's Hough stage is much shorter than its window kernel (1080p: +7 %
+    // over two sets, fewer streams for the command processor to juggle); at 8K the hybrid frames make the stage as long as the
+    // pixel stages and a second set lets two passes' Hough stages overlap (+15 %).
+    c->nhset = (size_t)H * W > (size_t)12 << 20 ? 2 : 1;
     if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
@@ -858,10 +864,15 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // (dst of this slot is all-zero again: k_pass_prepare ran before ev_noise, which the window kernel waited for)
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_MORPH, post);
+        if (c->lean && K == 1) {
+            hipLaunchKernelGGL(k_morph_close_frame, dim3((unsigned)((nb * c->WW + 63) / 64)), dim3(64), 0, post, sl.d_bbits, sl.d_bandflag, c->d_act,
+                               sl.d_nzlist, sl.d_nzcount, g);
+        } else {
         hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_bandflag,
                            sl.d_worklist, sl.d_nzcount + 1, g);
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_nzcount + 1, c->d_act,
                            sl.d_nzlist, sl.d_nzcount, g);
+        }
         span_end(c, post);
         EV_REC(c, sl.ev_close, post);
         // the dynamic mask looks n-1 frames back: the previous pass's binaries (written on another post stream when the
@@ -921,13 +932,13 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         // the per-frame protocol: routing + replay + packing in one launch (k_hough_single), then the one result copy
         P.lds_small = P.lds_large;
         P.lds_bytes = P.lds_large;
+        SingleResult R{sl.h_off, sl.h_nraw, sl.h_litcount, sl.h_gap, sl.h_fscal, (int4*)sl.h_lines, sl.d_fscal};
         hipLaunchKernelGGL(k_hough_single, dim3(1), dim3(HOUGH3_THREADS), std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned)),
-                           hstream[0], P, (int4*)sl.d_packed, sl.d_off, sl.d_litcopy);
+                           hstream[0], P, R);
         span_end(c, hstream[0]);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(sl.h_res, sl.d_res, sl.res_lines_off + sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K,
-                              hipMemcpyDeviceToHost, hstream[0]));
         HIPCHK(hipEventRecord(sl.ev_done, hstream[0]));
+        sl.host_complete = true;
         hs.last_slot = (int)(&sl - c->slot);
         c->prev_slot = (int)(&sl - c->slot);
         c->pass_seq += 1;
@@ -980,6 +991,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
 }
 
 static int run_detect(mdh_ctx* c, Slot& sl, int K) {
+    sl.host_complete = false;
     const int rc = run_pixels(c, sl, K);
     return rc != MDH_OK ? rc : run_hough(c, sl, K);
 }
@@ -1136,7 +1148,7 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
     spans_collect(c, sl);
     // the head of the packed segment array came with the scalars; fetch the tail if there is one
     const size_t head = (size_t)std::min(PACK_HEAD, MAX_LINES) * K, total = (size_t)sl.h_off[K];
-    if (total > head) {
+    if (total > head && !sl.host_complete) {
         HIPCHK(hipMemcpyAsync(sl.h_lines + 4 * head, sl.d_packed + 4 * head, sizeof(int) * 4 * (total - head), hipMemcpyDeviceToHost,
                               c->cstream));
         HIPCHK(hipStreamSynchronize(c->cstream));

@@ -652,12 +652,9 @@ __device__ __forceinline__ u128 hor_and3_open(u128 d, const Win& q) {
 // bits (border replication can count a sample twice per axis) the whole output block is zero and nothing is stored
 // for it (absent words read as zero).  The blocks that may produce output are compacted into a work list, so that
 // the stencil kernel runs with full waves instead of a few live lanes per wave.
-__global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
-                                                      unsigned* __restrict__ workcount, PassGeom g) {
-    RAISE_WAVE_PRIORITY();
-    const int i = blockIdx.y;
+// (device function: frame i, block `tid` of the frame; whole waves call it together -- k_post_single walks a frame with one workgroup)
+__device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ blockcnt, const PassGeom& g, int i, int tid) {
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     if (tid < nb * g.WW) {
         const int band = tid / g.WW, w = tid - band * g.WW;
@@ -675,6 +672,12 @@ __global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict
         const unsigned mx = (w == 0 || 64 * (w + 1) + 3 > g.W - 1) ? 2u : 1u;
         keep = total * my * mx >= 5u;
     }
+    return keep;
+}
+__device__ __forceinline__ void morph_select_block(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
+                                                   unsigned* __restrict__ workcount, const PassGeom& g, int i, int tid) {
+    const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const bool keep = morph_block_keep(blockcnt, g, i, tid);
     const u64 m = __ballot(keep);
     if (!m) return;
     const int lane = threadIdx.x & 63;
@@ -683,16 +686,17 @@ __global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict
     base = __shfl(base, 0);
     if (keep) worklist[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
 }
+__global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
+                                                      unsigned* __restrict__ workcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+    morph_select_block(blockcnt, worklist, workcount, g, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // One thread owns one listed block (a word column x a band of RB rows) and slides down it with 3-row pipelines.
-__global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
-                                                    const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
-                                                    unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
-    RAISE_WAVE_PRIORITY();
+__device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbits, unsigned item, ActWord* __restrict__ act_ring,
+                                                 unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, const PassGeom& g) {
   const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
-  const unsigned nwork = *workcount;
-  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < nwork; e += gridDim.x * blockDim.x) {
-    const unsigned item = worklist[e];
+  {
     const int i = item / (unsigned)(nb * g.WW);
     const int tid = item - (unsigned)i * (unsigned)(nb * g.WW);
     const int band = tid / g.WW, w = tid - band * g.WW;
@@ -737,6 +741,26 @@ __global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ 
     }
   }
 }
+__device__ __forceinline__ void morph_close_items(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
+                                                  unsigned nwork, ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
+                                                  unsigned* __restrict__ nzcount, const PassGeom& g, unsigned first, unsigned stride) {
+    for (unsigned e = first; e < nwork; e += stride) morph_close_item(bbits, worklist[e], act_ring, nzlist, nzcount, g);
+}
+// One frame (the per-frame protocol): every block tests its own neighbourhood and goes ahead -- no work list, one launch less
+// in the frame's chain of dependent commands.
+__global__ void __launch_bounds__(64) k_morph_close_frame(const ActWord* __restrict__ bbits, const unsigned* __restrict__ blockcnt,
+                                                          ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
+                                                          unsigned* __restrict__ nzcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (morph_block_keep(blockcnt, g, 0, tid)) morph_close_item(bbits, (unsigned)tid, act_ring, nzlist, nzcount, g);
+}
+__global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
+                                                    const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
+                                                    unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+    morph_close_items(bbits, worklist, *workcount, act_ring, nzlist, nzcount, g, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 // a8 + a9 count.  Dynamic mask (Detector.py:234-242): a pixel is "alive" unless it was lit in ALL of the last
 // len = min(n, t) binaries (sum of the last len binaries <= (len-1)*255);  dst = act & erode3x3(alive).
@@ -751,18 +775,15 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {
 // SIXTEEN LANES PER LISTED WORD (four words per wave): lane 3 * (dy + 1) + (k + 1) of a group fetches word w + k of row
 // y + dy from each of the len history frames (independent loads) and ANDs them; the 3x3 erode is finished by lanes 1,
 // 4, 7 of the group (one per row) and lane 0 stores the result.
-__global__ void __launch_bounds__(256) k_dy_sparse(const ActWord* __restrict__ act_ring, u64* __restrict__ dst_bits,
-                                                   const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount,
-                                                   int* __restrict__ rowcount, int* __restrict__ litcount,
-                                                   int* __restrict__ bbox, PassGeom g, int use_dy) {
-    RAISE_WAVE_PRIORITY();
+// (device function: `first_e` = this 16-lane group's first list entry, `ngroups` = groups walking the list)
+__device__ __forceinline__ void dy_sparse_items(const ActWord* __restrict__ act_ring, u64* __restrict__ dst_bits,
+                                                const unsigned* __restrict__ nzlist, unsigned total, int* __restrict__ rowcount,
+                                                int* __restrict__ litcount, int* __restrict__ bbox, const PassGeom& g, int use_dy,
+                                                unsigned first_e, unsigned ngroups) {
     const int words = g.H * g.WW;
-    const unsigned total = *nzcount;
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15, gbase = lane & 48;
-    const unsigned ngroups = gridDim.x * (blockDim.x >> 4);
     const int dy = sub / 3 - 1, k = sub % 3 - 1;  // sub >= 9: idle
-    const unsigned first_e = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     // all lanes of a wave run the same number of iterations (shuffles inside)
     for (unsigned e0 = first_e - (lane >> 4); e0 < total; e0 += ngroups) {
         const unsigned e = e0 + (lane >> 4);
@@ -813,6 +834,14 @@ __global__ void __launch_bounds__(256) k_dy_sparse(const ActWord* __restrict__ a
             atomicMax(&bbox[4 * i + 3], y);
         }
     }
+}
+__global__ void __launch_bounds__(256) k_dy_sparse(const ActWord* __restrict__ act_ring, u64* __restrict__ dst_bits,
+                                                   const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount,
+                                                   int* __restrict__ rowcount, int* __restrict__ litcount,
+                                                   int* __restrict__ bbox, PassGeom g, int use_dy) {
+    RAISE_WAVE_PRIORITY();
+    dy_sparse_items(act_ring, dst_bits, nzlist, *nzcount, rowcount, litcount, bbox, g, use_dy, (blockIdx.x * blockDim.x + threadIdx.x) >> 4,
+                    gridDim.x * (blockDim.x >> 4));
 }
 
 // dst (per slot, [K][H][WW]) is written only where it is non-zero, on an all-zero background; this restores the
@@ -1986,37 +2015,6 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     if (HYBRID) mask_lds = mask_dw <= budget_dw / 4;  // a huge bounding box: the mask stays in global memory, the LDS goes to the cells
     unsigned* cells = lmask + (mask_lds ? mask_dw : 0);
     const int cell_cap = HYBRID ? (P.no_lds_acc ? 0 : 2 * (budget_dw - (mask_lds ? mask_dw : 0))) : 0x7FFFFFFF;
-    // ---- rho windows from the bounding box: rho is monotone in x and in y for a fixed angle, so its extremes are at the corners
-    int w_lo = 0, w_size = 0;
-    float tc = 0.f, ts = 0.f;
-    if (tid < NUM_ANGLE) {
-        tc = P.trig[2 * tid];
-        ts = P.trig[2 * tid + 1];
-        const int r00 = rho_bin(bx0, by0, tc, ts, 0), r10 = rho_bin(bx1, by0, tc, ts, 0);
-        const int r01 = rho_bin(bx0, by1, tc, ts, 0), r11 = rho_bin(bx1, by1, tc, ts, 0);
-        w_lo = min(min(r00, r10), min(r01, r11));
-        w_size = max(max(r00, r10), max(r01, r11)) - w_lo + 1;
-    }
-    int placed = w_size, total = 0;
-    if (HYBRID) {
-        // the smallest windows first (the angles across the streak, where the votes pile up): largest size limit that fits
-        h3_scan(w_size, total, fix + 32, lane, wave);
-        if (total > cell_cap) {
-            int lo = 0, hi = P.numrho;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                int sum;
-                h3_scan(w_size <= mid ? w_size : 0, sum, fix + 32, lane, wave);
-                if (sum <= cell_cap) lo = mid; else hi = mid - 1;
-            }
-            placed = w_size <= lo ? w_size : 0;
-        }
-    }
-    const int off = h3_scan(placed, total, fix + 32, lane, wave);
-    const int cell_dw = (total + 1) / 2;
-    // ---- initialise: cells at the bias, one private zero cell per thread for the spare lanes, mailboxes
-    for (int p = tid; p < cell_dw; p += HOUGH3_THREADS) cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
-    cells[cell_dw + tid] = 0;
     if (tid < HOUGH3_FIXED_DWORDS) fix[tid] = 0;
     // ---- row-major point list + working mask from the words of the bounding box
     const size_t words = (size_t)P.H * P.WW;
@@ -2054,6 +2052,65 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
         __threadfence();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads();
+    // ---- rho windows from the bounding box: rho is monotone in x and in y for a fixed angle, so its extremes are at the corners
+    int w_lo = 0, w_size = 0;
+    float tc = 0.f, ts = 0.f;
+    if (tid < NUM_ANGLE) {
+        tc = P.trig[2 * tid];
+        ts = P.trig[2 * tid + 1];
+        const int r00 = rho_bin(bx0, by0, tc, ts, 0), r10 = rho_bin(bx1, by0, tc, ts, 0);
+        const int r01 = rho_bin(bx0, by1, tc, ts, 0), r11 = rho_bin(bx1, by1, tc, ts, 0);
+        w_lo = min(min(r00, r10), min(r01, r11));
+        w_size = max(max(r00, r10), max(r01, r11)) - w_lo + 1;
+    }
+    int placed = w_size, total = 0;
+    if (HYBRID) {
+        h3_scan(w_size, total, fix + 32, lane, wave);
+        if (total > cell_cap && cell_cap > 0) {
+            // The corner windows do not fit.  A streak is thin and usually oblique, so the rho range its points really span is
+            // up to a third smaller than what the corners of its bounding box span: one sweep over the point list (the cost
+            // of voting every point once) gives the exact window of every angle.
+            int rmin = 0x7FFFFFFF, rmax = -0x7FFFFFFF;
+            if (tid < NUM_ANGLE) {
+                int p = 0;
+                for (; p + 4 <= N; p += 4) {
+                    const uint4 q = *(const uint4*)&list[p];
+                    const int r0 = rho_bin(q.x & 0xFFFF, q.x >> 16, tc, ts, 0), r1 = rho_bin(q.y & 0xFFFF, q.y >> 16, tc, ts, 0);
+                    const int r2 = rho_bin(q.z & 0xFFFF, q.z >> 16, tc, ts, 0), r3 = rho_bin(q.w & 0xFFFF, q.w >> 16, tc, ts, 0);
+                    rmin = min(min(rmin, min(r0, r1)), min(r2, r3));
+                    rmax = max(max(rmax, max(r0, r1)), max(r2, r3));
+                }
+                for (; p < N; ++p) {
+                    const unsigned q = list[p];
+                    const int r = rho_bin(q & 0xFFFF, q >> 16, tc, ts, 0);
+                    rmin = min(rmin, r);
+                    rmax = max(rmax, r);
+                }
+                w_lo = rmin;
+                w_size = rmax - rmin + 1;
+            }
+            placed = w_size;
+            h3_scan(w_size, total, fix + 32, lane, wave);
+        }
+        if (total > cell_cap) {
+            // still too many: the smallest windows first (the angles across the streak, where the votes pile up) -- the largest
+            // size limit that fits; the other angles use the pooled global accumulator
+            int lo = 0, hi = P.numrho;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                int sum;
+                h3_scan(w_size <= mid ? w_size : 0, sum, fix + 32, lane, wave);
+                if (sum <= cell_cap) lo = mid; else hi = mid - 1;
+            }
+            placed = w_size <= lo ? w_size : 0;
+        }
+    }
+    const int off = h3_scan(placed, total, fix + 32, lane, wave);
+    const int cell_dw = (total + 1) / 2;
+    // ---- initialise: cells at the bias, one private zero cell per thread for the spare lanes
+    for (int p = tid; p < cell_dw; p += HOUGH3_THREADS) cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
+    cells[cell_dw + tid] = 0;
     __syncthreads();
     Hough3 C{P, tc, ts, tid < NUM_ANGLE ? 1u : 0u, 0, true, nullptr, cells, mask_lds, lmask, by0, rows, 2 * wlo, 2 * wpr, gmask, P.WW,
              (int)rint(P.out_gap[i]), i, 0, lane, wave, tid, fix, uv, false, P.dbg_phase != nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
@@ -2118,8 +2175,14 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_hybrid(HoughParams P)
 
 // The per-frame protocol (one frame, results wanted at once): routing, replay (whatever the tier) and result packing of
 // frame 0 in ONE launch -- a pass of one frame is a chain of dependent commands, and every command saved is ~5 us of latency.
-__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, int4* __restrict__ packed, int* __restrict__ off,
-                                                                  int* __restrict__ litcopy) {
+struct SingleResult {  // the pass's result block in (pinned, device-visible) HOST memory: no copy command behind the kernel
+    int *off, *nraw, *lit;
+    double* gap;
+    FrameScalars* fscal;
+    int4* packed;
+    const FrameScalars* d_fscal;  // the frame's scalars as the noise chain left them
+};
+__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, SingleResult R) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int tid = threadIdx.x;
@@ -2135,13 +2198,18 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, 
     else if (tier == 3 && tid < 64) ppht_one_wave_frame(P, 0, 0, lds_dyn);
     __threadfence();
     __syncthreads();
-    const int cnt = min((int)ld_l2((const unsigned*)&P.out_nraw[0]), MAX_LINES);
-    for (int q = tid; q < cnt; q += HOUGH3_THREADS) packed[q] = ((const int4*)P.out_lines)[q];
+    const int n_raw = (int)ld_l2((const unsigned*)&P.out_nraw[0]);
+    const int cnt = min(n_raw, MAX_LINES);
+    for (int q = tid; q < cnt; q += HOUGH3_THREADS) R.packed[q] = ((const int4*)P.out_lines)[q];
     if (tid == 0) {
-        off[0] = 0;
-        off[1] = cnt;
-        litcopy[0] = P.litcount[0];
+        R.off[0] = 0;
+        R.off[1] = cnt;
+        R.nraw[0] = n_raw;
+        R.lit[0] = P.litcount[0];
+        R.gap[0] = P.out_gap[0];
+        R.fscal[0] = R.d_fscal[0];
     }
+    __threadfence_system();
 }
 
 // ------------------------------------------------------------------------------------------------

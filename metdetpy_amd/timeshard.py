@@ -144,6 +144,10 @@ class TimeShard:
             due = [t for t in range(lo + 1, hi + 1) if due_frames(t, n, itv)]
             tot = np.array([v for t in due for v in table[t][1:]], np.int64)
             planes, thr_info = self.engine.pixels(tot)
+            if lo < self.start:
+                # warm-up frames: their window starts empty, so their binaries are dense garbage; the results are dropped anyway,
+                # and replaying HoughLinesP on a million points per frame would dominate the window's run time
+                planes[:, :min(K, self.start - lo)] = 0
             hinfo, raw, nms, prob = self.engine.hough_stage(planes, K)
             for j in range(K):
                 i = lo + j

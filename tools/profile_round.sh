@@ -1,26 +1,28 @@
 #!/bin/bash
-# Round profile of bench.py's default workload on the GPU box:  bash tools/profile_round.sh <tag>   (e.g. r01)
+# Round profile of a bench.py workload on the GPU box:  bash tools/profile_round.sh <tag> [workload]   (e.g. r02 C2)
 #   1. rocprofv3 --kernel-trace --stats          -> per-kernel durations (profiles/<tag>_rocprofv3_kernel_stats.csv)
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE    -> HBM traffic per launch, separate passes (MI355X_MICROARCH.md, HBM section)
 # Outputs land in gpurun_out/profile_<tag>/; copy the summaries into profiles/.
 set -u
 TAG=${1:-r01}
-OUT=gpurun_out/profile_$TAG
+WL=${2:-C2}
+OUT=gpurun_out/profile_${TAG}_$WL
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --steps 8 --warmup 2 --cpu-seconds 0 --parity-frames 0"
+ARGS="bench.py --workload $WL --steps 8 --warmup 2 --cpu-seconds 0 --parity-frames 0 --standalone-passes 0"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r --output-format csv -- python $ARGS > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o r --output-format csv -- python $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o r --output-format csv -- python $ARGS > "$OUT/write.log" 2>&1
-python - "$OUT" "$TAG" <<'PY'
-import csv, glob, json, sys, collections, shutil
-out, tag = sys.argv[1], sys.argv[2]
+python - "$OUT" "$TAG" "$WL" <<'PY'
+import csv, glob, json, sys, collections, shutil, os
+sys.path.insert(0, os.getcwd())
+out, tag, wl = sys.argv[1], sys.argv[2], sys.argv[3]
 def one(pattern):
     f = glob.glob(pattern, recursive=True)
     return f[0] if f else None
 stats = one(f"{out}/stats/**/*kernel_stats.csv")
 if stats:
-    shutil.copy(stats, f"{out}/{tag}_rocprofv3_kernel_stats.csv")
+    shutil.copy(stats, f"{out}/{tag}_rocprofv3_kernel_stats_{wl}.csv")
 def per_kernel(path, counter):
     acc, cnt, seen = collections.defaultdict(float), collections.Counter(), set()
     for row in csv.DictReader(open(path)):
@@ -32,8 +34,8 @@ def per_kernel(path, counter):
             seen.add((k, row["Dispatch_Id"])); cnt[k] += 1
     return {k: (acc[k] / cnt[k], cnt[k]) for k in acc}
 fetch, write = one(f"{out}/fetch/**/*counter_collection.csv"), one(f"{out}/write/**/*counter_collection.csv")
-res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py defaults (C2: 1920x1080, n = 8, 1024 frames per "
-               "launch). FETCH_SIZE (KB) is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-byte requests of wide coalesced "
+import bench
+res = {"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload {wl} at its default batch. FETCH_SIZE (KB) is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-byte requests of wide coalesced "
                "reads at 64 bytes); WRITE_SIZE taken as reported (uncalibrated).", "kernels": {}}
 if fetch and write:
     F, Wr = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
@@ -44,7 +46,8 @@ if fetch and write:
                              "hbm_read_bytes_per_launch": int(F[k][0] * 1024 * 2), "hbm_write_bytes_per_launch": int(Wr[k][0] * 1024)}
         if "stack_threshold" in k:
             res["stack_threshold_bytes_per_launch"] = res["kernels"][k]["hbm_read_bytes_per_launch"] + res["kernels"][k]["hbm_write_bytes_per_launch"]
-json.dump(res, open(f"{out}/pmc_traffic_C2.json", "w"), indent=1)
+res["frames_per_launch"] = bench.WORKLOADS[wl]["batch"]
+json.dump(res, open(f"{out}/pmc_traffic_{wl}.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "note"})[:1500])
 PY
-head -12 "$OUT/${TAG}_rocprofv3_kernel_stats.csv" 2>/dev/null | cut -c1-160
+head -14 "$OUT/${TAG}_rocprofv3_kernel_stats_${WL}.csv" 2>/dev/null | cut -c1-160
