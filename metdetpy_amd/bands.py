@@ -273,7 +273,8 @@ class BandedM3Detector:
         if K > self.max_batch:
             raise ValueError("K exceeds max_batch")
         kp = -(-K // N)
-        total = self._allreduce_sums(self.engine.noise(sub_frames, K=K, on_device=on_device))
+        part = self.engine.noise(sub_frames, K=K, on_device=True) if on_device else self.engine.noise(sub_frames)
+        total = self._allreduce_sums(part)
         if self.dist is None:
             sent, thr_info = self.engine.pixels(total)
             recv, on_dev = sent, False  # world == 1: the send layout of one band IS the receive layout
