@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="streams", choices=["streams", "bands", "timeshard"])
     ap.add_argument("--protocol", default="batch", choices=["batch", "per-frame"])
+    ap.add_argument("--detector", default="m3", choices=["m3", "classic"], help="classic: the reference's second line detector "
+                    "(ClassicDetector, Detector.py:245-296: 4-frame ring, fixed threshold 20 here), same stream and harness")
     ap.add_argument("--shards", type=int, default=8, help="--mode bands|timeshard with one process: bands / windows on this device")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--parity-frames", type=int, default=256, help="frames of the stream compared against the CPU oracle "
@@ -72,6 +74,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--standalone-passes", type=int, default=12, help="passes run one at a time after the timed region to "
                     "measure the non-overlapped duration of every kernel (0 = skip)")
+    ap.add_argument("--depth", type=int, default=0, help="passes in flight in the timed region (0 = as many as the library "
+                    "allows; 1 = one at a time: nothing overlaps, the kernel spans are the kernels' own durations)")
     ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive "
                     "rate; never the headline value, see DESIGN.md)")
     return ap.parse_args()
@@ -80,10 +84,47 @@ def parse():
 SENSITIVITY = "normal"
 
 
+DETECTOR = "m3"
+CLASSIC_THRESHOLD = 20  # |x_t - x_(t-1)| of the stream's N(30, 2.5) background has sigma 3.5: 20 keeps the noise out, a +60 streak in
+
+
 def make_cfg():
     from metdetpy_amd import BinaryCfg, BinaryCoreCfg, DynamicCfg, HoughLineCfg
+    if DETECTOR == "classic":  # fixed threshold (the oracle's ClassicOracle restates the detect() half of the class)
+        return BinaryCfg(BinaryCoreCfg(False, CLASSIC_THRESHOLD, SENSITIVITY, 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
     # config/m3det_normal.json (or m3det_high.json) detector block
     return BinaryCfg(BinaryCoreCfg(True, 7, SENSITIVITY, 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
+
+
+def make_detector(n, mask, device, max_batch):
+    from metdetpy_amd import ClassicDetector, M3Detector
+    if DETECTOR == "classic":
+        return ClassicDetector(1, 4.0, mask, 10, make_cfg(), None, device=device, max_batch=max_batch)
+    return M3Detector(1, n, mask, 10, make_cfg(), None, device=device, max_batch=max_batch)
+
+
+def parity_check_classic(frames, mask, local, count):
+    """ClassicDetector vs the NumPy oracle (PPHT from the C port) on the first frames of the stream: lit counts, raw segments."""
+    from oracle import c_oracle as co
+    from oracle import m3_oracle as mo
+    count = min(count, len(frames), 48)
+    det = make_detector(4, mask, local, count)
+    info, raw, _nms, _prob = det._ctx.process_batch(np.ascontiguousarray(frames[:count]))
+    det.close()
+    orc = mo.ClassicOracle(mask, threshold=CLASSIC_THRESHOLD, hough_threshold=10, hough_min_len=10, hough_max_gap=10, hough_fn=co.hough_lines_p)
+    bad, segs = [], 0
+    for i in range(count):
+        orc.update(frames[i])
+        o_lines, _ = orc.detect()
+        lit = int(np.count_nonzero(orc.dst)) if (orc.dst is not None and i >= 3) else 0
+        ok = int(info[i]["n_raw"]) == len(o_lines) and int(info[i]["lit_count"]) == lit and \
+            np.array_equal(raw[i][:min(len(o_lines), 512)], np.asarray(o_lines).reshape(-1, 4)[:512])
+        segs += len(o_lines)
+        if not ok:
+            bad.append(i)
+    return {"frames_checked": count, "raw_segments_checked": segs, "mismatching_frames": bad,
+            "verdict": "identical" if not bad else "MISMATCH",
+            "checked": "lit_count, raw Hough segments (order included) vs oracle/m3_oracle.py ClassicOracle"}
 
 
 def load_mask(H, W):
@@ -268,39 +309,61 @@ def make_stream_frames(wl, rank, mask, B, unique):
 
 
 def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_step, workload):
-    """Physical roofline of the window kernel.  Bytes one launch MUST move: every frame of the pass once plus the n-1
-    frames of history its window starts from, per time chunk (the kernel is blocked over the frames: grid.y chunks each
-    re-read n-1 frames), plus what it stores (tagged words of the sparse difference image: measured, ~0.6 % of the reads)."""
-    out = {"bound": "hbm", "kernel": "stack_threshold", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-    ms, launches = prof_pipe.get("stack_threshold", (0.0, 0))
+    """Physical roofline of the dominant pixel kernel (the window kernel; Classic: the difference kernel).  Bytes one launch
+    MUST move: every frame of the pass once plus the n-1 frames of history its window starts from, per time chunk (the
+    kernel is blocked over the frames: grid.y chunks each re-read n-1 frames).  What it stores (tagged words of the sparse
+    difference image: measured, ~0.6 % of the reads) is not counted.
+
+    `frac` is priced on the NON-OVERLAPPED launch: the kernel's duration with one pass in flight, measured live in this run with
+    HIP events on the library's stream (the `--standalone-passes` leg; `rocprofv3 --kernel-trace --stats` of `bench.py --depth 1`
+    averages the same launches: profiles/*_kernel_stats_*_depth1.csv).  Inside the pipelined timed region two launches of the
+    kernel overlap on the two main streams and share the machine with the other stages of the neighbouring passes, so a
+    launch's span there is about twice as long without the kernel being any slower: that figure is kept as
+    `frac_in_pipeline_per_launch` (what rocprofv3 averages for the default command), and `frac_at_pipeline_pace` prices the same
+    bytes on the time the pipeline spends per pass -- the kernel's real share of the peak in the product."""
+    kern = "classic" if DETECTOR == "classic" else "stack_threshold"
+    out = {"bound": "hbm", "kernel": kern, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    ms, launches = prof_pipe.get(kern, (0.0, 0))
     if not launches:
         return None
     frame = H * W
     words = H * ((W + 63) // 64)
-    waves = -(-words // 16) if W % 64 == 0 and n <= 8 else -(-words // 8)
-    nchunks = max(1, min(-(-4096 // waves), B // (2 * n)))
+    if DETECTOR == "classic":  # launch geometry of run_pixels (metdet_hip.hip)
+        waves = -(-words // 16)
+        nchunks = max(1, min(-(-8192 // waves), B // 8))
+    else:                      # launch_wide: 16 pixels per lane up to n = 16
+        waves = -(-words // 16) if W % 64 == 0 and n <= 16 else -(-words // 8)
+        nchunks = max(1, min(-(-4096 // waves), B // (2 * n)))
     tc = -(-B // nchunks)
     nchunks = -(-B // tc)
     compulsory = frame * (B + nchunks * (n - 1))
     avg_ms = ms / launches
+    frac_of = lambda t_ms: compulsory / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out.update({
-        "achieved": compulsory / (avg_ms * 1e-3) / 1e9, "frac": compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "launch_ms": avg_ms, "launches": launches, "bytes_per_launch": compulsory, "frames_per_launch": B,
+        "bytes_per_launch": compulsory, "frames_per_launch": B,
         "bytes_model": f"H*W*(frames + chunks*(n-1)) = {frame}*({B}+{nchunks}*{n - 1}): each frame byte once per launch plus the "
                        "window history per time chunk; stores (sparse tagged words) not counted",
-        "launch_ms_note": "mean duration of the window-kernel launches of the timed region (HIP events on the library's main "
-                          "stream, every 4th pass); the launches run inside the pipeline, next to the other stages of the "
-                          "neighbouring passes",
-        "frac_at_pipeline_pace": compulsory / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "launch_ms_in_pipeline": avg_ms, "launches_in_pipeline": launches,
+        "frac_in_pipeline_per_launch": frac_of(avg_ms),
+        "launches_overlapping_in_pipeline": avg_ms / ms_per_step,
+        "in_pipeline_note": "mean span of the kernel's launches in the timed region (HIP events on the library's main streams, every "
+                            "4th pass): consecutive launches overlap on the two main streams (MDH_MAIN_STREAMS=1 serialises them: "
+                            "shorter spans, ~10 % fewer frames/s) next to the other stages of the neighbouring passes",
+        "frac_at_pipeline_pace": frac_of(ms_per_step),
         "algorithmic_bytes_per_launch": (n + 1) * frame * B,
-        "algorithmic_frac": (n + 1) * frame * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_note": "SURVEY 8d's (n+1) reads per pixel per frame; the kernel keeps the window in registers and reads "
-                            "each byte once per launch, so this exceeds 1 by design and is not a bandwidth",
+                            "each byte once per launch, so the figure priced on these bytes exceeds 1 by design and is not a bandwidth",
     })
-    if prof_alone and prof_alone.get("stack_threshold", (0, 0))[1]:
-        a_ms = prof_alone["stack_threshold"][0] / prof_alone["stack_threshold"][1]
-        out["launch_ms_standalone"] = a_ms
-        out["frac_standalone"] = compulsory / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if prof_alone and prof_alone.get(kern, (0, 0))[1]:
+        a_ms = prof_alone[kern][0] / prof_alone[kern][1]
+        out.update({"launch_ms": a_ms, "launches": prof_alone[kern][1], "achieved": compulsory / (a_ms * 1e-3) / 1e9, "frac": frac_of(a_ms),
+                    "launch_ms_note": "mean duration of the kernel's launches with ONE pass in flight (nothing overlaps), HIP events on "
+                                      "the library's main stream, measured after the timed region of this run",
+                    "algorithmic_frac": (n + 1) * frame * B / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    else:  # --standalone-passes 0 (or --depth 1, where the timed region itself is non-overlapped)
+        out.update({"launch_ms": avg_ms, "launches": launches, "achieved": compulsory / (avg_ms * 1e-3) / 1e9, "frac": frac_of(avg_ms),
+                    "launch_ms_note": "mean span of the kernel's launches in the timed region (no stand-alone leg in this run)",
+                    "algorithmic_frac": (n + 1) * frame * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     traffic, src = None, None
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
     if os.path.exists(tpath):  # rocprofv3 PMC passes of this workload (tools/profile_round.sh), scaled to this batch
@@ -322,7 +385,7 @@ def run_streams(a, D, wl, mask):
     B = a.batch
     frames = make_stream_frames(wl, D.rank, mask, B, a.unique)
     uniq = len(frames)
-    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=D.local, max_batch=B)
+    det = make_detector(n, mask, D.local, B)
     ctx = det._ctx
     if a.host_input:
         import ctypes
@@ -351,7 +414,7 @@ def run_streams(a, D, wl, mask):
         """nsteps passes, up to ctx.max_in_flight queued: later passes are submitted before earlier ones are collected,
         so the pixel stages of one pass overlap the Hough stage of the previous one and the host stays ahead of the
         GPU.  Every pass is fully collected before run() returns."""
-        depth = depth or ctx.max_in_flight
+        depth = depth or (a.depth if a.depth > 0 else ctx.max_in_flight)
         for _s in range(nsteps):
             if ctx.in_flight >= depth:
                 collect()
@@ -441,8 +504,11 @@ def main():
     D = Dist()
     wl = WORKLOADS[a.workload]
     H, W, n = wl["H"], wl["W"], wl["n"]
-    global SENSITIVITY
+    global SENSITIVITY, DETECTOR
     SENSITIVITY = wl.get("sensitivity", "normal")
+    DETECTOR = a.detector
+    if DETECTOR == "classic":
+        n = 4
     if a.batch is None:
         a.batch = wl["batch"]
     mask = np.ones((H, W), np.uint8)
@@ -482,7 +548,9 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"{a.workload}: {wl['desc']}, m3det_{SENSITIVITY} detector cfg, {shape}"
+        "config": {"workload": f"{a.workload}: {wl['desc']}, "
+                               + (f"ClassicDetector (4-frame ring, fixed threshold {CLASSIC_THRESHOLD})" if DETECTOR == "classic" else f"m3det_{SENSITIVITY} detector cfg")
+                               + f", {shape}"
                                + (" -- INPUT FROM PINNED HOST MEMORY (PCIe-inclusive)" if a.host_input else ""),
                    "frame": [W, H], "window": n, "frames_per_step": B, "stream_period_frames": r["uniq"],
                    "parallelism": f"{a.mode} x{D.world}" if a.mode != "streams" else f"streams x{D.world}"},
@@ -498,10 +566,11 @@ def main():
             if r["prof_alone"]:
                 out["kernels_ms_standalone"] = {k: v[0] / v[1] for k, v in r["prof_alone"].items() if v[1]}
         frames = r["frames_sample"]
-        if D.world == 1 and a.cpu_seconds > 0 and frames is not None:
+        if D.world == 1 and a.cpu_seconds > 0 and frames is not None and DETECTOR == "m3":
             out["cpu_baseline"] = cpu_baseline(frames, n, mask, a.cpu_seconds)
         if D.world == 1 and a.parity_frames > 0 and frames is not None and "parity" not in out:
-            out["parity"] = parity_check(frames, n, mask, D.local, a.parity_frames)
+            out["parity"] = parity_check_classic(frames, mask, D.local, a.parity_frames) if DETECTOR == "classic" else \
+                parity_check(frames, n, mask, D.local, a.parity_frames)
         print(json.dumps(out), flush=True)
     D.close()
 

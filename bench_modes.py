@@ -105,38 +105,55 @@ def run_bands(a, D, wl, mask, cfg):
 
 
 def run_timeshard(a, D, wl, mask, cfg):
+    """ONE stream cut into time windows (the sharding north_star names).  The stream is resident in HBM (as in the stream
+    bench); --host-input reads it from pinned host memory instead (PCIe-inclusive, twice: two sweeps)."""
     import bench
     from metdetpy_amd import _lib
     from metdetpy_amd.timeshard import TimeShard
     H, W, n = wl["H"], wl["W"], wl["n"]
-    B = min(a.batch, 256)
-    base = bench.make_stream_frames(wl, 0, mask, 4 * B, a.unique)
-    uniq = len(base)
-    P = 4 * B
-    pool = None  # the stream: frame i = pool[i % P], materialised once in PINNED host memory so that a pass is a view, not a copy
-    steps = a.steps if a.steps is not None else 64
+    B = min(a.batch, 1024)
+    windows = D.world if D.world > 1 else a.shards
+    steps = a.steps if a.steps is not None else 4 * windows
     total = steps * B
+    base = bench.make_stream_frames(wl, 0, mask, total, a.unique)
+    uniq = len(base)
+    fb = H * W
+    pool = None      # host input: frame i = pool[i % P] in PINNED host memory, so that a pass is a view, not a copy
+    dpool = None     # resident input: frame i at dpool + i * fb
+    P = min(total, 4 * B)
 
     def read(lo, hi):
+        if pool is None:
+            return base[np.arange(lo, hi) % uniq]
         s = lo % P
         if s + (hi - lo) <= P:
             return pool[s:s + (hi - lo)]
         return pool[np.arange(lo, hi) % P]
 
-    windows = D.world if D.world > 1 else a.shards
     ranks = [D.rank] if D.world > 1 else list(range(windows))
-    shards = [TimeShard(1, n, mask, 10, cfg, total, read, rank=r, world=windows, device=D.local, max_batch=B) for r in ranks]
+    shards = [TimeShard(1, n, mask, 10, cfg, total, read, rank=r, world=windows, device=D.local, max_batch=B, scan_batch=min(B, 256))
+              for r in ranks]
     import ctypes
     hctx = shards[0].engine.band
-    pinned = hctx.host_alloc(P * H * W)
-    pool = np.ctypeslib.as_array((ctypes.c_uint8 * (P * H * W)).from_address(pinned)).reshape(P, H, W)
-    for i in range(P):
-        pool[i] = base[i % uniq]
+    pinned = None
+    if a.host_input:
+        pinned = hctx.host_alloc(P * fb)
+        pool = np.ctypeslib.as_array((ctypes.c_uint8 * (P * fb)).from_address(pinned)).reshape(P, H, W)
+        for i in range(P):
+            pool[i] = base[i % uniq]
+    else:
+        dpool = hctx.device_alloc(total * fb)
+        for start in range(0, total, uniq):  # the stream's period repeated
+            cnt = min(uniq, total - start)
+            hctx.device_upload(dpool + start * fb, base[:cnt])
+        for s in shards:
+            s.read_device = lambda lo, hi: dpool + lo * fb
     D.fence()
     t0 = time.perf_counter()
     mine = {}
     for s in shards:  # first sweep: the noise sums of the due frames of every window
         mine.update(s.scan())
+    t_scan = time.perf_counter() - t0
     if D.world > 1:
         tables = [None] * D.world
         D.d.all_gather_object(tables, mine)  # the threshold table: 16 bytes of sums per due frame
@@ -147,7 +164,11 @@ def run_timeshard(a, D, wl, mask, cfg):
         table = mine
     part = []
     for s in shards:  # second sweep: the detector passes of every window
-        part.extend(s.finish(table))
+        blk = s.finish_blocks(table)
+        if blk is None:
+            part.extend(s.finish(table))
+        else:
+            part.extend(("block",) + b for b in blk)
     if D.world > 1:
         gathered = [None] * D.world if D.rank == 0 else None
         D.d.gather_object(part, gathered, dst=0)  # the final detection gather
@@ -157,22 +178,36 @@ def run_timeshard(a, D, wl, mask, cfg):
     dt = time.perf_counter() - t0
     dt_all, _ = D.max_time_and_sum(dt, [0, 0, 0])
     first = read(0, min(64, total)).copy()
-    del pool
-    hctx.host_free(pinned)
+    if pinned is not None:
+        del pool
+        pool = None
+        hctx.host_free(pinned)
+    if dpool is not None:
+        hctx.device_free(dpool)
     for s in shards:
         s.close()
     tally = [0, 0, 0]
-    extra = {"timeshard": {"windows": windows, "frames": total, "warm_up_frames_per_window": 2 * (n - 1),
-                           "note": "every window reads its frames from HOST memory (PCIe-inclusive, twice: two sweeps); first sweep = noise sums of "
-                                   "the due frames (all-gathered table, 16 B per due frame), second sweep = the detector passes; three blocking "
-                                   "calls per pass"}}
+    extra = {"timeshard": {"windows": windows, "frames": total, "warm_up_frames_per_window": 2 * (n - 1), "first_sweep_s": t_scan,
+                           "input": "pinned host memory (PCIe-inclusive, twice: two sweeps)" if a.host_input else "resident in HBM",
+                           "note": "first sweep = noise sums of the due frames of every window (all-gathered table, 16 B per due frame); second "
+                                   "sweep = the pipelined detector passes of every window on a context positioned with mdh_seek "
+                                   "(+ mdh_inject_sums for the sigmas that fall into the refilling window, Hough muted over the warm-up)"}}
     if D.rank == 0:
         info = np.zeros(total, _lib.FRAME_INFO_DTYPE)
         results = [None] * total
+        empty = (np.array([]), np.zeros((0, 10)))
         for chunk in gathered:
-            for i, fi, lines, pred in chunk:
-                info[i] = fi
-                results[i] = (lines, pred)
+            for rec in chunk:
+                if rec[0] == "block":
+                    _tag, f0, binfo, hit, off = rec
+                    info[f0:f0 + len(binfo)] = binfo
+                    for j, lp in hit.items():
+                        results[f0 - off + j] = lp
+                else:
+                    i, fi, lines, pred = rec
+                    info[i] = fi
+                    results[i] = (lines, pred)
+        results = [r if r is not None else empty for r in results]
         tally = [int(info["n_raw"].sum()), int(info["n_nms"].sum()), int(info["lit_count"].sum())]
         if a.parity_frames > 0:
             cnt = min(a.parity_frames, 64, total)

@@ -61,7 +61,19 @@ typedef struct mdh_cfg {
     int32_t max_batch;           /* largest K accepted by one internal pass of mdh_process_batch (0 -> 64) */
     int32_t role;                /* MDH_ROLE_* */
     double mask_area;            /* float(np.sum(mask)) (Detector.py:191) */
+    int32_t hough_mode;          /* MDH_HOUGH_* : 0 = exact replay of cv2.HoughLinesP (the parity path), 1 = full accumulator */
+    int32_t reserved;            /* 0 */
 } mdh_cfg;
+
+/* hough_mode.  MDH_HOUGH_EXACT replays OpenCV's progressive probabilistic transform (same random visiting order, same
+ * segments in the same order: Detector.py:347-353).  MDH_HOUGH_ACCUMULATOR is a different, order-free algorithm on the same
+ * kernels' data structures: every lit pixel votes every angle (LDS atomics), then the strongest accumulator cell is taken
+ * while it holds >= threshold votes and a lit pixel on its line seeds the same walk / clear / take-back procedure.  Its
+ * segments are NOT OpenCV's; they agree with them under SURVEY 8d's tolerance rule (rho within 1 px and theta within 0.5 deg
+ * for isolated lines; identical collector records on streak streams: tests/test_gpu_hough_accumulator.py).  Frames with more
+ * than 8192 lit pixels are replayed exactly in both modes. */
+#define MDH_HOUGH_EXACT 0
+#define MDH_HOUGH_ACCUMULATOR 1
 
 /* Per-frame scalars: what M3Detector exposes as attributes after detect() (Detector.py:342-392, 394-448). */
 typedef struct mdh_frame_info {
@@ -215,6 +227,16 @@ int mdh_band_skip(mdh_ctx* ctx);
  * ring of binaries are empty, the noise EMA has been updated ema_updates times and stands at snr (EMA.cur_value), with
  * sigma / thr_float / thr the values in force after frame t0.  No pass may be in flight. */
 int mdh_seek(mdh_ctx* ctx, int64_t t0, int64_t ema_updates, double snr, double sigma, double thr_float, int thr);
+
+/* Time windows on a MDH_ROLE_FULL context (the pipelined mdh_submit_batch / mdh_collect_batch path, thresholds computed by the
+ * context itself): after mdh_seek the window is empty, so a sigma that falls due inside the 2(n-1) warm-up frames would be
+ * taken over an incomplete window -- and would then sit in the EMA for the rest of the chunk.  mdh_inject_sums supplies the
+ * sums (S1, S2: Detector.py:81-91 over the sub-ROI, as mdh_band_noise returns them) of due frame number t (1-based, not yet
+ * submitted) from the all-gathered table; the chain uses them instead of its own when frame t comes by.  Cleared by mdh_seek.
+ * mdh_mute_hough_until: frames numbered <= t skip the Hough stage (n_raw = 0): a window that starts empty turns its first
+ * frames into dense binaries whose replay would dominate the chunk, and their results are dropped anyway. */
+int mdh_inject_sums(mdh_ctx* ctx, int64_t t, int64_t s1, int64_t s2);
+int mdh_mute_hough_until(mdh_ctx* ctx, int64_t t);
 
 /* ---- Native MeteorCollector bookkeeping (collector.py:372-631) ---------------------------------------------
  * Host code, no GPU needed.  Consumes (frame, lines, cates) exactly as MeteorCollector.update does and queues the series it

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MDH_LIB") or os.path.join(_HERE, "libmetdet_hip.so") 
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
+MDH_HOUGH_EXACT, MDH_HOUGH_ACCUMULATOR = 0, 1
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 MDH_ROLE_FULL, MDH_ROLE_BAND, MDH_ROLE_HOUGH = 0, 1, 2
 MDH_BAND_HALO = 4
@@ -25,7 +26,8 @@ class MdhCfg(C.Structure):
     _fields_ = [("detector", C.c_int32), ("adaptive_bi_thre", C.c_int32), ("init_value", C.c_int32),
                 ("sensitivity", C.c_int32), ("interval", C.c_int32), ("roi", C.c_int32 * 4),
                 ("hough_threshold", C.c_int32), ("hough_min_len", C.c_int32), ("hough_max_gap", C.c_int32),
-                ("dy_mask", C.c_int32), ("max_batch", C.c_int32), ("role", C.c_int32), ("mask_area", C.c_double)]
+                ("dy_mask", C.c_int32), ("max_batch", C.c_int32), ("role", C.c_int32), ("mask_area", C.c_double),
+                ("hough_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MdhFrameInfo(C.Structure):
@@ -60,6 +62,7 @@ EXPORTS = [
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
+    "mdh_inject_sums", "mdh_mute_hough_until",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
     "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy"
 ]
@@ -130,6 +133,8 @@ def load():
     L.mdh_collector_active.argtypes = [vp]
     L.mdh_frame_sums.argtypes = [i32, vp, i32, u64, i32, vp]
     L.mdh_seek.argtypes = [vp, i64, i64, dbl, dbl, dbl, i32]
+    L.mdh_inject_sums.argtypes = [vp, i64, i64, i64]
+    L.mdh_mute_hough_until.argtypes = [vp, i64]
     _lib = L
     return L
 
@@ -332,6 +337,14 @@ class Context:
         """Reposition the context: the next frame is number t0 + 1; noise EMA / threshold state as given."""
         check(self.L.mdh_seek(self.handle, int(t0), int(ema_updates), float(snr), float(sigma), float(thr_float), int(thr)),
               "mdh_seek")
+
+    def inject_sums(self, t, s1, s2):
+        """Noise sums (S1, S2) of due frame number t (1-based, not yet submitted), used instead of the context's own."""
+        check(self.L.mdh_inject_sums(self.handle, int(t), int(s1), int(s2)), "mdh_inject_sums")
+
+    def mute_hough_until(self, t):
+        """Frames numbered <= t skip the Hough stage (time-window warm-up)."""
+        check(self.L.mdh_mute_hough_until(self.handle, int(t)), "mdh_mute_hough_until")
 
     def hough_planes(self, pieces, K, nbands, band_rows, on_device=False):
         """Step 3 (MDH_ROLE_HOUGH context): pieces = (nbands, K, band_rows, WW) u64 host array or a device pointer."""

@@ -153,6 +153,16 @@ class LocalBands:
         self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, nbands)
         p = self.s.plan
         self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device) for b in range(p.nbands)]
+        # one host thread per band: every band has a context of its own (a context is used by one thread at a time, and ctypes
+        # releases the GIL inside a call), so the bands' blocking steps run side by side on the device the way they do on N GPUs
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=p.nbands) if engine is HipBandEngine and p.nbands > 1 else None
+
+    def _each(self, fn):
+        """fn(b, engine) for every band; side by side when the engines are the HIP ones."""
+        if self._pool is None:
+            return [fn(b, e) for b, e in enumerate(self.engines)]
+        return list(self._pool.map(lambda be: fn(*be), enumerate(self.engines)))
 
     def detect_batch(self, frames: np.ndarray):
         """frames: (K,H,W) u8, whole frames.  Returns (results, info) like M3Detector.detect_batch."""
@@ -191,21 +201,23 @@ class LocalBands:
             self._recv = [ctx.device_alloc(N * piece) for _ in range(N)]
             self._xchg_kp = kp
         piece = self._xchg_kp * p.band_rows * p.WW * 8
-        parts = [e.noise(sub_ptrs[b], K=K, on_device=True) for b, e in enumerate(self.engines)]
+        parts = self._each(lambda b, e: e.noise(sub_ptrs[b], K=K, on_device=True))
         total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]
-        thr = [e.pixels(total, out=self._send[b])[1] for b, e in enumerate(self.engines)]
-        ctx = self.engines[0].band
+        thr = self._each(lambda b, e: e.pixels(total, out=self._send[b])[1])
         live = kp * p.band_rows * p.WW * 8
-        for r in range(N):
+
+        def receive(r, e):  # "all-to-all": rank r pulls slice r of every band's send buffer
             for b in range(N):
-                ctx.device_copy(self._recv[r] + b * live, self._send[b] + r * live, live)
+                e.band.device_copy(self._recv[r] + b * live, self._send[b] + r * live, live)
+        self._each(receive)
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
         results = [None] * K
+        staged = self._each(lambda r, e: e.hough_stage(self._recv[r], kp, on_device=True) if len(range(r, K, N)) else None)
         for r, e in enumerate(self.engines):
             mine = len(range(r, K, N))
             if mine == 0:
                 continue
-            hi, raw, nms, prob = e.hough_stage(self._recv[r], kp, on_device=True)
+            hi, raw, nms, prob = staged[r]
             for j in range(mine):
                 i = j * N + r
                 info[i] = _merge_info(thr[0][i], hi[j])
@@ -219,6 +231,9 @@ class LocalBands:
 
     def close(self):
         self._free_xchg()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
         for e in self.engines:
             e.close()
 

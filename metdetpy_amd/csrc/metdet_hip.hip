@@ -100,6 +100,14 @@ struct Slot {
     // the pass occupying the slot
     bool busy = false, used = false;
     bool host_complete = false;  // the pass wrote its whole result block into host memory itself (k_hough_single)
+    // per-frame protocol: k_hough_single zeroes behind itself what k_pass_prepare would zero in front of the slot's next pass
+    // (lean_clean: the slot is in that state now; was_clean: it was when the pass being queued took it), and announces its
+    // results through a word in the pinned result block that the host polls
+    bool lean_clean = true, was_clean = false;
+    unsigned* h_seq = nullptr;
+    unsigned seq_no = 0;
+    bool seq_armed = false;
+    const uint8_t** h_hdr_dev = nullptr;  // device-visible address of the pinned header (the kernels read the table from host memory)
     int K = 0;
     int64_t t_base = 0;
 };
@@ -107,8 +115,9 @@ struct Slot {
 // Hough-private buffers and streams.  Consecutive passes alternate between the sets, so the (latency-bound) Hough stage of
 // one pass overlaps the next pass's instead of queueing behind it.
 struct HoughSet {
-    hipStream_t stream[2] = {nullptr, nullptr};  // [0] routing + small-LDS launch + result copies, [1] the other launches
-    hipEvent_t ev_big = nullptr, ev_cls = nullptr;
+    // [0] routing + small-LDS launch + result copies, [1] hybrid + one-wave launches (the pooled buffers), [2] large-LDS launch
+    hipStream_t stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_big = nullptr, ev_big2 = nullptr, ev_cls = nullptr;
     // Pooled buffers of the frames that cannot live in LDS alone (hybrid accumulator / mask: `pool` slots; global point lists
     // of the one-wave kernel: `pool_list` slots).  A workgroup keeps one slot and walks through its share of the frames.
     int pool = 0, pool_list = 0;
@@ -180,6 +189,19 @@ struct mdh_ctx {
     bool pending = false;
     bool lean = false;         // the pass being queued runs on the staging stream alone (mdh_update / mdh_detect)
     hipEvent_t ev_copy = nullptr;  // lean mode: the caller's frame has been read
+    // lean mode, the caller's buffer is pinned host memory and no sigma is due: the window kernel reads the frame (and the
+    // pointer table) from host memory itself and leaves the ring copy; the chain is window -> morphology -> mask -> Hough
+    const uint8_t* lean_direct = nullptr;  // device-visible address of the caller's frame, or null
+    bool lean_direct_on = true;            // MDH_LEAN_DIRECT=0 switches the path off (A/B)
+    bool lean_poll = true;                 // MDH_LEAN_POLL=0: wait on the event instead of polling the result block
+    // time-window sharding on a full context: noise sums of due frames supplied by the caller (the frames of a window that
+    // restarted empty cannot produce them: mdh_inject_sums), and frames whose Hough stage is skipped (mdh_mute_hough_until)
+    std::vector<std::pair<int64_t, std::pair<int64_t, int64_t>>> injected;  // (frame number, (S1, S2)), any order
+    long long* h_inject = nullptr;         // pinned staging of the injected sums of the pass being queued
+    int64_t mute_until = 0;
+    unsigned* d_read_count = nullptr;      // waves of the direct window kernel that have finished (zero between launches)
+    unsigned* h_read_flag = nullptr;       // pinned word: read_seq once the caller's frame has been read
+    unsigned read_seq = 0;
     // A pass mutates host-side stream state (EMA schedule, history, ring positions) while it is being queued; if a HIP call
     // fails half-way the context no longer describes the stream, so it refuses further work instead of producing silently
     // wrong thresholds / windows.
@@ -246,9 +268,11 @@ static void free_all(mdh_ctx* c) {
                 c->host_us[3] / c->host_n);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* dev[] = {c->d_ring, c->d_hist, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg};
+    void* dev[] = {c->d_ring, c->d_hist, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg, c->d_read_count};
     for (void* p : dev)
         if (p) hipFree(p);
+    if (c->h_read_flag) hipHostFree(c->h_read_flag);
+    if (c->h_inject) hipHostFree(c->h_inject);
     for (Slot& s : c->slot) {
         void* sdev[] = {s.d_bbits, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr};
         for (void* p : sdev)
@@ -273,6 +297,7 @@ static void free_all(mdh_ctx* c) {
         for (void* p : hdev)
             if (p) hipFree(p);
         if (h.ev_big) hipEventDestroy(h.ev_big);
+        if (h.ev_big2) hipEventDestroy(h.ev_big2);
         if (h.ev_cls) hipEventDestroy(h.ev_cls);
         for (hipStream_t q : h.stream)
             if (q) hipStreamDestroy(q);
@@ -362,7 +387,9 @@ static int create_impl(mdh_ctx* c) {
         HoughSet& h = c->hset[hi];
         HIPCHK(make_stream(&h.stream[0], "MDH_PRIO_HOUGH"));
         HIPCHK(make_stream(&h.stream[1], "MDH_PRIO_HOUGH"));
+        HIPCHK(make_stream(&h.stream[2], "MDH_PRIO_HOUGH"));
         HIPCHK(hipEventCreateWithFlags(&h.ev_big, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h.ev_big2, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h.ev_cls, hipEventDisableTiming));
     }
     const size_t K = c->Kmax, HW = c->HW, words = c->words;
@@ -378,6 +405,9 @@ static int create_impl(mdh_ctx* c) {
         if (c->cfg.detector == MDH_DET_M3) TRY(dev_alloc(c->d_act, (size_t)c->R * words));
     }
     TRY(dev_alloc(c->d_state, 1));
+    TRY(dev_alloc(c->d_read_count, 4));
+    TRY(host_alloc(c->h_read_flag, 16));
+    c->h_read_flag[0] = 0;
     for (int hi = 0; hi < c->nhset && hough; ++hi) {
         HoughSet& h = c->hset[hi];
         h.pool = (int)std::min<size_t>(K, 256);  // one hybrid workgroup per CU (it takes the whole LDS)
@@ -404,6 +434,9 @@ static int create_impl(mdh_ctx* c) {
             s.h_jobs = (NoiseJob*)(s.h_hdr + ptr_bytes);
             s.d_ptrtab = (const uint8_t**)s.d_hdr;
             s.d_jobs = (NoiseJob*)(s.d_hdr + ptr_bytes);
+            void* dv = nullptr;
+            if (hipHostGetDevicePointer(&dv, s.h_hdr, 0) == hipSuccess) s.h_hdr_dev = (const uint8_t**)dv;
+            else (void)hipGetLastError();
         }
         TRY(dev_alloc(s.d_sums, 2 * K));
         TRY(dev_alloc(s.d_jobres, K + 1));
@@ -434,7 +467,9 @@ static int create_impl(mdh_ctx* c) {
             const size_t o_fs = o_gap + a16(sizeof(double) * K), o_lines = o_fs + a16(sizeof(FrameScalars) * K);
             const size_t total = o_lines + sizeof(int) * 4 * K * (size_t)MAX_LINES;
             TRY(dev_alloc(s.d_res, total));
-            TRY(host_alloc(s.h_res, total));
+            TRY(host_alloc(s.h_res, total + 64));
+            s.h_seq = (unsigned*)(s.h_res + total);  // behind everything a result copy ever touches
+            *s.h_seq = 0;
             s.res_lines_off = o_lines;
             s.d_off = (int*)s.d_res;                 s.h_off = (int*)s.h_res;
             s.d_nraw = (int*)(s.d_res + o_nraw);     s.h_nraw = (int*)(s.h_res + o_nraw);
@@ -500,6 +535,10 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         set_err("mdh_create: row-band tiling is built for the M3 detector only");
         return nullptr;
     }
+    if (cfg->hough_mode != MDH_HOUGH_EXACT && cfg->hough_mode != MDH_HOUGH_ACCUMULATOR) {
+        set_err("mdh_create: cfg.hough_mode must be MDH_HOUGH_EXACT or MDH_HOUGH_ACCUMULATOR");
+        return nullptr;
+    }
     const int* r = cfg->roi;
     // a band may hold no row of the noise ROI (empty roi: r[2] == r[0]); a Hough-only context never looks at it
     const bool roi_empty_ok = role == MDH_ROLE_BAND && r[2] == r[0] && r[3] >= r[1];
@@ -562,6 +601,8 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
+    if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
+    if (const char* v = getenv("MDH_LEAN_POLL")) c->lean_poll = atoi(v) != 0;
 
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
@@ -660,6 +701,14 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
         const int64_t rs = (t_base + i) % c->R;
         c->h_ptrtab[c->n - 1 + i] = on_device ? frames + (size_t)i * c->HW : c->d_ring + (size_t)rs * c->HW;
     }
+    if (c->lean_direct) {
+        // no copy commands at all: the table entry of the frame is the caller's (pinned) buffer, the table itself stays in
+        // the slot's pinned header, and no sigma is due (checked by the caller), so there are no jobs
+        c->h_ptrtab[c->n - 1] = c->lean_direct;
+        c->d_ptrtab = sl.h_hdr_dev;
+        sl.nj = 0;
+        return MDH_OK;
+    }
     if (!on_device) {
         // contiguous host frames -> ring slots (t_base + i) % R : at most two runs
         int i = 0;
@@ -725,7 +774,7 @@ static void launch_tb(mdh_ctx* c, const PassGeom& g) {
 }
 
 template <int N, int PPL>
-static void launch_wide(mdh_ctx* c, const PassGeom& g) {
+static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     const int words = (int)c->words;
     const int waves = (words + PPL - 1) / PPL;
     static const int target_waves = getenv("MDH_WIN_WAVES") ? atoi(getenv("MDH_WIN_WAVES")) : 4096;  // experiment switch
@@ -733,11 +782,16 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g) {
     nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
-                       c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc);
+    if (lean.copy_dst)  // per-frame protocol: its own instantiation, the batched one pays nothing for it
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
+                           c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
+                           c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
 }
 
-static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
+// copy_dst: see k_stack_threshold_wide (per-frame protocol; the caller has made sure a wide-load variant applies)
+static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g, const LeanArgs& copy_dst = LeanArgs{}) {
     const int words = (int)c->words;
     if (c->force_generic) {
         hipLaunchKernelGGL(k_stack_threshold_generic, dim3((words + 3) / 4, g.K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr,
@@ -753,7 +807,7 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
     static const int wide16_max_n = getenv("MDH_WIDE16_MAXN") ? atoi(getenv("MDH_WIDE16_MAXN")) : 16;  // A/B switch
     if (align >= 16 && g.n >= 2 && g.n <= std::min(16, wide16_max_n) && !c->force_ppl8) {
         switch (g.n) {
-#define W16_CASE(N) case N: launch_wide<N, 16>(c, g); return;
+#define W16_CASE(N) case N: launch_wide<N, 16>(c, g, copy_dst); return;
             W16_CASE(2) W16_CASE(3) W16_CASE(4) W16_CASE(5) W16_CASE(6) W16_CASE(7) W16_CASE(8)
             W16_CASE(9) W16_CASE(10) W16_CASE(11) W16_CASE(12) W16_CASE(13) W16_CASE(14) W16_CASE(15) W16_CASE(16)
 #undef W16_CASE
@@ -761,7 +815,7 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g) {
     }
     if (align >= 8 && g.n >= 2 && g.n <= 16) {
         switch (g.n) {
-#define W8_CASE(N) case N: launch_wide<N, 8>(c, g); return;
+#define W8_CASE(N) case N: launch_wide<N, 8>(c, g, copy_dst); return;
             W8_CASE(2) W8_CASE(3) W8_CASE(4) W8_CASE(5) W8_CASE(6) W8_CASE(7) W8_CASE(8) W8_CASE(9) W8_CASE(10) W8_CASE(11) W8_CASE(12) W8_CASE(13) W8_CASE(14) W8_CASE(15) W8_CASE(16)
 #undef W8_CASE
         }
@@ -811,6 +865,22 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
                                c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
         }
         span_end(c, c->nstream);
+        if (!c->injected.empty()) {
+            // sums the caller knows better (mdh_inject_sums) replace what the kernel made of an incomplete window
+            for (int j = 0; j < nj; ++j) {
+                const int64_t t = t_base + 1 + sl.h_jobs[j].frame;
+                for (size_t q = 0; q < c->injected.size(); ++q) {
+                    if (c->injected[q].first != t) continue;
+                    if (!c->h_inject) HIPCHK(hipHostMalloc((void**)&c->h_inject, sizeof(long long) * 2 * 64 * NSLOT_MAX));
+                    long long* stage = c->h_inject + ((size_t)(&sl - c->slot) * 64 + (size_t)(j % 64)) * 2;
+                    stage[0] = c->injected[q].second.first;
+                    stage[1] = c->injected[q].second.second;
+                    HIPCHK(hipMemcpyAsync(c->d_sums + 2 * j, stage, sizeof(long long) * 2, hipMemcpyHostToDevice, c->nstream));
+                    c->injected.erase(c->injected.begin() + q);
+                    break;
+                }
+            }
+        }
     }
     HIPCHK(hipGetLastError());
     *nj_out = nj;
@@ -848,15 +918,43 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // pass's post streams, overlapping the window kernel of the following pass(es).
     // (the post streams are NOT the Hough streams: morphology of pass p must not queue behind the Hough stage of pass p-2)
     hipStream_t post = c->lean ? c->nstream : c->pstream[c->pass_seq & 1];
-    EV_WAIT(c, c->stream, sl.ev_noise);  // thresholds, pointer table, history copies, cleared counters
+    if (!c->lean_direct) EV_WAIT(c, c->stream, sl.ev_noise);  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
         static const bool skip_window = getenv("MDH_SKIP_WINDOW") != nullptr;  // timing experiments only: results are wrong
-        if (!skip_window) launch_stack_threshold(c, g);  // (nothing stored = all zero: the words are tagged)
+        LeanArgs copy_dst{};
+        if (c->lean_direct) {  // the threshold is the detector's running one (no sigma due), the frame's ring copy is the kernel's job
+            c->d_thr = &c->d_state->thr;
+            c->read_seq += 1;
+            if (c->read_seq == 0) c->read_seq = 1;
+            copy_dst = LeanArgs{c->d_ring + (size_t)(t_base % c->R) * c->HW, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
+                                c->lean_poll ? c->d_read_count : nullptr, c->h_read_flag, c->read_seq};
+        }
+        if (!skip_window) launch_stack_threshold(c, g, copy_dst);  // (nothing stored = all zero: the words are tagged)
         span_end(c, c->stream);
+        // the caller's buffer has been read when the kernel is done: announced by the kernel itself (polled word), or by an event
+        if (c->lean_direct && !c->lean_poll) HIPCHK(hipEventRecord(c->ev_copy, c->stream));
     } else {
         span_begin(c, KK_CLASSIC, c->stream);
-        hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, sl.d_planes, g);
+        // time-blocked wide-load kernel when the layout allows it (rows of whole 64-pixel words, 16-byte aligned frames, a ring of
+        // 3 or 4 frames); MDH_CLASSIC_TB=0 keeps the one-lane-per-pixel kernel (A/B and parity testing)
+        static const bool classic_tb = !(getenv("MDH_CLASSIC_TB") && atoi(getenv("MDH_CLASSIC_TB")) == 0);
+        bool wide = classic_tb && c->W % 64 == 0 && !c->force_bytes && !c->force_generic && (g.n == 3 || g.n == 4) && K >= 1;
+        for (int e = 0; e < c->n - 1 + K && wide; ++e) wide = ((uintptr_t)c->h_ptrtab[e] & 15) == 0;
+        if (wide) {
+            const int waves = (words + 15) / 16;
+            int nchunks = std::max(1, std::min((8192 + waves - 1) / waves, K / 8));
+            const int Tc = (K + nchunks - 1) / nchunks;
+            nchunks = (K + Tc - 1) / Tc;
+            if (g.n == 4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classic_diff_tb<4>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream, c->d_ptrtab,
+                                   c->d_thr, sl.d_planes, g, Tc);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classic_diff_tb<3>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream, c->d_ptrtab,
+                                   c->d_thr, sl.d_planes, g, Tc);
+        } else {
+            hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, sl.d_planes, g);
+        }
         span_end(c, c->stream);
     }
     EV_REC(c, sl.ev_k1, c->stream);
@@ -880,12 +978,19 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         if (c->prev_slot >= 0 && c->prev_slot != (int)(&sl - c->slot))
             EV_WAIT(c, post, c->slot[c->prev_slot].ev_close);
         span_begin(c, KK_DY_APPLY, post);
-        hipLaunchKernelGGL(k_dy_sparse, dim3(2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
+        hipLaunchKernelGGL(k_dy_sparse, dim3(c->lean && K == 1 ? 64 : 2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
                            sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
         span_end(c, post);
     } else {
-        hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
-                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
+        static const bool classic_rb = !(getenv("MDH_CLASSIC_TB") && atoi(getenv("MDH_CLASSIC_TB")) == 0);
+        span_begin(c, KK_MORPH, post);
+        if (classic_rb)
+            hipLaunchKernelGGL(k_classic_stencil_rb, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
+                               sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
+        else
+            hipLaunchKernelGGL(k_classic_stencil, dim3((words + 255) / 256, K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
+                               sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
+        span_end(c, post);
     }
     EV_REC(c, sl.ev_pix, post);
     return MDH_OK;
@@ -919,6 +1024,8 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.lds_small = c->lean ? c->lds_large : c->lds_small; P.lds_large = c->lds_large;
     P.all_one_wave = c->hough_one_wave;
     P.perm = c->d_perm;
+    P.mute = (int)std::max<int64_t>(0, std::min<int64_t>(K, c->mute_until - sl.t_base));
+    P.acc_mode = c->cfg.hough_mode == MDH_HOUGH_ACCUMULATOR;
     P.list_cap = HOUGH_MAX_LIST; P.cell_cap = 61440;  // the one-wave kernel's LDS
     // Routing first (k_hough_classify: adaptive gap, and which launch replays each frame), then the launches side by side:
     // the small-LDS three-wave launch on stream [0]; the large-LDS launch, the hybrid launch (pooled global accumulator) and
@@ -926,13 +1033,21 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     // costs a launch of workgroups that leave at once.  The set's previous user queued its work on these same streams and
     // stream [0] waited for its stream [1] before packing, so the pooled buffers and the lists are free by stream order.
     EV_WAIT(c, hstream[0], sl.ev_pix);
+    bool large_split = false;
     span_begin(c, KK_HOUGH, hstream[0]);
     static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr;  // timing experiments only: results are wrong
     if (c->lean && K == 1 && !skip_hough) {
         // the per-frame protocol: routing + replay + packing in one launch (k_hough_single), then the one result copy
         P.lds_small = P.lds_large;
         P.lds_bytes = P.lds_large;
-        SingleResult R{sl.h_off, sl.h_nraw, sl.h_litcount, sl.h_gap, sl.h_fscal, (int4*)sl.h_lines, sl.d_fscal};
+        const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
+        sl.seq_no += 1;
+        if (sl.seq_no == 0) sl.seq_no = 1;
+        sl.seq_armed = c->lean_poll;
+        SingleResult R{sl.h_off, sl.h_nraw, sl.h_litcount, sl.h_gap, sl.h_fscal, (int4*)sl.h_lines, sl.d_fscal,
+                       c->lean_direct ? c->d_state : nullptr, sl.seq_armed ? sl.h_seq : nullptr, sl.seq_no,
+                       1, sl.d_bandflag, (unsigned)(nb * c->WW)};
+        sl.lean_clean = true;
         hipLaunchKernelGGL(k_hough_single, dim3(1), dim3(HOUGH3_THREADS), std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned)),
                            hstream[0], P, R);
         span_end(c, hstream[0]);
@@ -957,23 +1072,39 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
             P.flist = hs.d_tier_list + (size_t)t * K;
             P.fcount = hs.d_tier_count + t;
         };
-        tier(1);
         P.lds_bytes = c->lds_large;
         static const int grid_l = getenv("MDH_HOUGH_GRID_LARGE") ? atoi(getenv("MDH_HOUGH_GRID_LARGE")) : 256;
         static const int grid_s = getenv("MDH_HOUGH_GRID_SMALL") ? atoi(getenv("MDH_HOUGH_GRID_SMALL")) : 1024;
-        if (!c->lean) hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_l)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        // The hybrid frames are the longest replays of a pass (a 2000-point 4K streak: 0.6-0.8 ms against 0.1-0.3 ms for a
+        // frame that lives in LDS), so their launch goes first and the large-LDS launch runs BESIDE it on a stream of its own
+        // instead of in front of it: the stage then lasts as long as its longest frame, not as the sum of the tiers' tails.
+        // (MDH_HOUGH_SPLIT=0: round-2a order, large -> hybrid -> one-wave on one stream.)
+        static const bool split = !(getenv("MDH_HOUGH_SPLIT") && atoi(getenv("MDH_HOUGH_SPLIT")) == 0);
+        hipStream_t lstream = split ? hs.stream[2] : hstream[1];
+        if (!c->lean && !split) {
+            tier(1);
+            hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_l)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        }
         tier(2);
         hipLaunchKernelGGL(k_hough3_hybrid, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
         tier(3);
         hipLaunchKernelGGL(k_hough_ppht, dim3(std::min(K, hs.pool_list)), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned),
                            hstream[1], P);
         EV_REC(c, hs.ev_big, hstream[1]);
+        if (!c->lean && split) {
+            EV_WAIT(c, lstream, hs.ev_cls);
+            tier(1);
+            hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_l)), dim3(HOUGH3_THREADS), P.lds_bytes, lstream, P);
+            EV_REC(c, hs.ev_big2, lstream);
+            large_split = true;
+        }
         tier(0);
         P.lds_bytes = P.lds_small;
         hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_s)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[0], P);
         (void)Kmax;
     }
     EV_WAIT(c, hstream[0], hs.ev_big);
+    if (large_split) EV_WAIT(c, hstream[0], hs.ev_big2);
     span_end(c, hstream[0]);
     HIPCHK(hipGetLastError());
     // pack the segments and send the head of the packed array along with the scalars; collect_pass fetches the rest only
@@ -1090,6 +1221,9 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     c->prof = c->prof_every > 0 && c->pass_seq % c->prof_every == 0;
     sl.K = K;
     sl.t_base = c->t;
+    sl.was_clean = sl.lean_clean;
+    sl.lean_clean = false;
+    sl.seq_armed = false;
     if (getenv("MDH_TAG_PASS")) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
     c->cur_spans = &sl.spans;
     c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr;
@@ -1142,7 +1276,18 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
     const int K = sl.K;
     const double t0 = now_us();
     host_log("collect begin", c->pass_seq - c->in_flight);
-    HIPCHK(hipEventSynchronize(sl.ev_done));
+    bool seen = false;
+    if (sl.seq_armed && sl.host_complete && sl.spans.empty()) {
+        // the kernel stores this word last (system-scope release) into the pinned result block: seeing it is seeing the results,
+        // a few microseconds before the completion signal of the kernel would wake the host.  Bounded: after ~2 ms the event decides.
+        volatile unsigned* flag = sl.h_seq;
+        const double t_spin = now_us();
+        for (int spin = 0; !seen; ++spin) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == sl.seq_no) seen = true;
+            else if ((spin & 1023) == 1023 && now_us() - t_spin > 2000) break;
+        }
+    }
+    if (!seen) HIPCHK(hipEventSynchronize(sl.ev_done));
     host_log("collect woke", c->pass_seq - c->in_flight);
     const double t1 = now_us();
     spans_collect(c, sl);
@@ -1208,6 +1353,30 @@ extern "C" int mdh_collect_batch(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_
     return rc == MDH_OK ? K : rc;
 }
 
+// Per-frame protocol, fast path: may the window kernel read this frame from the caller's buffer itself?  Yes when the buffer
+// is host memory a kernel can reach (hipHostMalloc / hipHostRegister: mdh_host_alloc), the slot is clean (its last pass was a
+// per-frame one), a wide-load window kernel applies (16-byte aligned rows of 64-pixel words) and no sigma is due for the frame
+// (Detector.py:82,87: one frame in interval * n) -- then the threshold is the running one and the noise chain has nothing to do.
+// Returns the device-visible address of the frame, or null (the general path: DMA copy, header copy, prepare, noise chain).
+static const uint8_t* lean_direct_source(mdh_ctx* c, const Slot& sl, const uint8_t* frame) {
+    if (!c->lean_direct_on || !sl.was_clean || !sl.h_hdr_dev) return nullptr;
+    if (c->cfg.detector != MDH_DET_M3 || c->W % 64 != 0 || c->force_generic || c->force_bytes || c->n < 2 || c->n > 16) return nullptr;
+    const int64_t t = c->t + 1;
+    const int64_t std_interval = (int64_t)c->cfg.interval * c->n;
+    if (t <= c->n || (std_interval > 0 && t % std_interval == 0)) return nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, frame) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: not an error, just not reachable from a kernel
+        return nullptr;
+    }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    const uintptr_t dp = (uintptr_t)a.devicePointer;
+    if (dp & 15) return nullptr;
+    for (int e = 0; e < c->n - 1; ++e)
+        if ((uintptr_t)c->hist[e] & 15) return nullptr;
+    return (const uint8_t*)dp;
+}
+
 // The reference's per-frame protocol (MetDetPy.py:197-198).  mdh_update queues the WHOLE pass of the frame -- copy, noise /
 // threshold chain, pixel stages, Hough, result copy -- on one stream without a single cross-stream dependency, and returns
 // as soon as the caller's buffer has been read (the reference copies it, utils.py:280; while the 2 MB travel over PCIe the
@@ -1224,14 +1393,28 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
     c->lean = true;
     c->stream = c->nstream;
+    c->lean_direct = lean_direct_source(c, *sl, frame);
     rc = stage_frames(c, *sl, frame, 1, 0);
     if (rc == MDH_OK) rc = retire_frames(c, *sl, 1, 0);
-    if (rc == MDH_OK) rc = run_noise(c, *sl, 1);
+    if (rc == MDH_OK && !c->lean_direct) rc = run_noise(c, *sl, 1);
     if (rc == MDH_OK) rc = run_detect(c, *sl, 1);
     c->lean = false;
+    const bool direct = c->lean_direct != nullptr;
+    c->lean_direct = nullptr;
     if (rc != MDH_OK) return poison(c, rc);
     slot_commit(c, *sl);
-    HIPCHK(hipEventSynchronize(c->ev_copy));  // the caller may reuse `frame` after return
+    // the caller may reuse `frame` after return
+    bool read_seen = false;
+    if (direct && c->lean_poll) {
+        const double t_spin = now_us();
+        for (int spin = 0; !read_seen; ++spin) {
+            if (__atomic_load_n(c->h_read_flag, __ATOMIC_ACQUIRE) == c->read_seq) read_seen = true;
+            else if ((spin & 1023) == 1023 && now_us() - t_spin > 2000) break;
+        }
+        if (!read_seen) HIPCHK(hipStreamSynchronize(c->nstream));  // (never expected: the whole chain instead of the word)
+    } else {
+        HIPCHK(hipEventSynchronize(c->ev_copy));
+    }
     c->pending = true;
     return MDH_OK;
 }
@@ -1385,6 +1568,21 @@ extern "C" int mdh_band_skip(mdh_ctx* c) {
     return MDH_OK;
 }
 
+extern "C" int mdh_inject_sums(mdh_ctx* c, int64_t t, int64_t s1, int64_t s2) {
+    if (!c) { set_err("mdh_inject_sums: null context"); return MDH_E_ARG; }
+    if (c->role == MDH_ROLE_HOUGH) { set_err("mdh_inject_sums: a MDH_ROLE_HOUGH context has no noise chain"); return MDH_E_STATE; }
+    if (t <= c->t) { set_err("mdh_inject_sums: the frame has already been submitted"); return MDH_E_ARG; }
+    if (c->injected.size() >= 64) { set_err("mdh_inject_sums: too many pending entries"); return MDH_E_STATE; }
+    c->injected.push_back({t, {s1, s2}});
+    return MDH_OK;
+}
+
+extern "C" int mdh_mute_hough_until(mdh_ctx* c, int64_t t) {
+    if (!c) { set_err("mdh_mute_hough_until: null context"); return MDH_E_ARG; }
+    c->mute_until = t;
+    return MDH_OK;
+}
+
 extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr, double sigma, double thr_float, int thr) {
     if (!c) { set_err("mdh_seek: null context"); return MDH_E_ARG; }
     if (c->role == MDH_ROLE_HOUGH) { set_err("mdh_seek: a MDH_ROLE_HOUGH context has no stream position"); return MDH_E_STATE; }
@@ -1393,6 +1591,8 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     c->t = t0;
+    c->injected.clear();
+    c->mute_until = 0;
     c->hist.assign(c->n - 1, c->d_zero);  // the window restarts empty: the next 2(n-1) frames are warm-up
     c->ema_t = ema_updates;
     c->ema_warm = c->n;  // the schedule (utils.py:360-368) is a function of the update count alone; it re-derives "ramp over"
@@ -1414,6 +1614,10 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
         }
     }
     HIPCHK(hipStreamSynchronize(c->nstream));
+    // hipMemset on device memory returns before the fill has run, and the library's streams are non-blocking ones that do not
+    // wait for the null stream: without this, the passes submitted next race the fills above and lose tagged words to them
+    // (seen with frames resident in HBM, where nothing slows the first pass down; host frames hid it behind their PCIe copy)
+    HIPCHK(hipDeviceSynchronize());
     c->prev_slot = -1;
     c->last_slot = -1;
     return MDH_OK;
@@ -1502,7 +1706,9 @@ extern "C" int mdh_device_free(mdh_ctx* c, void* p) {
 extern "C" int mdh_device_copy(mdh_ctx* c, void* dst, const void* src, uint64_t bytes) {
     if (!c || !dst || !src) return MDH_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    // done when the call returns, whatever the runtime makes of a device-to-device hipMemcpy: the consumers run on non-blocking streams
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->cstream));
+    HIPCHK(hipStreamSynchronize(c->cstream));
     return MDH_OK;
 }
 extern "C" void* mdh_host_alloc(mdh_ctx* c, uint64_t bytes) {

@@ -378,10 +378,44 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_U16
 #define WIDE_U16 4  // frames per load burst of the 16-pixels-per-lane kernel (A/B builds: -DWIDE_U16=8)
 #endif
-template <int N, int PPL>
+// Per-frame protocol only (all null otherwise): see k_stack_threshold_wide.
+struct LeanArgs {
+    uint8_t* copy_dst;          // ring slot that receives the copy of frame 0
+    u64* clr_dst;               // the slot's dst plane: the words its previous pass wrote (clr_list[0 .. clr_count[0])) are zeroed,
+    const unsigned* clr_list;   //   then the list counters are reset -- what k_pass_prepare / k_noise_finalize do for a batched pass
+    unsigned* clr_count;
+    // "the caller's buffer has been read": the last wave to finish stores `seq` into the host word the caller polls (an event
+    // record between this kernel and the next one would cost the chain ~5 us)
+    unsigned* done_count;       // device counter, zero between launches
+    unsigned* done_flag;        // host (pinned) word
+    unsigned seq;
+};
+__device__ __forceinline__ void lean_wave_done(const LeanArgs& lean, unsigned total_waves) {
+    if ((threadIdx.x & 63) == 0 && lean.done_count != nullptr) {
+        if (atomicAdd(lean.done_count, 1u) == total_waves - 1) {
+            *lean.done_count = 0;
+            __hip_atomic_store(lean.done_flag, lean.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+template <int N, int PPL, bool LEAN>
 __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
-                                                              unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
+                                                              unsigned* __restrict__ blockcnt, PassGeom g, int Tc,
+                                                              LeanArgs lean) {
+    // lean.copy_dst (per-frame protocol only, otherwise null): frame 0 of the pass is read straight from the caller's pinned
+    // HOST buffer (its table entry is a host address: the loads cross PCIe) and the kernel leaves the copy the next windows
+    // reach back to in the ring slot copy_dst -- no DMA command, and no DMA-to-compute hand-over, in front of the frame's
+    // chain.  The first workgroup also wipes what the slot's previous frame left in dst (kept until now for get_binary / visu).
+    // (LEAN is a template parameter: the batched instantiation must not pay registers for it -- 161 VGPRs / 3 waves per SIMD at
+    // n = 8 and 252 / 2 at n = 16 are both at the edge of an occupancy step)
+    uint8_t* __restrict__ const copy_dst = LEAN ? lean.copy_dst : nullptr;
+    if (LEAN && lean.clr_count != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+        const unsigned listed = lean.clr_count[0];
+        for (unsigned e = threadIdx.x; e < listed; e += 256) lean.clr_dst[lean.clr_list[e]] = 0;
+        __syncthreads();
+        if (threadIdx.x < 2) lean.clr_count[threadIdx.x] = 0;
+    }
     constexpr int RW = PPL / 2;   // packed pair registers per window entry
     constexpr int DW = PPL / 4;   // dwords per load
     constexpr int LPW = 64 / PPL; // lanes per 64-pixel word
@@ -390,10 +424,16 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
     const int gw0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPL;  // a wave covers PPL words
-    if (gw0 >= words) return;
+    if (gw0 >= words) {
+        if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
+        return;
+    }
     const int i0 = blockIdx.y * Tc;
     const int steps = min(Tc, g.K - i0);
-    if (steps <= 0) return;
+    if (steps <= 0) {
+        if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
+        return;
+    }
     const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
     const int q = lane % LPW;
     const int gw = gw0 + lane / LPW;
@@ -499,6 +539,9 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         PK a[RW];
                         unpack(cur[u], a);
                         const int i = i0 + s;
+                        if constexpr (LEAN) {
+                            if (copy_dst != nullptr && i == 0 && gw < words) *(dvec*)(copy_dst + off) = cur[u];
+                        }
                         // b = (max - floor(sum / len) > T)  <=>  sum + T * len - max * len < 0.  The left side is within
                         // [-255 len, 510 len], i.e. inside int16 for len <= 16 (this kernel's N), so b is the sign bit of
                         // one packed multiply-add whose addend is sum + T * len (T >= 256 can never fire; clamping it
@@ -575,6 +618,7 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         }
     }
+    if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -997,6 +1041,99 @@ __global__ void __launch_bounds__(256) k_classic_diff(const uint8_t* const* __re
     }
 }
 
+// Time-blocked variant for frames whose width is a multiple of 64 and whose bases are 16-byte aligned (the layout of
+// k_stack_threshold_wide: a wave owns 16 words = 1024 pixels, a lane 16 consecutive pixels, one 128-bit buffer load per lane
+// per frame) -- a wave walks through the frames of its time chunk with the three previous frames in registers, so every frame
+// byte is fetched once per pass instead of four times, by 16x fewer load instructions.  |a - b| > T on packed u16 pairs:
+// min(a - b, b - a) mod 2^16 is the absolute difference, and bit 15 of T - |d| is the comparison.  N = ring size (3 or 4:
+// int(4 / fps * fps) can truncate to 3, and numpy's negative ring indices then wrap -- Detector.py:258-261).
+template <int N>
+__global__ void __launch_bounds__(256) k_classic_diff_tb(const uint8_t* const* __restrict__ ptrtab, const int* __restrict__ thr_tab,
+                                                         u64* __restrict__ planes, PassGeom g, int Tc) {
+    constexpr int PPL = 16, RW = 8, DW = 4;
+    typedef unsigned dvec __attribute__((ext_vector_type(DW)));
+    const int lane = threadIdx.x & 63;
+    const int words = g.H * g.WW;
+    const int gw0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPL;
+    if (gw0 >= words) return;
+    const int i0 = blockIdx.y * Tc;
+    const int steps = min(Tc, g.K - i0);
+    if (steps <= 0) return;
+    const int q = lane & 3;
+    const int gw = gw0 + (lane >> 2);
+    const int frame_bytes = g.H * g.W;
+    const int off = gw < words ? gw * 64 + q * PPL : 0x7FFFFFF0;  // past the frame -> zeros
+    union PK {
+        unsigned u;
+        u16x2 v;
+    };
+    auto fetch = [&](int e) -> dvec {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
+        return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    };
+    auto unpack = [&](const dvec& d, PK (&p)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const unsigned sel = 0x0C000C00u | (unsigned)(r & 3) | ((unsigned)(4 + (r & 3)) << 16);
+            p[r].u = __builtin_amdgcn_perm(d[r / 4 + DW / 2], d[r / 4], sel);
+        }
+    };
+    // hist[k] = frame (current - 1 - k); table entry of pass frame i is i + n - 1, so the prologue reads entries i0 + n - 2 - k
+    PK hist[3][RW];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < N - 1) unpack(fetch(i0 + N - 2 - k), hist[k]);
+        else {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) hist[k][r].u = 0;
+        }
+    }
+    dvec nxt = fetch(i0 + N - 1);
+    for (int s = 0; s < steps; ++s) {
+        const int i = i0 + s;
+        const dvec cur = nxt;
+        if (s + 1 < steps) nxt = fetch(i + N);
+        PK f0[RW];
+        unpack(cur, f0);
+        const unsigned short T = (unsigned short)min(__builtin_amdgcn_readfirstlane(thr_tab[i]), 256);
+        const u16x2 Tv = {T, T};
+        unsigned acc1 = 0, acc2 = 0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            // f_k = ring[cur - k] with numpy wrap: k % N frames back
+            const u16x2 a0 = f0[r].v;
+            const u16x2 a1 = (1 % N) == 0 ? a0 : hist[(1 % N) - 1][r].v;
+            const u16x2 a2 = (2 % N) == 0 ? a0 : hist[(2 % N) - 1][r].v;
+            const u16x2 a3 = (3 % N) == 0 ? a0 : hist[(3 % N) - 1][r].v;
+            PK d1, d2;
+            d1.v = Tv - __builtin_elementwise_min((u16x2)(a1 - a0), (u16x2)(a0 - a1));
+            d2.v = Tv - __builtin_elementwise_min((u16x2)(a3 - a2), (u16x2)(a2 - a3));
+            acc1 = (acc1 >> 1) | (d1.u & 0x80008000u);
+            acc2 = (acc2 >> 1) | (d2.u & 0x80008000u);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            hist[2][r] = hist[1][r];
+            hist[1][r] = hist[0][r];
+            hist[0][r] = f0[r];
+        }
+        // low half bits 8..15 = pixels 0..7, high half bits 24..31 = pixels 8..15 (see k_stack_threshold_wide)
+        const unsigned bits1 = ((acc1 >> 8) & 0xFFu) | ((acc1 >> 16) & 0xFF00u);
+        const unsigned bits2 = ((acc2 >> 8) & 0xFFu) | ((acc2 >> 16) & 0xFF00u);
+        const unsigned both = bits1 | (bits2 << 16);
+        // gather the four lanes of a word: lane 0 <- 1, 2 <- 3, then 0 <- 2 (quad-permute DPP)
+        const unsigned odd = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xF5, 0xF, 0xF, true);
+        const unsigned p1 = (both & 0xFFFFu) | (odd << 16);          // plane 1, pixels 0..31 of the lane pair
+        const unsigned p2 = (both >> 16) | (odd & 0xFFFF0000u);      // plane 2
+        const unsigned p1u = (unsigned)__builtin_amdgcn_mov_dpp((int)p1, 0xAA, 0xF, 0xF, true);
+        const unsigned p2u = (unsigned)__builtin_amdgcn_mov_dpp((int)p2, 0xAA, 0xF, 0xF, true);
+        if (q == 0 && gw < words) {
+            planes[((size_t)i * 2 + 0) * words + gw] = (u64)p1 | ((u64)p1u << 32);
+            planes[((size_t)i * 2 + 1) * words + gw] = (u64)p2 | ((u64)p2u << 32);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__ planes, u64* __restrict__ dst_bits,
                                                          int* __restrict__ rowcount, int* __restrict__ litcount,
                                                          int* __restrict__ bbox, PassGeom g) {
@@ -1040,6 +1177,57 @@ __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__
     }
 }
 
+// The same stencil with one thread per (word column, band of MORPH_RB rows): the rows slide through three-deep register
+// pipelines (dilated first difference, masked second difference), so a word of either plane is fetched once per band
+// (+ 4 / 2 halo rows) instead of 15 / 3 times per output word.  Bands whose planes are empty produce nothing but zeros.
+__global__ void __launch_bounds__(256) k_classic_stencil_rb(const u64* __restrict__ planes, u64* __restrict__ dst_bits,
+                                                            int* __restrict__ rowcount, int* __restrict__ litcount,
+                                                            int* __restrict__ bbox, PassGeom g) {
+    const int i = blockIdx.y;
+    const int words = g.H * g.WW;
+    const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nb * g.WW) return;
+    const int band = tid / g.WW, w = tid - band * g.WW;
+    const int y0 = band * MORPH_RB;
+    const long long t = g.t_base + 1 + i;
+    const bool active = t >= g.n;  // Detector.py:263: fewer than stack_maxsize frames -> no detection
+    const Win q = make_win(w, g.W);
+    const u64* p1 = planes + ((size_t)i * 2 + 0) * words;
+    const u64* p2 = planes + ((size_t)i * 2 + 1) * words;
+    u64* out_plane = dst_bits + (size_t)i * words;
+    u128 h1a = 0, h1b = 0;   // hor_or3 of the first-difference rows yy-2, yy-1
+    u128 k_a = 0, k_b = 0;   // hor_or3 of the kept second-difference rows (yy-1)-2, (yy-1)-1
+#pragma unroll
+    for (int it = 0; it < MORPH_RB + 4; ++it) {
+        const int yy = y0 - 2 + it;  // first-difference row entering the pipeline
+        u128 h1c = 0;
+        if (active && yy >= 0 && yy < g.H) h1c = hor_or3(load_win(p1 + (size_t)yy * g.WW, w, g.WW));
+        const int yk = yy - 1;       // row whose dilated first difference is complete now
+        u128 k_c = 0;
+        if (active && yk >= 0 && yk < g.H) {
+            const u128 d1 = h1a | h1b | h1c;
+            k_c = hor_or3(load_win(p2 + (size_t)yk * g.WW, w, g.WW) & ~d1 & q.valid);
+        }
+        const int yo = yy - 2;       // output row complete now
+        if (yo >= y0 && yo < g.H && yo < y0 + MORPH_RB) {
+            const u64 out = (u64)(((k_a | k_b | k_c) & q.valid) >> 3);
+            out_plane[(size_t)yo * g.WW + w] = out;
+            if (out) {
+                const int c = __popcll(out);
+                atomicAdd(&rowcount[i * g.H + yo], c);
+                atomicAdd(&litcount[i], c);
+                atomicMax(&bbox[4 * i + 0], g.W - 1 - (w * 64 + __builtin_ctzll(out)));
+                atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(out));
+                atomicMax(&bbox[4 * i + 2], g.H - 1 - yo);
+                atomicMax(&bbox[4 * i + 3], yo);
+            }
+        }
+        h1a = h1b; h1b = h1c;
+        k_a = k_b; k_b = k_c;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a10: cv2.HoughLinesP = progressive probabilistic Hough, replayed exactly:
 // row-major non-zero list, cv::RNG(2^64-1) visiting order, float32 rho without FMA contraction,
@@ -1080,6 +1268,8 @@ struct HoughParams {
     int lds_bytes;         // dynamic LDS bytes of this launch
     const unsigned short* perm;  // visiting-order tables: the table of an N-point frame starts at N(N-1)/2
     const int* bbox;       // [K][4] {W-1 - min x, max x, H-1 - min y, max y} of the lit pixels
+    int mute;              // the first `mute` frames of the pass are not replayed (time-window warm-up: results dropped anyway)
+    int acc_mode;          // 1 = full-accumulator Hough (h3_accumulate) instead of the exact replay, in the three-wave kernels
 };
 
 
@@ -1632,7 +1822,7 @@ __device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
         gap = gg * P.max_gap;
     }
     if (lane == 0) P.out_gap[i] = gap;
-    if (N < P.threshold) {  // (threshold >= 1, so this covers the empty frame)
+    if (N < P.threshold || i < P.mute) {  // (threshold >= 1, so this covers the empty frame)
         if (lane == 0) P.out_nraw[i] = 0;
         return -1;
     }
@@ -1703,6 +1893,9 @@ struct Hough3 {
     bool touched_global;
     bool timing;           // MDH_HOUGH_DEBUG: cycles per phase (thread 0's view)
     long long ph[8];       // steps (table, list, mask), votes, hits + barrier, trigger (take back, arg-max), walk, clear, un-vote, lines
+    // full-accumulator mode (h3_accumulate): this thread's cached row maximum and whether an un-vote has hit its cell since
+    int best_r;
+    bool dirty;
 };
 #define H3_T(C, k, t0) do { if ((C).timing) { const long long t1_ = clock64(); (C).ph[k] += t1_ - (t0); (t0) = t1_; } } while (0)
 
@@ -1751,9 +1944,10 @@ __device__ __forceinline__ int h3_vote_value(unsigned o, int sh) {
 __device__ __forceinline__ u64 h3_uniform(u64 v) {  // the value is wave-uniform: tell the compiler (keeps it in SGPRs)
     return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
-template <bool HYBRID>
+template <bool HYBRID, bool ACC = false>
 __device__ __forceinline__ void h3_unvote(Hough3& C, int x, int y) {
     const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+    if (ACC && r == C.best_r) C.dirty = true;
     if (!HYBRID || C.in_lds) {
         const int c = r + C.cbase;
         atomicSub(&C.cells[c >> 1], C.vinc << ((c & 1) * 16));
@@ -1782,7 +1976,9 @@ __device__ __forceinline__ int h3_scan(int v, int& total, unsigned* scratch, int
 
 // The point (x, y) reached the threshold at angle bn (hough.cpp, second half of the loop).  Wave k (k = 0, 1) walks direction
 // k; ends with a barrier after which every wave sees the cleared mask and the taken-back votes of ITS OWN cells.
-template <bool HYBRID>
+// ACC (full-accumulator mode): every lit pixel has voted, so the votes of every cleared pixel are taken back whether or not
+// the segment is long enough -- the accumulator stays the vote count of the pixels still in the mask.
+template <bool HYBRID, bool ACC = false>
 __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     const HoughParams& P = C.P;
     const int lane = C.lane;
@@ -1863,7 +2059,7 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
                 was = h3_clear<HYBRID>(C, j1, i1);  // (step 0 belongs to both directions: the atomic gives it to one of them)
                 pt = ((unsigned)i1 << 16) | (unsigned)j1;
             }
-            if (good) {
+            if (good || ACC) {
                 const u64 ms = __ballot(was);
                 if (ms) {
                     unsigned base = 0;
@@ -1877,20 +2073,22 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     }
     __syncthreads();  // the mask is cleared, the un-vote list is complete
     H3_T(C, 5, tph);
-    if (good) {
+    if (good || ACC) {
         const int M = __builtin_amdgcn_readfirstlane((int)C.fix[24]);
         int m = 0;
         for (; m + 4 <= M; m += 4) {  // four points per LDS read (the list is 16-byte aligned)
             const uint4 q = *(const uint4*)&C.uv[m];
-            h3_unvote<HYBRID>(C, q.x & 0xFFFF, q.x >> 16);
-            h3_unvote<HYBRID>(C, q.y & 0xFFFF, q.y >> 16);
-            h3_unvote<HYBRID>(C, q.z & 0xFFFF, q.z >> 16);
-            h3_unvote<HYBRID>(C, q.w & 0xFFFF, q.w >> 16);
+            h3_unvote<HYBRID, ACC>(C, q.x & 0xFFFF, q.x >> 16);
+            h3_unvote<HYBRID, ACC>(C, q.y & 0xFFFF, q.y >> 16);
+            h3_unvote<HYBRID, ACC>(C, q.z & 0xFFFF, q.z >> 16);
+            h3_unvote<HYBRID, ACC>(C, q.w & 0xFFFF, q.w >> 16);
         }
         for (; m < M; ++m) {
             const unsigned q = C.uv[m];
-            h3_unvote<HYBRID>(C, q & 0xFFFF, q >> 16);
+            h3_unvote<HYBRID, ACC>(C, q & 0xFFFF, q >> 16);
         }
+    }
+    if (good) {
         if (C.found < MAX_LINES && C.tid == 0) {
             int* o = P.out_lines + ((size_t)C.frame * MAX_LINES + C.found) * 4;
             o[0] = ex0; o[1] = ey0; o[2] = ex1; o[3] = ey1;
@@ -1993,6 +2191,126 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
             // the rest of the step against the updated mask
             am = __ballot(kk < N && lane > tl && h3_bit<HYBRID>(C, px, py));
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hough_mode = MDH_HOUGH_ACCUMULATOR: a FULL-accumulator Hough on the same data structures (BASELINE north_star's
+// "LDS-binned atomics").  Every lit pixel votes every angle at once (order-free LDS atomics, thread t = angle t), then the
+// strongest cell of the whole accumulator is taken again and again while it holds at least `threshold` votes: a lit pixel on
+// that (rho, theta) line seeds the same walk / clear / take-back procedure as the progressive transform (h3_line).  No random
+// visiting order, no dependence on which cell happens to cross the threshold first: the result is a function of the binary
+// image alone, the strongest lines come out first, and the work per frame is one vote sweep plus one line procedure per
+// segment.  It is a DIFFERENT algorithm from cv2.HoughLinesP: its segments are compared with the exact replay's under SURVEY
+// 8d's tolerance rule (rho / theta of matched segments, collector records), never bit for bit.
+__device__ __forceinline__ int h3_cell_value(const Hough3& C, int r) {
+    const int c = r + C.cbase;
+    return (int)((C.cells[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
+}
+template <bool HYBRID>
+__device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, int w_size) {
+    const HoughParams& P = C.P;
+    const int lane = C.lane, tid = C.tid;
+    // ---- one sweep: all votes (un-ordered; a thread's own cells, but a dword can hold the last cell of one angle's window and
+    // the first of the next, hence atomics)
+    {
+        int p = 0;
+        for (; p + 4 <= N; p += 4) {
+            const uint4 q = *(const uint4*)&list[p];
+            int sh;
+            h3_vote_issue<HYBRID>(C, q.x & 0xFFFF, q.x >> 16, 1u, sh);
+            h3_vote_issue<HYBRID>(C, q.y & 0xFFFF, q.y >> 16, 1u, sh);
+            h3_vote_issue<HYBRID>(C, q.z & 0xFFFF, q.z >> 16, 1u, sh);
+            h3_vote_issue<HYBRID>(C, q.w & 0xFFFF, q.w >> 16, 1u, sh);
+        }
+        for (; p < N; ++p) {
+            const unsigned q = list[p];
+            int sh;
+            h3_vote_issue<HYBRID>(C, q & 0xFFFF, q >> 16, 1u, sh);
+        }
+    }
+    if (HYBRID) __threadfence();
+    __syncthreads();
+    C.dirty = true;
+    C.best_r = 0;
+    int best = -1;
+    const bool has_angle = tid < NUM_ANGLE;
+    for (int iter = 0; iter <= N; ++iter) {  // every line event clears at least its seed pixel
+        // ---- this angle's strongest cell (smallest rho among equals); rescanned only when an un-vote has touched it
+        if (has_angle && C.dirty) {
+            best = -1;
+            int br = w_lo;
+            for (int r = w_lo; r < w_lo + w_size; ++r) {
+                int v;
+                if (!HYBRID || C.in_lds) v = h3_cell_value(C, r);
+                else v = (int)ld_l2((const unsigned*)&C.acc_row[r]);
+                if (v > best) {
+                    best = v;
+                    br = r;
+                }
+            }
+            C.best_r = br;
+            C.dirty = false;
+        }
+        // ---- strongest cell of the accumulator: larger count first, then the smaller angle ("first maximum wins")
+        const unsigned key = has_angle ? (((unsigned)(best + 1 + KEY_BIAS) << 8) | (unsigned)(255 - tid)) : 0u;
+        const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(key, 0);
+        if (lane == 0) C.fix[8 + C.wave] = wmax;
+        __syncthreads();
+        const unsigned top = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(C.fix[8], C.fix[9]), C.fix[10]));
+        const int count = (int)(top >> 8) - 1 - KEY_BIAS;
+        const int bn = 255 - (int)(top & 0xFF);
+        if (count < P.threshold) break;  // (uniform: every thread reads the same three words)
+        if (tid == bn) C.fix[11] = (unsigned)C.best_r;
+        if (tid == 0) C.fix[25] = 0xFFFFFFFFu;
+        __syncthreads();
+        const int rho = (int)C.fix[11];
+        // ---- seed: the MIDDLE one (row-major order) of the lit pixels that vote for that cell.  The walk follows the cell's angle
+        // (1-degree grid) from the seed in both directions; starting in the middle halves the drift against a line whose true
+        // angle lies between two grid angles.
+        const float sc = P.trig[2 * bn], ss = P.trig[2 * bn + 1];
+        const int chunk = (N + HOUGH3_THREADS - 1) / HOUGH3_THREADS;
+        const int p_lo = min(N, tid * chunk), p_hi = min(N, p_lo + chunk);
+        auto votes_here = [&](int p) -> bool {
+            const unsigned q = list[p];
+            const int x = q & 0xFFFF, y = q >> 16;
+            return __float2int_rn(__fadd_rn(__fmul_rn((float)x, sc), __fmul_rn((float)y, ss))) == rho && h3_bit<HYBRID>(C, x, y);
+        };
+        int mine = 0;
+        for (int p = p_lo; p < p_hi; ++p) mine += votes_here(p) ? 1 : 0;
+        int voters;
+        const int before = h3_scan(mine, voters, C.fix + 32, lane, C.wave);  // (two barriers)
+        const int want = voters / 2;
+        if (voters > 0 && want >= before && want < before + mine) {
+            int k = want - before;
+            for (int p = p_lo; p < p_hi; ++p)
+                if (votes_here(p) && k-- == 0) {
+                    C.fix[25] = (unsigned)p;
+                    break;
+                }
+        }
+        __syncthreads();
+        const unsigned seed = C.fix[25];
+        __syncthreads();
+        if (seed == 0xFFFFFFFFu) {
+            // cannot happen while the accumulator mirrors the mask; kept so that a stale cell could never spin the loop
+            if (tid == bn) {
+                C.dirty = true;
+                if (!HYBRID || C.in_lds) {
+                    const int c = rho + C.cbase;
+                    atomicAnd(&C.cells[c >> 1], ~(0xFFFFu << ((c & 1) * 16)));
+                    atomicOr(&C.cells[c >> 1], (unsigned)CELL_BIAS << ((c & 1) * 16));
+                } else {
+                    C.acc_row[rho] = 0;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        const unsigned q = list[seed];
+        h3_line<HYBRID, true>(C, q & 0xFFFF, q >> 16, bn);  // walks, clears, takes the votes back (marks touched maxima dirty)
+        if (HYBRID) __threadfence();
+        __syncthreads();
     }
 }
 
@@ -2122,7 +2440,8 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
         C.cbase = 2 * (cell_dw + tid);  // r is 0 for the spare lanes (tc = ts = 0): their private cell
     }
     const long long w1 = P.dbg ? wall_clock64() : 0;
-    h3_replay<HYBRID>(C, N, list);
+    if (P.acc_mode) h3_accumulate<HYBRID>(C, N, list, w_lo, w_size);
+    else h3_replay<HYBRID>(C, N, list);
     if (tid == 0) P.out_nraw[i] = C.found;
     if (P.dbg && tid == 0) {  // MDH_HOUGH_DEBUG=1: points, tier, 100 MHz ticks (set-up, PPHT), segments, LDS cells
         long long* d = P.dbg + (size_t)i * 8;
@@ -2180,7 +2499,15 @@ struct SingleResult {  // the pass's result block in (pinned, device-visible) HO
     double* gap;
     FrameScalars* fscal;
     int4* packed;
-    const FrameScalars* d_fscal;  // the frame's scalars as the noise chain left them
+    const FrameScalars* d_fscal;  // the frame's scalars as the noise chain left them ...
+    const ScalarState* d_state;   // ... or (no sigma was due for the frame: no noise chain ran) the detector's running scalars
+    unsigned* seq_flag;           // host word the caller polls: set to `seq` once every result above is visible to the host
+    unsigned seq;
+    // clean-after-use: what k_pass_prepare / k_noise_finalize would zero in front of the slot's NEXT pass is zeroed behind this
+    // one, after the results are out, so that a frame's chain starts with the window kernel
+    int clean;                    // (row / frame lit counts and the bounding box are reached through HoughParams)
+    unsigned* blockcnt;
+    unsigned n_blockcnt;
 };
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, SingleResult R) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
@@ -2207,9 +2534,27 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, 
         R.nraw[0] = n_raw;
         R.lit[0] = P.litcount[0];
         R.gap[0] = P.out_gap[0];
-        R.fscal[0] = R.d_fscal[0];
+        if (R.d_state) {
+            const ScalarState st = *R.d_state;
+            FrameScalars f;
+            f.thr_f = st.thr_f; f.snr = st.ema_v; f.sigma = st.sigma; f.thr = st.thr; f.pad = 0;
+            R.fscal[0] = f;
+        } else {
+            R.fscal[0] = R.d_fscal[0];
+        }
     }
     __threadfence_system();
+    __syncthreads();
+    if (tid == 0 && R.seq_flag) __hip_atomic_store(R.seq_flag, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (R.clean) {  // the host already has its results; the slot's counters are left as those of a fresh one
+        // (dst and its word list stay: get_binary / visu may still ask for the frame; the slot's next pass wipes the listed words)
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int e = tid; e < P.H; e += HOUGH3_THREADS) ((int*)P.rowcount)[e] = 0;
+        if (tid == 0) ((int*)P.litcount)[0] = 0;
+        if (tid < 4) ((int*)P.bbox)[tid] = 0;
+        for (unsigned e = tid; e < R.n_blockcnt / 4; e += HOUGH3_THREADS) ((uint4*)R.blockcnt)[e] = z;
+        for (unsigned e = (R.n_blockcnt & ~3u) + tid; e < R.n_blockcnt; e += HOUGH3_THREADS) R.blockcnt[e] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

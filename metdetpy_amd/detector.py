@@ -67,7 +67,13 @@ class LineDetector(BaseDetector):
     _native_kind = _lib.MDH_DET_M3
 
     def __init__(self, window_sec: float, fps: float, mask: np.ndarray, num_cls: int, cfg: BinaryCfg, logger=None,
-                 *, device: int = 0, max_batch: int = 64):
+                 *, device: int = 0, max_batch: int = 64, hough_mode: str = "exact"):
+        """hough_mode: "exact" (default) replays cv2.HoughLinesP segment for segment -- the parity path; "accumulator" runs the
+        order-free full-accumulator transform (include/metdet_hip.h, MDH_HOUGH_ACCUMULATOR): different segments, same detections
+        under the tolerance rule of SURVEY 8d."""
+        if hough_mode not in ("exact", "accumulator"):
+            raise ValueError("hough_mode must be 'exact' or 'accumulator'")
+        self.hough_mode = hough_mode
         self.mask = mask
         self.num_cls = num_cls
         self.logger = logger
@@ -105,6 +111,7 @@ class LineDetector(BaseDetector):
         c.dy_mask = int(bool(self.dynamic_cfg.dy_mask))
         c.max_batch = int(max_batch)
         c.mask_area = float(self.mask_area)
+        c.hough_mode = _lib.MDH_HOUGH_ACCUMULATOR if hough_mode == "accumulator" else _lib.MDH_HOUGH_EXACT
         self._ctx = _lib.Context(H, W, self.stack_maxsize, c, device=device)
         self._H, self._W = H, W
         self._pending = False

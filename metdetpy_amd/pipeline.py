@@ -16,13 +16,14 @@ from .utils import VERSION, get_num_class
 
 def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: BinaryCfg, collector_cfg: CollectorCfg,
                   rt: RuntimeParams, *, window_sec: float = 1.0, batch: int = 64, device: int = 0, logger=None,
-                  detector_cls=M3Detector, start_frame: int = 0, collector_cls=MeteorCollector):
+                  detector_cls=M3Detector, start_frame: int = 0, collector_cls=MeteorCollector, detector_kwargs=None):
     """Feed `frames` (each (H,W) uint8, one per exposure frame) through the detector and the collector exactly in the
     order the reference's loop does: collector.update(i, lines, cates) when the frame has lines, or on every
     eq_int_fps-th iteration (MetDetPy.py:200-202); collector.clear() at the end (MetDetPy.py:237).
     The result arrays of a pass go to the (native) collector in one call.  `collector_cls` exists for the tests, which run their
     Python restatement of the reference's collector through the same loop frame by frame.  Returns (records, per_frame_info)."""
-    det = detector_cls(window_sec, rt.eq_fps, mask, get_num_class(), detector_cfg, logger, device=device, max_batch=batch)
+    det = detector_cls(window_sec, rt.eq_fps, mask, get_num_class(), detector_cfg, logger, device=device, max_batch=batch,
+                       **(detector_kwargs or {}))
     col = collector_cls(collector_cfg, rt, None, logger)
     native_collector = hasattr(col, "update_batch")
     infos = []

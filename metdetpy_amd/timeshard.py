@@ -13,8 +13,13 @@ Rank r owns frames [s_r, e_r).  Two things tie a frame to its past:
     replay the scalar chain on the host (NoiseChain, the same arithmetic as the library's k_noise_finalize); each rank
     then positions its context at its start (mdh_seek) with the exact EMA / threshold state.
 
-The second sweep is the band path with a single band: mdh_band_noise -> mdh_band_pixels (sums from the gathered table)
--> mdh_hough_planes.  Results are identical to one detector running the whole stream (tests/test_timeshard.py).
+The second sweep is the ordinary pipelined detector (mdh_submit_batch / mdh_collect_batch, several passes in flight, frames
+read in place when they are resident in HBM) on a context positioned with mdh_seek: it computes the sigmas of its chunk
+itself -- the same exact integer sums -- except for the due frames that fall into the first n frames after the seek, whose
+window is still filling; those come from the gathered table (mdh_inject_sums).  The Hough stage of the warm-up frames is
+skipped (mdh_mute_hough_until).  An engine substituted for the HIP one (CPU tests of the exchange logic) takes the band path
+with a single band instead: mdh_band_noise -> mdh_band_pixels (sums from the table) -> mdh_hough_planes.  Results are
+identical to one detector running the whole stream either way (tests/test_timeshard.py).
 """
 from __future__ import annotations
 
@@ -86,16 +91,25 @@ class TimeShard:
     -> its frames' results.  `read(lo, hi)` returns frames [lo, hi) of the stream as a (hi-lo, H, W) uint8 array."""
 
     def __init__(self, window_sec, fps, mask, num_cls, cfg, total_frames, read, *, rank=0, world=1, device=0, max_batch=64,
-                 engine=HipBandEngine):
+                 engine=HipBandEngine, read_device=None, scan_batch=None):
+        """read_device(lo, hi) (optional): device pointer of frames [lo, hi) when the stream is resident in HBM, contiguous.
+        scan_batch: frames per call of the first sweep (default max_batch)."""
         self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, 1)
         self.cfg, self.read, self.total = cfg, read, int(total_frames)
+        self.read_device = read_device
+        self.pipelined = engine is HipBandEngine
+        self.SB = int(scan_batch or max_batch)
         self.rank, self.world, self.B = int(rank), int(world), int(max_batch)
         n = self.s.n
         self.start, self.end = chunk_bounds(self.total, self.world)[self.rank]
         # The warm-up may reach into earlier ranks' chunks (the frames are only read), so a chunk may be shorter than the
         # warm-up itself: every rank derives the same bounds from (total, world) and none can fail alone before a collective.
         self.warm = max(0, self.start - 2 * (n - 1))
-        self.engine = engine(self.s.plan, 0, n, cfg, self.s.mask_area, self.B, device)
+        self.engine = engine(self.s.plan, 0, n, cfg, self.s.mask_area, self.SB if self.pipelined else self.B, device)
+        self.det = None
+        if self.pipelined and self.end > self.start:
+            from .detector import M3Detector
+            self.det = M3Detector(window_sec, fps, np.asarray(mask), num_cls, cfg, None, device=device, max_batch=self.B)
 
     def _chain(self):
         b = self.cfg.binary
@@ -109,9 +123,13 @@ class TimeShard:
             return out
         st0 = self._chain().state()
         self.engine.seek(self.warm, **st0)  # the scalar state plays no part in the sums
-        for lo in range(self.warm, self.end, self.B):
-            hi = min(self.end, lo + self.B)
-            sums = self.engine.noise(self.read(lo, hi))
+        SB = self.SB if self.pipelined else self.B
+        for lo in range(self.warm, self.end, SB):
+            hi = min(self.end, lo + SB)
+            if self.read_device is not None:
+                sums = self.engine.noise(self.read_device(lo, hi), K=hi - lo, on_device=True)
+            else:
+                sums = self.engine.noise(self.read(lo, hi))
             self.engine.skip()
             j = 0
             for t in range(lo + 1, hi + 1):
@@ -136,6 +154,8 @@ class TimeShard:
             if t > self.warm:
                 break
             chain.update(*table[t])
+        if self.pipelined:
+            return self._finish_pipelined(table, chain)
         self.engine.seek(self.warm, **chain.state())
         for lo in range(self.warm, self.end, self.B):
             hi = min(self.end, lo + self.B)
@@ -157,8 +177,70 @@ class TimeShard:
                     res.append((i, info, lines, pred))
         return res
 
+    def finish_blocks(self, table: dict):
+        """finish() for consumers that work on whole passes (bench, batched collector): [(first_frame, info[K'], {j: (lines,
+        cls_pred)} for the frames j (index into the pass, counted from its first frame incl. dropped warm-up) with lines, offset)]."""
+        if not self.pipelined or self.end <= self.start:
+            return None
+        chain = self._chain()
+        for t in sorted(table):
+            if t > self.warm:
+                break
+            chain.update(*table[t])
+        return self._finish_pipelined(table, chain, blocks=True)
+
+    def _finish_pipelined(self, table, chain, blocks=False):
+        """Second sweep on a full detector context: seek, inject the sums its restarted window cannot produce, mute the
+        warm-up frames' Hough stage, then passes in flight like any stream."""
+        n = self.s.n
+        ctx = self.det._ctx
+        ctx.seek(self.warm, **chain.state())
+        if self.warm > 0:
+            for t in sorted(table):
+                if self.warm < t < self.warm + n:  # fewer than n frames since the seek: the window is still filling
+                    ctx.inject_sums(t, table[t][1], table[t][2])
+        ctx.mute_hough_until(self.start)
+        B = self.B
+        bufs = [(np.zeros(B, _lib.FRAME_INFO_DTYPE), np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32),
+                 np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32), np.zeros((B, _lib.MDH_MAX_LINES), np.float64))]
+        queue, res = [], []
+
+        def collect():
+            lo, K, _keep = queue.pop(0)
+            info, raw, nms, prob = bufs[0]
+            ctx.collect_into(info, raw, nms, prob)
+            first = max(0, self.start - lo)  # frames before it are warm-up: dropped
+            if blocks:
+                # one record per pass: the per-frame scalars as an array, (lines, cls_pred) only for the frames that have lines
+                hit = {}
+                for j in np.flatnonzero(info["n_nms"][first:K] > 0) + first:
+                    hit[int(j)] = _package(self.s.num_cls, info[j], raw[j], nms[j], prob[j])
+                res.append((lo + first, info[first:K].copy(), hit, first))
+                return
+            for j in range(first, K):
+                lines, pred = _package(self.s.num_cls, info[j], raw[j], nms[j], prob[j])
+                res.append((lo + j, info[j].copy(), lines, pred))
+
+        for lo in range(self.warm, self.end, B):
+            hi = min(self.end, lo + B)
+            if ctx.in_flight >= ctx.max_in_flight:
+                collect()
+            if self.read_device is not None:
+                ctx.submit(self.read_device(lo, hi), hi - lo, True)
+                queue.append((lo, hi - lo, None))
+            else:
+                frames = np.ascontiguousarray(self.read(lo, hi))
+                ctx.submit(frames.ctypes.data, hi - lo, False)
+                queue.append((lo, hi - lo, frames))  # the frames must stay valid until the pass is collected
+        while queue:
+            collect()
+        return res
+
     def close(self):
         self.engine.close()
+        if self.det is not None:
+            self.det.close()
+            self.det = None
 
 
 def run_time_sharded(window_sec, fps, mask, num_cls, cfg, total_frames, read, *, dist=None, rank=0, world=1, device=0,

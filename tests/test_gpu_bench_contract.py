@@ -30,7 +30,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # physical pricing: the bytes a launch must move (each frame byte once + the carried window) over the measured duration
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
     assert 128 * 1080 * 1920 <= r["bytes_per_launch"] <= 1.5 * 128 * 1080 * 1920 and 0 < r["frac"] < 1
-    assert 0 < r["frac_standalone"] < 1 and r["launch_ms_standalone"] > 0 and 0 < r["frac_at_pipeline_pace"] < 1
+    assert 0 < r["frac_in_pipeline_per_launch"] < 1 and r["launch_ms_in_pipeline"] > 0 and 0 < r["frac_at_pipeline_pace"] < 1
+    assert "ONE pass in flight" in r["launch_ms_note"]  # frac is priced on the non-overlapped launch
     assert r["algorithmic_bytes_per_launch"] == 9 * 128 * 1080 * 1920 and r["algorithmic_frac"] > r["frac"]
     assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"] or r["traffic_source"] == "live"
     assert set(d["kernels_ms_standalone"]) >= {"stack_threshold", "hough_ppht"}

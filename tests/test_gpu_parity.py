@@ -15,10 +15,18 @@ from tests.helpers import binary_cfg, busy_frames, frames_normal, oracle_kwargs
 pytestmark = pytest.mark.gpu
 
 
-def run_pair(frames, n, mask, cfg, *, batch=None, check_act=True, max_batch=64):
-    """Feed the same frames to the GPU detector and the oracle; assert parity frame by frame."""
+def run_pair(frames, n, mask, cfg, *, batch=None, check_act=True, max_batch=64, pinned=False):
+    """Feed the same frames to the GPU detector and the oracle; assert parity frame by frame.  pinned: the per-frame protocol
+    gets its frames in pinned host memory (mdh_host_alloc), which the window kernel then reads itself (no DMA copy)."""
     H, W = mask.shape
     det = M3Detector(1, n, mask, 10, cfg, None, max_batch=max_batch)
+    pool = None
+    if pinned:
+        import ctypes
+        arr = np.ascontiguousarray(np.stack(frames))
+        pool = det._ctx.host_alloc(arr.nbytes)
+        ctypes.memmove(pool, arr.ctypes.data, arr.nbytes)
+        frames = np.ctypeslib.as_array((ctypes.c_uint8 * arr.nbytes).from_address(pool)).reshape(arr.shape)
     orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
     assert tuple(det.stack.std_roi) == tuple(orc.stack.std_roi)
     total_lines = 0
@@ -66,8 +74,71 @@ def run_pair(frames, n, mask, cfg, *, batch=None, check_act=True, max_batch=64):
                     dst = orc.dst
                 compare(t + i, res[i][0], res[i][1], info[i], dst, None)
             t += len(chunk)
+    if pool is not None:
+        del frames
+        det._ctx.host_free(pool)
     det.close()
     return total_lines
+
+
+@pytest.mark.parametrize("shape,n", [((128, 256), 8), ((135, 192), 4), ((96, 128), 16), ((64, 64), 2)])
+def test_m3_per_frame_from_pinned_memory(shape, n):
+    """The per-frame protocol's fast path (the window kernel reads the caller's pinned buffer and the pointer table from
+    host memory, no DMA / prepare / noise commands when no sigma is due; results announced through the polled word): same
+    bar as every other path, dst and the pre-mask binary included, across several sigma-due frames (interval * n)."""
+    mask = np.ones(shape, np.uint8)
+    s = SkyStream(*shape, 31 + n, speed=5, streak_period=11, streak_life=7)
+    total = run_pair([s.next() for _ in range(5 * n + 40)], n, mask, binary_cfg("normal"), pinned=True)
+    assert total > 0 or n == 2  # (a two-frame window keeps too little of a streak for a segment)
+    # widths that are not a multiple of 64 take the general path from the same pinned buffers
+    shape2 = (60, 100)
+    s = SkyStream(*shape2, 5, speed=5, streak_period=11, streak_life=7)
+    run_pair([s.next() for _ in range(30)], 4, np.ones(shape2, np.uint8), binary_cfg("normal"), pinned=True)
+
+
+def test_m3_per_frame_pinned_interleaved_with_batches():
+    """Batched passes leave the slots in the state k_pass_prepare expects, per-frame passes in the clean-after-use state:
+    a detector that alternates between the two protocols must keep producing the oracle's results."""
+    import ctypes
+    shape, n = (128, 192), 6
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg("normal")
+    s = SkyStream(*shape, 99, speed=5, streak_period=9, streak_life=6)
+    frames = np.stack([s.next() for _ in range(96)])
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
+    pool = det._ctx.host_alloc(frames.nbytes)
+    ctypes.memmove(pool, frames.ctypes.data, frames.nbytes)
+    pinned = np.ctypeslib.as_array((ctypes.c_uint8 * frames.nbytes).from_address(pool)).reshape(frames.shape)
+    t, total = 0, 0
+    plan = [("f", 9), ("b", 20), ("f", 13), ("b", 3), ("f", 25), ("b", 16), ("f", 10)]
+    for kind, cnt in plan:
+        if kind == "f":
+            for k in range(cnt):
+                det.update(pinned[t])
+                lines, pred = det.detect()
+                orc.update(frames[t])
+                o_lines, o_pred = orc.detect()
+                assert det.bi_threshold == orc.bi_threshold, t
+                assert det.lines_num == orc.lines_num, t
+                assert np.array_equal(np.asarray(lines).reshape(-1, 4), np.asarray(o_lines).reshape(-1, 4)), t
+                assert np.array_equal(det.dst, orc.dst), t
+                total += len(o_lines)
+                t += 1
+        else:
+            res, info = det.detect_batch(frames[t:t + cnt])
+            for i in range(cnt):
+                orc.update(frames[t + i])
+                o_lines, o_pred = orc.detect()
+                assert int(info[i]["bi_threshold"]) == orc.bi_threshold, t + i
+                assert int(info[i]["n_raw"]) == orc.lines_num, t + i
+                assert np.array_equal(np.asarray(res[i][0]).reshape(-1, 4), np.asarray(o_lines).reshape(-1, 4)), t + i
+                total += len(o_lines)
+            t += cnt
+    assert total > 0
+    del pinned
+    det._ctx.host_free(pool)
+    det.close()
 
 
 @pytest.mark.parametrize("shape,n", [((54, 96), 4), ((67, 131), 8), ((64, 64), 3), ((135, 240), 8)])
@@ -188,15 +259,18 @@ def test_hough_many_points_global_list():
     run_pair([base, blob, base], n, mask, cfg)
 
 
-@pytest.mark.parametrize("n_eff", [4, 3])
-def test_classic_detector(n_eff):
-    shape = (80, 144)
+@pytest.mark.parametrize("n_eff,fps", [(4, 25.0), (3, 49.0)])
+@pytest.mark.parametrize("shape", [(80, 144), (72, 192), (40, 64)])
+def test_classic_detector(n_eff, fps, shape):
+    """Per-frame protocol.  49 fps: int(4 / fps * fps) truncates to 3 and the reference's negative ring indices wrap
+    (Detector.py:258-261).  Widths that are a multiple of 64 take the time-blocked wide-load kernel, the others the byte kernel."""
     mask = np.ones(shape, np.uint8)
     cfg = binary_cfg(adaptive=False, init_value=12, hough=(10, 10, 3))
-    fps = 25.0
     det = ClassicDetector(1, fps, mask, 10, cfg, None)
-    assert det.stack_maxsize == int(4 / fps * fps)
-    orc = mo.ClassicOracle(mask, threshold=12, hough_threshold=10, hough_min_len=10, hough_max_gap=3, hough_fn=co.hough_lines_p)
+    assert det.stack_maxsize == int(4 / fps * fps) == n_eff
+    orc = mo.ClassicOracle(mask, threshold=12, hough_threshold=10, hough_min_len=10, hough_max_gap=3, hough_fn=co.hough_lines_p,
+                           n=n_eff) if n_eff != 4 else \
+        mo.ClassicOracle(mask, threshold=12, hough_threshold=10, hough_min_len=10, hough_max_gap=3, hough_fn=co.hough_lines_p)
     got = 0
     for t, f in enumerate(busy_frames(31, 16, shape)):
         det.update(f); lines, pred = det.detect()
@@ -206,8 +280,37 @@ def test_classic_detector(n_eff):
         if t >= 3:
             assert np.array_equal(det.dst, orc.dst), t
         got += len(o_lines)
-    assert got > 0
+    assert got > 0 or shape[1] <= 64
     det.close()
+
+
+@pytest.mark.parametrize("n_eff,fps", [(4, 25.0), (3, 49.0)])
+def test_classic_detector_batched_equals_per_frame(n_eff, fps):
+    """Passes of many frames (several time chunks of the time-blocked kernel, windows reaching back into the previous pass)
+    against the per-frame protocol of a second detector and against the oracle."""
+    shape = (96, 256)
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=12, hough=(10, 10, 3))
+    frames = np.stack(busy_frames(77, 83, shape))
+    a = ClassicDetector(1, fps, mask, 10, cfg, None, max_batch=40)
+    b = ClassicDetector(1, fps, mask, 10, cfg, None)
+    kw = dict(n=n_eff) if n_eff != 4 else {}
+    orc = mo.ClassicOracle(mask, threshold=12, hough_threshold=10, hough_min_len=10, hough_max_gap=3, hough_fn=co.hough_lines_p, **kw)
+    res = []
+    for lo in (0, 40, 57):
+        hi = {0: 40, 40: 57, 57: 83}[lo]
+        out, info = a.detect_batch(frames[lo:hi])
+        res += out
+    got = 0
+    for t in range(len(frames)):
+        b.update(frames[t]); lines, pred = b.detect()
+        orc.update(frames[t]); o_lines, _ = orc.detect()
+        assert np.array_equal(np.asarray(res[t][0]).reshape(-1, 4), np.asarray(lines).reshape(-1, 4)), t
+        assert np.array_equal(np.asarray(lines).reshape(-1, 4), o_lines.reshape(-1, 4)), t
+        got += len(o_lines)
+    assert got > 0
+    a.close()
+    b.close()
 
 
 def test_api_errors():

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported():
 def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(_lib.MdhFrameInfo) == 56 and _lib.FRAME_INFO_DTYPE.itemsize == 56
-    assert C.sizeof(_lib.MdhCfg) == 16 * 4 + 8
+    assert C.sizeof(_lib.MdhCfg) == 16 * 4 + 8 + 8
     hdr = open(os.path.join(ROOT, "include", "metdet_hip.h")).read()
     assert "#define MDH_MAX_LINES 512" in hdr and _lib.MDH_MAX_LINES == 512
 

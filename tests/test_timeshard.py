@@ -51,11 +51,20 @@ def test_noise_chain_replays_the_oracle_series(sens, sigma):
     assert changes > 0
 
 
-def simulate(world, frames, n, mask, cfg, B, engine):
+def simulate(world, frames, n, mask, cfg, B, engine, resident=False):
     total = len(frames)
     read = lambda lo, hi: frames[lo:hi]
     shards = [TimeShard(n / 10, 10, mask, 10, cfg, total, read, rank=r, world=world, max_batch=B, engine=engine)
               for r in range(world)]
+    pool = None
+    if resident:  # the stream lives in HBM: both sweeps read it in place
+        ctx = shards[0].engine.band
+        frames = np.ascontiguousarray(frames)
+        pool = ctx.device_alloc(frames.nbytes)
+        ctx.device_upload(pool, frames)
+        fb = frames[0].nbytes
+        for s in shards:
+            s.read_device = lambda lo, hi: pool + lo * fb
     table = {}
     for s in shards:
         part = s.scan()
@@ -65,6 +74,9 @@ def simulate(world, frames, n, mask, cfg, B, engine):
     out = []
     for s in shards:
         out += s.finish(table)
+    if pool is not None:
+        shards[0].engine.band.device_free(pool)
+    for s in shards:
         s.close()
     assert [o[0] for o in out] == list(range(total))
     return out
@@ -152,6 +164,8 @@ def test_hip_time_shards_equal_whole_stream(kind, world, H, W, n, total, B):
     assert sum(w["n_raw"] for w in want) > 0
     out = simulate(world, frames, n, mask, cfg, B, HipBandEngine)
     check_against([(o[2], o[3]) for o in out], [o[1] for o in out], want)
+    out_dev = simulate(world, frames, n, mask, cfg, B, HipBandEngine, resident=True)
+    check_against([(o[2], o[3]) for o in out_dev], [o[1] for o in out_dev], want)
     whole = M3Detector(n / 10, 10, mask, 10, cfg, None, max_batch=B)
     _, winfo = whole.detect_batch(frames)
     whole.close()
@@ -182,6 +196,30 @@ def test_seek_errors_and_restart():
     det._ctx.update(frames[0])
     with pytest.raises(_lib.MetDetHipError, match="in flight"):
         det._ctx.seek(0)
+    det.close()
+
+
+@pytest.mark.gpu
+def test_seek_then_resident_frames_at_once():
+    """mdh_seek wipes the tagged binaries with device-side fills; the passes submitted right behind it -- frames resident in HBM,
+    so nothing delays the first kernels -- must not race those fills (they did: streak frames lost their lit pixels)."""
+    from metdetpy_amd import M3Detector
+    H, W, n, K = 540, 960, 8, 256
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case("sky", H, W, n, K, 21)
+    frames = np.ascontiguousarray(frames)
+    det = M3Detector(n / 10, 10, mask, 10, cfg, None, max_batch=K)
+    ctx = det._ctx
+    pool = ctx.device_alloc(frames.nbytes)
+    ctx.device_upload(pool, frames)
+    first = ctx.process_batch(pool, K=K, on_device=True)
+    assert int(first[0]["n_raw"].sum()) > 0
+    for _ in range(3):
+        ctx.seek(0, thr=5, thr_float=5.0)
+        again = ctx.process_batch(pool, K=K, on_device=True)
+        assert np.array_equal(first[0], again[0])
+        assert np.array_equal(first[1], again[1])
+    ctx.device_free(pool)
     det.close()
 
 

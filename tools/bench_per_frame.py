@@ -33,7 +33,7 @@ def main():
             ctx.profile_read(True)
         tu = td = 0.0
         segs = 0
-        N = 3000
+        N = int(os.environ.get("PF_N", "3000"))
         t0 = time.perf_counter()
         for k in range(N):
             f = pinned[k % len(pinned)]

@@ -11,6 +11,8 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="bench.py --workload $WL --steps 8 --warmup 2 --cpu-seconds 0 --parity-frames 0 --standalone-passes 0"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r --output-format csv -- python $ARGS > "$OUT/stats.log" 2>&1
+# the same passes one at a time (nothing overlaps): the average duration of the window kernel here is what roofline.launch_ms / frac use
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_d1" -o r --output-format csv -- python $ARGS --depth 1 > "$OUT/stats_d1.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o r --output-format csv -- python $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o r --output-format csv -- python $ARGS > "$OUT/write.log" 2>&1
 python - "$OUT" "$TAG" "$WL" <<'PY'
@@ -23,6 +25,9 @@ def one(pattern):
 stats = one(f"{out}/stats/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, f"{out}/{tag}_rocprofv3_kernel_stats_{wl}.csv")
+stats1 = one(f"{out}/stats_d1/**/*kernel_stats.csv")
+if stats1:
+    shutil.copy(stats1, f"{out}/{tag}_rocprofv3_kernel_stats_{wl}_depth1.csv")
 def per_kernel(path, counter):
     acc, cnt, seen = collections.defaultdict(float), collections.Counter(), set()
     for row in csv.DictReader(open(path)):

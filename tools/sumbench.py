@@ -6,6 +6,6 @@ for f in sys.argv[1:]:
     except Exception as e:
         print(f, "ERR", open(f.replace(".json", ".err")).read()[-300:].replace("\n", " | ")); continue
     r = d.get('roofline', {})
-    print(f"{f.split('/')[-1]:26s} {d['value']:10.0f} fps {d['ms_per_step']:.3f} ms/step B {d['config']['frames_per_step']} frac {r.get('frac', 0):.3f} alone {r.get('frac_standalone', 0):.3f} pace {r.get('frac_at_pipeline_pace', 0):.3f} {d.get('parity', {}).get('verdict')}")
+    print(f"{f.split('/')[-1]:26s} {d['value']:10.0f} fps {d['ms_per_step']:.3f} ms/step B {d['config']['frames_per_step']} frac(alone) {r.get('frac', 0):.3f} in-pipe/launch {r.get('frac_in_pipeline_per_launch', 0):.3f} pace {r.get('frac_at_pipeline_pace', 0):.3f} {d.get('parity', {}).get('verdict')}")
     print('    pipe ', {k[:10]: round(v, 3) for k, v in d.get('kernels_ms_per_step', {}).items()})
     print('    alone', {k[:10]: round(v, 3) for k, v in d.get('kernels_ms_standalone', {}).items()})
