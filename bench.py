@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s is wha
 
 WORKLOADS = {
     "C2": dict(H=1080, W=1920, n=8, seed=20220413, batch=2048, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
-    "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=512, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
+    "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=1024, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
     "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2048, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
     "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=128, sensitivity="high",
                desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--standalone-passes", type=int, default=12, help="passes run one at a time after the timed region to "
                     "measure the non-overlapped duration of every kernel (0 = skip)")
+    ap.add_argument("--hough-mode", default="exact", choices=["exact", "accumulator"], help="accumulator: the order-free "
+                    "full-accumulator transform (MDH_HOUGH_ACCUMULATOR) instead of the exact replay of cv2.HoughLinesP; parity is then "
+                    "the tolerance rule of SURVEY 8d (collector records matched against the exact mode's), not bit-exactness")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight in the timed region (0 = as many as the library "
                     "allows; 1 = one at a time: nothing overlaps, the kernel spans are the kernels' own durations)")
     ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive "
@@ -85,6 +88,7 @@ SENSITIVITY = "normal"
 
 
 DETECTOR = "m3"
+HOUGH_MODE = "exact"
 CLASSIC_THRESHOLD = 20  # |x_t - x_(t-1)| of the stream's N(30, 2.5) background has sigma 3.5: 20 keeps the noise out, a +60 streak in
 
 
@@ -100,7 +104,47 @@ def make_detector(n, mask, device, max_batch):
     from metdetpy_amd import ClassicDetector, M3Detector
     if DETECTOR == "classic":
         return ClassicDetector(1, 4.0, mask, 10, make_cfg(), None, device=device, max_batch=max_batch)
-    return M3Detector(1, n, mask, 10, make_cfg(), None, device=device, max_batch=max_batch)
+    return M3Detector(1, n, mask, 10, make_cfg(), None, device=device, max_batch=max_batch, hough_mode=HOUGH_MODE)
+
+
+def parity_check_accumulator(frames, n, mask, local, count):
+    """hough_mode = accumulator is a different algorithm from cv2.HoughLinesP: its parity is SURVEY 8d's tolerance rule.  The
+    same frames go through the exact-mode detector (itself bit-exact against the oracle, see the default run) and the
+    accumulator-mode one, both through the native collector; every record of either must have a partner in the other with
+    time IoU >= 0.3 and box IoU >= 0.3 (evaluate.py's matching rule)."""
+    from metdetpy_amd import M3Detector
+    from metdetpy_amd.collector import NativeMeteorCollector
+    from metdetpy_amd.metstruct import CollectorCfg, MeteorCfg, RecheckSwitch, RuntimeParams
+    from metdetpy_amd.pipeline import calculate_area_iou, calculate_time_iou
+    count = min(count, len(frames))
+    H, W = mask.shape
+    ccfg = CollectorCfg(MeteorCfg(15, 4, [0, 8], [2, 21], [0, 0.6], 0.5, 2048), RecheckSwitch(False), {})
+    rt = RuntimeParams(fps=float(n), exp_frame=1, eq_fps=float(n), eq_int_fps=n, exp_time=1.0 / n, runtime_size=[W, H],
+                       raw_size=[W, H], positive_category_list=["METEOR", "RED_SPRITE"])
+
+    class Box:
+        def __init__(self, t):
+            (self.x1, self.x2), (self.y1, self.y2) = sorted([t.pt1[0], t.pt2[0]]), sorted([t.pt1[1], t.pt2[1]])
+
+    recs, segs = {}, {}
+    for mode in ("exact", "accumulator"):
+        det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=count, hough_mode=mode)
+        info, _raw, nms, prob = det._ctx.process_batch(np.ascontiguousarray(frames[:count]))
+        det.close()
+        col = NativeMeteorCollector(ccfg, rt)
+        col.update_batch(0, 0, info, nms, prob)
+        col.clear()
+        recs[mode] = [t for r in col.met_exporter.meteor_list for t in r.target]
+        segs[mode] = int(info["n_raw"].sum())
+
+    def unmatched(a_list, b_list):
+        return sum(1 for a in a_list if not any(calculate_time_iou(a, b) >= 0.3 and calculate_area_iou(Box(a), Box(b)) >= 0.3 for b in b_list))
+
+    miss = unmatched(recs["accumulator"], recs["exact"]) + unmatched(recs["exact"], recs["accumulator"])
+    return {"frames_checked": count, "records_exact": len(recs["exact"]), "records_accumulator": len(recs["accumulator"]),
+            "unmatched_records": miss, "raw_segments_exact": segs["exact"], "raw_segments_accumulator": segs["accumulator"],
+            "verdict": "matched under tolerance" if miss == 0 and recs["exact"] else "MISMATCH",
+            "checked": "collector records of the accumulator-mode detector vs the exact-mode detector, time IoU >= 0.3 and box IoU >= 0.3 both ways"}
 
 
 def parity_check_classic(frames, mask, local, count):
@@ -258,7 +302,9 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.d = None
         self.tdev = None
-        if self.world > 1:
+        # MDH_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL branch -- init, barrier,
+        # all-reduce, all-gather on device tensors -- on a one-GPU box; launch under torch.distributed.run or set MASTER_ADDR / PORT)
+        if self.world > 1 or os.environ.get("MDH_BENCH_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
             backend = os.environ.get("MDH_BENCH_BACKEND", "nccl")
@@ -504,9 +550,10 @@ def main():
     D = Dist()
     wl = WORKLOADS[a.workload]
     H, W, n = wl["H"], wl["W"], wl["n"]
-    global SENSITIVITY, DETECTOR
+    global SENSITIVITY, DETECTOR, HOUGH_MODE
     SENSITIVITY = wl.get("sensitivity", "normal")
     DETECTOR = a.detector
+    HOUGH_MODE = a.hough_mode
     if DETECTOR == "classic":
         n = 4
     if a.batch is None:
@@ -550,6 +597,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: {wl['desc']}, "
                                + (f"ClassicDetector (4-frame ring, fixed threshold {CLASSIC_THRESHOLD})" if DETECTOR == "classic" else f"m3det_{SENSITIVITY} detector cfg")
+                               + (", hough_mode = accumulator (NOT cv2.HoughLinesP's segments)" if HOUGH_MODE == "accumulator" else "")
                                + f", {shape}"
                                + (" -- INPUT FROM PINNED HOST MEMORY (PCIe-inclusive)" if a.host_input else ""),
                    "frame": [W, H], "window": n, "frames_per_step": B, "stream_period_frames": r["uniq"],
@@ -569,8 +617,12 @@ def main():
         if D.world == 1 and a.cpu_seconds > 0 and frames is not None and DETECTOR == "m3":
             out["cpu_baseline"] = cpu_baseline(frames, n, mask, a.cpu_seconds)
         if D.world == 1 and a.parity_frames > 0 and frames is not None and "parity" not in out:
-            out["parity"] = parity_check_classic(frames, mask, D.local, a.parity_frames) if DETECTOR == "classic" else \
-                parity_check(frames, n, mask, D.local, a.parity_frames)
+            if DETECTOR == "classic":
+                out["parity"] = parity_check_classic(frames, mask, D.local, a.parity_frames)
+            elif HOUGH_MODE == "accumulator":
+                out["parity"] = parity_check_accumulator(frames, n, mask, D.local, a.parity_frames)
+            else:
+                out["parity"] = parity_check(frames, n, mask, D.local, a.parity_frames)
         print(json.dumps(out), flush=True)
     D.close()
 

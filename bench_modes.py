@@ -195,14 +195,16 @@ def run_timeshard(a, D, wl, mask, cfg):
     if D.rank == 0:
         info = np.zeros(total, _lib.FRAME_INFO_DTYPE)
         results = [None] * total
+        from metdetpy_amd.timeshard import unpack_block
         empty = (np.array([]), np.zeros((0, 10)))
         for chunk in gathered:
             for rec in chunk:
                 if rec[0] == "block":
-                    _tag, f0, binfo, hit, off = rec
+                    f0, binfo = rec[1], rec[2]
                     info[f0:f0 + len(binfo)] = binfo
-                    for j, lp in hit.items():
-                        results[f0 - off + j] = lp
+                    if f0 < 64:  # per-frame (lines, cls_pred) only where the parity leg looks
+                        for i, _fi, lines, pred in unpack_block(rec[1:], 10):
+                            results[i] = (lines, pred)
                 else:
                     i, fi, lines, pred = rec
                     info[i] = fi

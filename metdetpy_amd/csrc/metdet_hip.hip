@@ -1602,10 +1602,13 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
     st.thr_f = thr_float;
     st.thr = thr;
     HIPCHK(hipMemcpy(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
-    // binaries of the previous position must not be taken for frames of the new one (the ring is tagged by frame number)
-    if (c->d_act) HIPCHK(hipMemset(c->d_act, 0, sizeof(ActWord) * (size_t)c->R * c->words));
-    for (int si = 0; si < c->nslot; ++si)
-        if (c->slot[si].d_bbits) HIPCHK(hipMemset(c->slot[si].d_bbits, 0, sizeof(ActWord) * (size_t)c->Kmax * c->words));
+    // binaries of the previous position must not be taken for frames of the new one (the ring is tagged by frame number);
+    // a context that has not run a pixel stage yet holds none (gigabytes of fills saved per time window)
+    if (c->pass_seq > 0) {
+        if (c->d_act) HIPCHK(hipMemset(c->d_act, 0, sizeof(ActWord) * (size_t)c->R * c->words));
+        for (int si = 0; si < c->nslot; ++si)
+            if (c->slot[si].d_bbits) HIPCHK(hipMemset(c->slot[si].d_bbits, 0, sizeof(ActWord) * (size_t)c->Kmax * c->words));
+    }
     for (int si = 0; si < c->nslot; ++si) {
         Slot& sl = c->slot[si];
         if (sl.used && sl.d_dst && sl.d_nzlist) {

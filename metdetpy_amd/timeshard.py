@@ -178,8 +178,10 @@ class TimeShard:
         return res
 
     def finish_blocks(self, table: dict):
-        """finish() for consumers that work on whole passes (bench, batched collector): [(first_frame, info[K'], {j: (lines,
-        cls_pred)} for the frames j (index into the pass, counted from its first frame incl. dropped warm-up) with lines, offset)]."""
+        """finish() for consumers that work on whole passes (bench, batched collector): one (first_frame, info[K'], rows, nms, prob)
+        per pass -- rows = indices (into info) of the frames with segments, nms[r, :info[rows[r]]["n_nms"]] their lineset_nms output,
+        prob likewise.  `unpack_block` turns one into the per-frame (lines, cls_pred) of finish().  None when the engine is not
+        the HIP one."""
         if not self.pipelined or self.end <= self.start:
             return None
         chain = self._chain()
@@ -211,11 +213,12 @@ class TimeShard:
             ctx.collect_into(info, raw, nms, prob)
             first = max(0, self.start - lo)  # frames before it are warm-up: dropped
             if blocks:
-                # one record per pass: the per-frame scalars as an array, (lines, cls_pred) only for the frames that have lines
-                hit = {}
-                for j in np.flatnonzero(info["n_nms"][first:K] > 0) + first:
-                    hit[int(j)] = _package(self.s.num_cls, info[j], raw[j], nms[j], prob[j])
-                res.append((lo + first, info[first:K].copy(), hit, first))
+                # one record per pass, arrays only (what a batched collector takes): the per-frame scalars, and the NMS segments /
+                # non-line probabilities of the frames that have any, cut to the widest of them
+                cnt = info["n_nms"][first:K]
+                rows = np.flatnonzero(cnt > 0) + first
+                cmax = int(cnt.max()) if len(rows) else 0
+                res.append((lo + first, info[first:K].copy(), rows - first, nms[rows, :cmax].copy(), prob[rows, :cmax].copy()))
                 return
             for j in range(first, K):
                 lines, pred = _package(self.s.num_cls, info[j], raw[j], nms[j], prob[j])
@@ -241,6 +244,23 @@ class TimeShard:
         if self.det is not None:
             self.det.close()
             self.det = None
+
+
+def unpack_block(block, num_cls):
+    """[(frame, info, lines, cls_pred)] of one finish_blocks() record, as finish() returns them."""
+    f0, info, rows, nms, prob = block
+    out = []
+    where = {int(r): k for k, r in enumerate(rows)}
+    for j in range(len(info)):
+        if j in where:
+            k, c = where[j], int(info[j]["n_nms"])
+            pred = np.zeros((c, num_cls))
+            pred[:, -1] = prob[k, :c]
+            pred[:, 0] = 1 - prob[k, :c]
+            out.append((f0 + j, info[j], nms[k, :c].copy(), pred))
+        else:
+            out.append((f0 + j, info[j], np.array([]), np.zeros((0, num_cls))))
+    return out
 
 
 def run_time_sharded(window_sec, fps, mask, num_cls, cfg, total_frames, read, *, dist=None, rank=0, world=1, device=0,

@@ -72,3 +72,27 @@ def test_bench_config1_end_to_end_workload():
     assert "BGR" in d["config"]["workload"] and d["config"]["frame"] == [960, 540]
     assert d["parity"]["verdict"] == "identical" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["detections"]["raw_segments"] > 0
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """The "nccl" (= RCCL) branch of the timed harness -- process-group init on the device, barrier, max-reduce of the time,
+    all-gather of the detection counts on device tensors -- with a world of one rank launched the way the driver launches N
+    (a one-GPU box cannot hold two RCCL ranks; the two-rank run of this suite goes over gloo)."""
+    env = dict(os.environ, MDH_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "128", "--steps", "6", "--warmup", "2",
+                          "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0 and d["detections"]["lit_pixels"] > 0
+
+
+def test_bench_classic_and_accumulator_entries():
+    d = _run(["--detector", "classic", "--batch", "128", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--parity-frames", "24"])
+    assert d["parity"]["verdict"] == "identical" and "ClassicDetector" in d["config"]["workload"] and d["roofline"]["kernel"] == "classic"
+    d = _run(["--hough-mode", "accumulator", "--batch", "128", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--parity-frames", "128"])
+    assert d["parity"]["verdict"] == "matched under tolerance" and d["parity"]["records_exact"] >= 1
+    assert "accumulator" in d["config"]["workload"]
