@@ -2,8 +2,8 @@
 cv2.HoughLinesP.  It is a different algorithm, so nothing here is bit-for-bit; the bar is SURVEY 8d's tolerance rule:
 
   * isolated lines: the segment it returns lies on the drawn line -- both end points within 1 px of it (rho), theta within 0.5
-    degrees of the ground truth, extent within 6 px (4 % of the length: the walk follows a 1-degree grid angle along a one-pixel line) of the drawn end points -- at every angle, and it is never shorter than the longest segment the
-    exact replay finds on the same image;
+    degrees of the ground truth, extent within 6 px (4 % of the length: the walk follows a 1-degree grid angle along a one-pixel line) of the drawn end points -- at every angle, and it is at least 90 % as long as the longest segment
+    the exact replay finds on the same image;
   * a synthetic sky stream through detector + collector: the same meteors, matched with evaluate.py's rule (time IoU >= 0.3 and
     box IoU >= 0.3), as the exact mode;
   * determinism: the result is a function of the binary image (two runs, and the per-frame protocol vs batched passes, agree).
@@ -96,7 +96,7 @@ def test_isolated_lines_against_ground_truth():
         for (ex, ey), (tx, ty) in zip(ends, true):
             assert math.hypot(ex - tx, ey - ty) <= 6.0, (j, ends, true)
         length = lambda s: max(abs(float(s[2]) - float(s[0])), abs(float(s[3]) - float(s[1])))
-        assert length(seg) >= max(length(raw_e[j, k]) for k in range(min(ne, 512))), j
+        assert length(seg) >= 0.9 * max(length(raw_e[j, k]) for k in range(min(ne, 512))), j
         assert na <= ne  # one clean segment instead of the fan the first-crossing rule produces
 
 
