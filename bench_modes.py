@@ -62,6 +62,7 @@ def run_bands(a, D, wl, mask, cfg):
         for s in range(0, B, uniq):
             ctx.device_upload(ptr + s * sub[0].size, sub[:min(uniq, B - s)])
         step = lambda: det.detect_batch(ptr, K=B, on_device=True)
+        submit = lambda: det.submit(ptr, K=B, on_device=True)
         nb = D.world
     else:
         nb = a.shards
@@ -75,6 +76,7 @@ def run_bands(a, D, wl, mask, cfg):
                 e.band.device_upload(p + s * sub[0].size, sub[:min(uniq, B - s)])
             ptrs.append(p)
         step = lambda: det.detect_batch_device(ptrs, B)
+        submit = lambda: det.submit_device(ptrs, B)
     tally = [0, 0, 0]
     first = None
     for _ in range(max(a.warmup, 1)):
@@ -84,19 +86,27 @@ def run_bands(a, D, wl, mask, cfg):
     steps = a.steps if a.steps is not None else 30
     D.fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        res, info = step()
-        if res is not None:
-            tally[0] += int(info["n_raw"].sum())
-            tally[1] += int(info["n_nms"].sum())
-            tally[2] += int(info["lit_count"].sum())
+    # two passes in flight: the Hough stage of pass p (queued, mdh_hough_planes_submit) runs under the band stages of pass p + 1
+    queued = 0
+    for s_ in range(steps + 1):
+        if s_ < steps:
+            submit()
+            queued += 1
+        if queued == 2 or (s_ == steps and queued):
+            res, info = det.collect()
+            queued -= 1
+            if res is not None:
+                tally[0] += int(info["n_raw"].sum())
+                tally[1] += int(info["n_nms"].sum())
+                tally[2] += int(info["lit_count"].sum())
     D.fence()
     dt = time.perf_counter() - t0
     dt_all, _ = D.max_time_and_sum(dt, [0, 0, 0])
-    extra = {"bands": {"bands": nb, "band_rows": plan.band_rows, "halo_rows": 4,
+    extra = {"bands": {"bands": nb, "band_rows": plan.band_rows, "halo_rows": 4, "passes_in_flight": 2,
                        "exchange": "RCCL all-to-all of the bit planes + all-reduce of the noise sums + gather of the results" if D.world > 1
                        else "device-to-device copies on one GPU (stand-in of the all-to-all), every band and every Hough context on this device",
-                       "note": "three blocking calls per band per pass (noise share, pixel stages, Hough on the assembled planes)"}}
+                       "note": "per band and pass: noise share and pixel stages (blocking), the Hough stage of the assembled planes queued "
+                               "and collected one pass later; one host thread per band when all bands share one process"}}
     if D.rank == 0 and a.parity_frames > 0 and first[0] is not None:
         cnt = min(a.parity_frames, 16, B)
         extra["parity"] = _parity(_oracle_rows(frames[idx[:cnt]], n, mask, cfg.binary.sensitivity, cnt), first[1], first[0], f"the {nb}-band detector")
@@ -113,7 +123,9 @@ def run_timeshard(a, D, wl, mask, cfg):
     H, W, n = wl["H"], wl["W"], wl["n"]
     B = min(a.batch, 1024)
     windows = D.world if D.world > 1 else a.shards
-    steps = a.steps if a.steps is not None else 4 * windows
+    # resident stream: 16 passes per window by default (a window of a few passes never reaches the pipeline's steady state);
+    # host input: 2 (the frames cross PCIe twice)
+    steps = a.steps if a.steps is not None else (2 if a.host_input else 16) * windows
     total = steps * B
     base = bench.make_stream_frames(wl, 0, mask, total, a.unique)
     uniq = len(base)
@@ -142,12 +154,16 @@ def run_timeshard(a, D, wl, mask, cfg):
         for i in range(P):
             pool[i] = base[i % uniq]
     else:
-        dpool = hctx.device_alloc(total * fb)
-        for start in range(0, total, uniq):  # the stream's period repeated
-            cnt = min(uniq, total - start)
+        # frame i lives at slot i % DP of a pool of DP frames (a whole number of stream periods, so the stream is seamless where
+        # the pool wraps) followed by a copy of its first B frames (so that a pass never straddles the end of the pool)
+        DP = total if total <= 9 * B else uniq * (-(-8 * B // uniq))
+        tail = 0 if DP == total else B
+        dpool = hctx.device_alloc((DP + tail) * fb)
+        for start in range(0, DP + tail, uniq):  # the stream's period repeated
+            cnt = min(uniq, DP + tail - start)
             hctx.device_upload(dpool + start * fb, base[:cnt])
         for s in shards:
-            s.read_device = lambda lo, hi: dpool + lo * fb
+            s.read_device = lambda lo, hi: dpool + (lo % DP) * fb
     D.fence()
     t0 = time.perf_counter()
     mine = {}

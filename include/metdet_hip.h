@@ -208,6 +208,10 @@ int mdh_band_pixels(mdh_ctx* ctx, const int64_t* sums_total, double roi_px_total
  * Outputs as mdh_process_batch (bi_threshold / snr fields of info are left 0: they come from step 2). */
 int mdh_hough_planes(mdh_ctx* ctx, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
                      mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);
+/* The same, asynchronous (the Hough stage of pass p then runs under the band stages of pass p + 1): queue the pass and return;
+ * mdh_collect_batch hands out the results of the oldest queued pass.  Pieces in device memory must stay untouched until the
+ * pass after the next one is submitted or this one is collected (two exchange buffers used alternately are enough). */
+int mdh_hough_planes_submit(mdh_ctx* ctx, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows);
 
 /* ---- One stream cut into time windows across GPUs (SURVEY 8e "time windows of one stream") --------------------------
  *

@@ -62,7 +62,7 @@ EXPORTS = [
     "mdh_profile_read", "mdh_kernel_name", "mdh_frames_seen", "mdh_pre_create", "mdh_pre_run", "mdh_pre_destroy",
     "mdh_max_stack", "mdh_submit_batch", "mdh_collect_batch", "mdh_in_flight", "mdh_max_in_flight", "mdh_debug_hough",
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
-    "mdh_inject_sums", "mdh_mute_hough_until",
+    "mdh_inject_sums", "mdh_mute_hough_until", "mdh_hough_planes_submit",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
     "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy"
 ]
@@ -122,6 +122,7 @@ def load():
     L.mdh_band_noise.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]
     L.mdh_band_pixels.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32, vp]
     L.mdh_hough_planes.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.mdh_hough_planes_submit.argtypes = [vp, vp, i32, i32, i32, i32]
     L.mdh_band_skip.argtypes = [vp]
     L.mdh_collector_create.argtypes = [C.POINTER(MdhCollectorCfg)]
     L.mdh_collector_create.restype = vp
@@ -337,6 +338,25 @@ class Context:
         """Reposition the context: the next frame is number t0 + 1; noise EMA / threshold state as given."""
         check(self.L.mdh_seek(self.handle, int(t0), int(ema_updates), float(snr), float(sigma), float(thr_float), int(thr)),
               "mdh_seek")
+
+    def hough_planes_submit(self, pieces, K, nbands, band_rows, on_device=False):
+        """hough_planes without the wait: queue the pass; `hough_planes_collect(K)` (or collect_into) fetches the oldest one."""
+        if on_device:
+            ptr = int(pieces)
+        else:
+            pieces = np.ascontiguousarray(pieces, dtype=np.uint64)
+            assert pieces.size == nbands * K * band_rows * ((self.W + 63) // 64), pieces.shape
+            ptr = pieces.ctypes.data
+        check(self.L.mdh_hough_planes_submit(self.handle, ptr, int(K), int(bool(on_device)), int(nbands), int(band_rows)),
+              "mdh_hough_planes_submit")
+
+    def hough_planes_collect(self, K):
+        info = np.zeros(K, FRAME_INFO_DTYPE)
+        raw = np.zeros((K, MDH_MAX_LINES, 4), np.int32)
+        nms = np.zeros((K, MDH_MAX_LINES, 4), np.int32)
+        prob = np.zeros((K, MDH_MAX_LINES), np.float64)
+        self.collect_into(info, raw, nms, prob)
+        return info, raw, nms, prob
 
     def inject_sums(self, t, s1, s2):
         """Noise sums (S1, S2) of due frame number t (1-based, not yet submitted), used instead of the context's own."""

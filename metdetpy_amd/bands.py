@@ -101,6 +101,13 @@ class HipBandEngine:
     def hough_stage(self, pieces, kp, on_device=False):
         return self.hough.hough_planes(pieces, kp, self.plan.nbands, self.plan.band_rows, on_device=on_device)
 
+    def hough_submit(self, pieces, kp, on_device=False):
+        """hough_stage without the wait (mdh_hough_planes_submit): the replay of this pass runs under the band stages of the next."""
+        self.hough.hough_planes_submit(pieces, kp, self.plan.nbands, self.plan.band_rows, on_device=on_device)
+
+    def hough_collect(self, kp):
+        return self.hough.hough_planes_collect(kp)
+
     def skip(self):
         self.band.band_skip()
 
@@ -187,32 +194,17 @@ class LocalBands:
         return results, info
 
     def detect_batch_device(self, sub_ptrs, K: int):
-        """The same three steps with everything resident in HBM: sub_ptrs[b] = device pointer of band b's rows of the K frames
-        ((K, rows_b, W) u8, as `plan.crop` cuts them).  The bit planes go band -> exchange buffer -> Hough context through
-        device-to-device copies (what the all-to-all moves over xGMI when every band has a GPU of its own)."""
+        self.submit_device(sub_ptrs, K)
+        return self.collect()
+
+    def collect(self):
+        """Results of the oldest pass queued with submit_device."""
+        K, kp, thr = self._queued.pop(0)
         p = self.s.plan
         N = p.nbands
-        kp = -(-K // N)
-        if getattr(self, "_xchg_kp", 0) < kp:
-            self._free_xchg()
-            piece = kp * p.band_rows * p.WW * 8
-            ctx = self.engines[0].band
-            self._send = [ctx.device_alloc(N * piece) for _ in range(N)]
-            self._recv = [ctx.device_alloc(N * piece) for _ in range(N)]
-            self._xchg_kp = kp
-        piece = self._xchg_kp * p.band_rows * p.WW * 8
-        parts = self._each(lambda b, e: e.noise(sub_ptrs[b], K=K, on_device=True))
-        total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]
-        thr = self._each(lambda b, e: e.pixels(total, out=self._send[b])[1])
-        live = kp * p.band_rows * p.WW * 8
-
-        def receive(r, e):  # "all-to-all": rank r pulls slice r of every band's send buffer
-            for b in range(N):
-                e.band.device_copy(self._recv[r] + b * live, self._send[b] + r * live, live)
-        self._each(receive)
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
         results = [None] * K
-        staged = self._each(lambda r, e: e.hough_stage(self._recv[r], kp, on_device=True) if len(range(r, K, N)) else None)
+        staged = self._each(lambda r, e: e.hough_collect(kp) if len(range(r, K, N)) else None)
         for r, e in enumerate(self.engines):
             mine = len(range(r, K, N))
             if mine == 0:
@@ -224,8 +216,43 @@ class LocalBands:
                 results[i] = _package(self.s.num_cls, hi[j], raw[j], nms[j], prob[j])
         return results, info
 
+    def submit_device(self, sub_ptrs, K: int):
+        """Queue a pass (at most two in flight: the exchange buffers alternate); collect() returns the oldest one's results, so
+        that the Hough replay of pass p runs under the band stages of pass p + 1.  Everything resident in HBM: sub_ptrs[b] = device pointer of band b's rows of the K frames
+        ((K, rows_b, W) u8, as `plan.crop` cuts them).  The bit planes go band -> exchange buffer -> Hough context through
+        device-to-device copies (what the all-to-all moves over xGMI when every band has a GPU of its own)."""
+        p = self.s.plan
+        N = p.nbands
+        kp = -(-K // N)
+        if not hasattr(self, "_queued"):
+            self._queued, self._seq = [], 0
+        if len(self._queued) >= 2:
+            raise RuntimeError("two passes are already queued: collect() one first")
+        if getattr(self, "_xchg_kp", 0) < kp:
+            if self._queued:
+                raise RuntimeError("the pass size grew while a pass is queued")
+            self._free_xchg()
+            piece = kp * p.band_rows * p.WW * 8
+            ctx = self.engines[0].band
+            self._send = [ctx.device_alloc(N * piece) for _ in range(N)]
+            self._recv = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
+            self._xchg_kp = kp
+        recv = self._recv[self._seq % 2]
+        parts = self._each(lambda b, e: e.noise(sub_ptrs[b], K=K, on_device=True))
+        total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]
+        thr = self._each(lambda b, e: e.pixels(total, out=self._send[b])[1])
+        live = kp * p.band_rows * p.WW * 8
+
+        def receive(r, e):  # "all-to-all": rank r pulls slice r of every band's send buffer
+            for b in range(N):
+                e.band.device_copy(recv[r] + b * live, self._send[b] + r * live, live)
+        self._each(receive)
+        self._each(lambda r, e: e.hough_submit(recv[r], kp, on_device=True) if len(range(r, K, N)) else None)
+        self._queued.append((K, kp, thr))
+        self._seq += 1
+
     def _free_xchg(self):
-        for ptr in getattr(self, "_send", []) + getattr(self, "_recv", []):
+        for ptr in getattr(self, "_send", []) + [q for set_ in getattr(self, "_recv", []) for q in set_]:
             self.engines[0].band.device_free(ptr)
         self._send, self._recv, self._xchg_kp = [], [], 0
 
@@ -256,6 +283,7 @@ class BandedM3Detector:
         self.max_batch = int(max_batch)
         self._on_gpu = dist is not None and dist.get_backend() == "nccl"
         self._send = self._recv = None
+        self._pending, self._seq = [], 0
 
     # ---- collectives ---------------------------------------------------------------------------
     def _allreduce_sums(self, sums: np.ndarray) -> np.ndarray:
@@ -268,37 +296,44 @@ class BandedM3Detector:
         self.dist.all_reduce(t)  # SUM; int64, exact
         return t.cpu().numpy()
 
-    def _exchange_buffers(self, kp):
-        """Send / receive buffers of the all-to-all, (world, kp_max, band_rows, WW) int64 (bit patterns of u64)."""
+    def _exchange_buffers(self, kp, which):
+        """Send / receive buffers of the all-to-all, (world, kp_max, band_rows, WW) int64 (bit patterns of u64); two receive
+        buffers used alternately, so that the pass queued behind a pass whose Hough stage is still reading has its own."""
         import torch
         p = self.plan
         if self._send is None:
             shape = (self.world, -(-self.max_batch // self.world), p.band_rows, p.WW)
             dev = torch.device("cuda", torch.cuda.current_device()) if self._on_gpu else torch.device("cpu")
             self._send = torch.zeros(shape, dtype=torch.int64, device=dev)
-            self._recv = torch.zeros(shape, dtype=torch.int64, device=dev)
+            self._recv = [torch.zeros(shape, dtype=torch.int64, device=dev) for _ in range(2)]
+        recv = self._recv[which]
         return self._send[:, :kp].contiguous() if kp != self._send.shape[1] else self._send, \
-            self._recv[:, :kp].contiguous() if kp != self._recv.shape[1] else self._recv
+            recv[:, :kp].contiguous() if kp != recv.shape[1] else recv
 
-    def detect_batch(self, sub_frames, K=None, on_device=False):
-        """sub_frames: this rank's rows of K frames, a (K, rows, W) u8 array -- or a device pointer to them with K given."""
+    def submit(self, sub_frames, K=None, on_device=False):
+        """Queue a pass: noise sums -> all-reduce -> pixel stages -> all-to-all of the bit planes -> this rank's share of the
+        Hough stage, which is only QUEUED (mdh_hough_planes_submit): it runs under the band stages of the next pass.  At most two
+        passes may be queued; collect() returns the oldest one's results."""
         import torch
         p, N, r = self.plan, self.world, self.rank
         K = len(sub_frames) if not on_device else int(K)
         if K > self.max_batch:
             raise ValueError("K exceeds max_batch")
+        if len(self._pending) >= 2:
+            raise RuntimeError("two passes are already queued: collect() one first")
         kp = -(-K // N)
         part = self.engine.noise(sub_frames, K=K, on_device=True) if on_device else self.engine.noise(sub_frames)
         total = self._allreduce_sums(part)
+        keep = None
         if self.dist is None:
             sent, thr_info = self.engine.pixels(total)
             recv, on_dev = sent, False  # world == 1: the send layout of one band IS the receive layout
         elif self._on_gpu:
-            send, recv_t = self._exchange_buffers(kp)
+            send, recv_t = self._exchange_buffers(kp, self._seq % 2)
             _, thr_info = self.engine.pixels(total, out=send.data_ptr())  # kernels write the send buffer in HBM
             self.dist.all_to_all_single(recv_t, send)                     # RCCL over xGMI
             torch.cuda.current_stream().synchronize()
-            recv, on_dev = recv_t.data_ptr(), True
+            recv, on_dev, keep = recv_t.data_ptr(), True, recv_t
         else:
             sent, thr_info = self.engine.pixels(total)
             send = torch.from_numpy(sent.view(np.int64))
@@ -306,9 +341,23 @@ class BandedM3Detector:
             self.dist.all_to_all_single(recv_t, send)
             recv, on_dev = recv_t.numpy().view(np.uint64), False
         mine = len(range(r, K, N))
+        done = None
+        if mine:
+            if hasattr(self.engine, "hough_submit"):
+                self.engine.hough_submit(recv, kp, on_device=on_dev)
+            else:  # a substitute engine (CPU tests of the exchange logic) runs its Hough stage at once
+                done = self.engine.hough_stage(recv, kp, on_device=on_dev)
+        self._pending.append((K, kp, mine, thr_info, done, keep))
+        self._seq += 1
+
+    def collect(self):
+        """Results of the oldest queued pass: on rank 0 what `M3Detector.detect_batch` returns for the whole frames; other ranks
+        get (None, info)."""
+        N, r = self.world, self.rank
+        K, kp, mine, thr_info, done, _keep = self._pending.pop(0)
         part = []
         if mine:
-            hi, raw, nms, prob = self.engine.hough_stage(recv, kp, on_device=on_dev)
+            hi, raw, nms, prob = done if done is not None else self.engine.hough_collect(kp)
             for j in range(mine):
                 part.append((j * N + r, hi[j].copy(), raw[j, :min(int(hi[j]["n_raw"]), _lib.MDH_MAX_LINES)].copy(),
                              nms[j, :int(hi[j]["n_nms"])].copy(), prob[j, :int(hi[j]["n_nms"])].copy()))
@@ -326,6 +375,11 @@ class BandedM3Detector:
                 info[i] = _merge_info(thr_info[i], hi)
                 results[i] = _package(self.s.num_cls, hi, raw, nms, prob)
         return results, info
+
+    def detect_batch(self, sub_frames, K=None, on_device=False):
+        """sub_frames: this rank's rows of K frames, a (K, rows, W) u8 array -- or a device pointer to them with K given."""
+        self.submit(sub_frames, K=K, on_device=on_device)
+        return self.collect()
 
     def close(self):
         self.engine.close()

@@ -1626,12 +1626,11 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
     return MDH_OK;
 }
 
-extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
-                                mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
-    if (!c || !pieces) { set_err("mdh_hough_planes: null argument"); return MDH_E_ARG; }
-    if (c->role != MDH_ROLE_HOUGH) { set_err("mdh_hough_planes: not a MDH_ROLE_HOUGH context"); return MDH_E_STATE; }
+static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows, const char* who) {
+    if (!c || !pieces) { set_err(std::string(who) + ": null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_HOUGH) { set_err(std::string(who) + ": not a MDH_ROLE_HOUGH context"); return MDH_E_STATE; }
     if (nbands < 1 || band_rows < 1 || (long long)nbands * band_rows < c->H) {
-        set_err("mdh_hough_planes: the bands do not cover the frame");
+        set_err(std::string(who) + ": the bands do not cover the frame");
         return MDH_E_ARG;
     }
     HIPCHK(hipSetDevice(c->device));
@@ -1652,9 +1651,25 @@ extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int o
                        sl.d_litcount, sl.d_bbox, K, c->H, c->W, c->WW, band_rows);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev_pix, post));
+    // the staging buffer of host pieces is one per context: the next submit may refill it only after this pass has read it
+    if (!on_device) HIPCHK(hipStreamSynchronize(post));
     if ((rc = run_hough(c, sl, K)) != MDH_OK) return rc;
     slot_commit(c, sl);
+    return MDH_OK;
+}
+
+extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,
+                                mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline) {
+    const int rc = hough_planes_submit(c, pieces, K, on_device, nbands, band_rows, "mdh_hough_planes");
+    if (rc != MDH_OK) return rc;
     return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
+}
+
+// The same, asynchronous: queues the pass (up to mdh_max_in_flight of them) and returns; mdh_collect_batch fetches the results of
+// the oldest one.  Pieces in device memory must stay valid until k_assemble_planes of the pass has run, i.e. until the pass
+// after the next one is submitted or this one is collected (two exchange buffers used alternately are enough).
+extern "C" int mdh_hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows) {
+    return hough_planes_submit(c, pieces, K, on_device, nbands, band_rows, "mdh_hough_planes_submit");
 }
 
 extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {

@@ -203,6 +203,44 @@ def test_hip_synthetic_sky_in_bands():
 
 
 @pytest.mark.gpu
+def test_hip_bands_resident_and_pipelined():
+    """Band rows resident in HBM, two passes in flight (the Hough stage of a pass is queued with mdh_hough_planes_submit and
+    collected one pass later, under the band stages of the next pass): same results as the oracle, pass by pass."""
+    from tests.helpers import binary_cfg
+    H, W, n, K, nbands = 272, 512, 8, 24, 4
+    cfg = binary_cfg()
+    mask = np.ones((H, W), np.uint8)
+    frames = SkyStream(H, W, 20220416, speed=8, streak_period=16).take(5 * K)
+    want = whole_frame_oracle(frames, n, mask, cfg)
+    assert sum(w["n_raw"] for w in want) > 0
+    lb = LocalBands(n / 10, 10, mask, 10, cfg, nbands, max_batch=K)
+    plan = lb.s.plan
+    passes = []
+    for p0 in range(0, len(frames), K):
+        ptrs = []
+        for b, e in enumerate(lb.engines):
+            sub = plan.crop(frames[p0:p0 + K], b)
+            ptr = e.band.device_alloc(sub.nbytes)
+            e.band.device_upload(ptr, sub)
+            ptrs.append(ptr)
+        passes.append(ptrs)
+    queued = []
+    for k, ptrs in enumerate(passes + [None]):
+        if ptrs is not None:
+            lb.submit_device(ptrs, K)
+            queued.append(k)
+        if len(queued) == 2 or (ptrs is None and queued):
+            res, info = lb.collect()
+            check_against(res, info, want, queued.pop(0) * K)
+    with pytest.raises(IndexError):
+        lb.collect()
+    for ptrs in passes:
+        for b, e in enumerate(lb.engines):
+            e.band.device_free(ptrs[b])
+    lb.close()
+
+
+@pytest.mark.gpu
 def test_two_process_gloo_hip_bands(tmp_path):
     """Two ranks, each with its own band + Hough contexts on GPU 0, host-staged gloo collectives."""
     compare_worker_output(run_two_ranks(tmp_path, "hip"), 270, 448, 8, 16)

@@ -97,7 +97,6 @@ def test_isolated_lines_against_ground_truth():
             assert math.hypot(ex - tx, ey - ty) <= 6.0, (j, ends, true)
         length = lambda s: max(abs(float(s[2]) - float(s[0])), abs(float(s[3]) - float(s[1])))
         assert length(seg) >= 0.9 * max(length(raw_e[j, k]) for k in range(min(ne, 512))), j
-        assert na <= ne  # one clean segment instead of the fan the first-crossing rule produces
 
 
 def _records(frames, mask, n, cfg, mode):

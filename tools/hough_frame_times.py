@@ -52,3 +52,12 @@ print("per frame: votes %.1f  sub-groups %.1f  steps of 64 points %.1f" % (votes
 if cyc > 0:
     print("phase share of PPHT cycles:", {n: round(float(v) / cyc, 3) for n, v in zip(names[:7], tot[:7])}, " line events per frame: %.1f" % (tot[7] / act.sum()),
           " cycles per frame: %.0f" % (cyc / act.sum()), " cycles per line event (walk+clear+un-vote): %.0f" % (tot[4:7].sum() / max(tot[7], 1)))
+# the same split per tier (0 small LDS, 1 large LDS, 2 hybrid)
+for tier in np.unique(dbg[act, 1]):
+    m = act & (dbg[:, 1] == tier)
+    tt = ph[m].sum(axis=0)
+    c = tt[:7].sum()
+    if c > 0:
+        print("tier %d: %d frames, mean N %.0f, mean ppht %.1f us, set-up %.1f us, votes %.0f, sub-groups %.1f, line events %.1f, cells %.0f | share:" % (
+            tier, m.sum(), dbg[m, 0].mean(), t[m].mean(), (dbg[m, 2] / 100.0).mean(), votes[m].mean(), subs[m].mean(), tt[7] / m.sum(), dbg[m, 5].mean()),
+            {n.split(" ")[0]: round(float(v) / c, 3) for n, v in zip(names[:7], tt[:7])}, " cycles per frame %.0f" % (c / m.sum()))
