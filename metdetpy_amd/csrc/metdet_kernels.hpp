@@ -718,22 +718,25 @@ __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ bl
     }
     return keep;
 }
-__device__ __forceinline__ void morph_select_block(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
-                                                   unsigned* __restrict__ workcount, const PassGeom& g, int i, int tid) {
+// The work list is kept PER FRAME (segment i = entries [i * blocks_per_frame, ...), count in workcount[i]).  One list with one
+// counter serialised this kernel on a dense binary (a lowered threshold lets noise through: every block of every frame is kept):
+// 130 k same-address atomics, 1.35 ms per 128 frames at 8K -- more than the stencil kernel behind it (rocprofv3 PMC: SQ_WAIT_ANY ~
+// SQ_WAVE_CYCLES).  With a counter per frame the appends of different frames go to different L2 channels.  (Aggregating over
+// 1024-thread workgroups instead cost the 4K pipeline 9 %: such a workgroup needs 16 wave slots on one CU at once.)
+__global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
+                                                      unsigned* __restrict__ workcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const int i = blockIdx.y;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool keep = morph_block_keep(blockcnt, g, i, tid);
     const u64 m = __ballot(keep);
     if (!m) return;
     const int lane = threadIdx.x & 63;
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(workcount, (unsigned)__popcll(m));
+    if (lane == 0) base = atomicAdd(&workcount[i], (unsigned)__popcll(m));
     base = __shfl(base, 0);
-    if (keep) worklist[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
-}
-__global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
-                                                      unsigned* __restrict__ workcount, PassGeom g) {
-    RAISE_WAVE_PRIORITY();
-    morph_select_block(blockcnt, worklist, workcount, g, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+    if (keep) worklist[(size_t)i * (nb * g.WW) + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
 }
 
 // One thread owns one listed block (a word column x a band of RB rows) and slides down it with 3-row pipelines.
@@ -781,12 +784,22 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
         const bool dC_in = yd >= 0 && yd < g.H;
         u128 eC = dC_in ? hor_and3_open(dC, q) : ones;  // rows outside the image never win the erode
         const int ya = yy - 3;
-        if (ya >= y0 && ya < g.H) {
-            const u64 a = (u64)((dA & dB & eC & q.valid) >> 3);
-            // Only words with lit pixels are stored, and listed for the sparse dynamic-mask pass.
-            if (a) {
-                dst[(size_t)ya * g.WW + w] = ActWord{a, (u64)t};
-                nzlist[atomicAdd(nzcount, 1u)] = (unsigned)((size_t)i * g.H * g.WW + (size_t)ya * g.WW + w);
+        {
+            u64 a = 0;
+            if (ya >= y0 && ya < g.H) a = (u64)((dA & dB & eC & q.valid) >> 3);
+            // Only words with lit pixels are stored, and listed for the sparse dynamic-mask pass: one append per wave and row step
+            // (the lanes of a wave walk their items in lockstep), not one same-address atomic per word.
+            const u64 have = __ballot(a != 0);
+            if (have) {
+                const int lane_ = threadIdx.x & 63;
+                const int leader = __builtin_ctzll(have);
+                unsigned base = 0;
+                if (lane_ == leader) base = atomicAdd(nzcount, (unsigned)__popcll(have));
+                base = __shfl(base, leader);
+                if (a) {
+                    dst[(size_t)ya * g.WW + w] = ActWord{a, (u64)t};
+                    nzlist[base + __popcll(have & ((1ull << lane_) - 1))] = (unsigned)((size_t)i * g.H * g.WW + (size_t)ya * g.WW + w);
+                }
             }
         }
         bA = bB; bB = brow;
@@ -796,10 +809,26 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
     }
   }
 }
+// Every frame's segment of the work list gets the same share of the grid's waves (nwaves / K of them, at least one), which walk
+// it 64 entries at a time: one look at the frame's count per wave.  (Walking all wave-slots of all segments instead -- a count
+// load per slot -- cost the sparse 4K pipeline 10 %: 63 dependent loads per wave to find out that there is nothing to do.)
 __device__ __forceinline__ void morph_close_items(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
-                                                  unsigned nwork, ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
-                                                  unsigned* __restrict__ nzcount, const PassGeom& g, unsigned first, unsigned stride) {
-    for (unsigned e = first; e < nwork; e += stride) morph_close_item(bbits, worklist[e], act_ring, nzlist, nzcount, g);
+                                                  const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
+                                                  unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, const PassGeom& g,
+                                                  unsigned first_wave, unsigned nwaves) {
+    const unsigned per_frame = (unsigned)(((g.H + MORPH_RB - 1) / MORPH_RB) * g.WW);
+    const unsigned K = (unsigned)g.K;
+    const unsigned wpf = nwaves >= K ? nwaves / K : 1u;  // waves per frame
+    const unsigned groups = nwaves / wpf;                // frames walked side by side
+    const unsigned grp = __builtin_amdgcn_readfirstlane(first_wave / wpf);
+    const unsigned sub = __builtin_amdgcn_readfirstlane(first_wave - grp * wpf);
+    const unsigned lane = threadIdx.x & 63;
+    if (grp >= groups) return;
+    for (unsigned i = grp; i < K; i += groups) {
+        const unsigned cnt = workcount[i];
+        const unsigned* seg = worklist + (size_t)i * per_frame;
+        for (unsigned e = sub * 64 + lane; e < cnt; e += wpf * 64) morph_close_item(bbits, seg[e], act_ring, nzlist, nzcount, g);
+    }
 }
 // One frame (the per-frame protocol): every block tests its own neighbourhood and goes ahead -- no work list, one launch less
 // in the frame's chain of dependent commands.
@@ -814,7 +843,7 @@ __global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ 
                                                     const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
                                                     unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
     RAISE_WAVE_PRIORITY();
-    morph_close_items(bbits, worklist, *workcount, act_ring, nzlist, nzcount, g, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    morph_close_items(bbits, worklist, workcount, act_ring, nzlist, nzcount, g, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
 }
 
 // a8 + a9 count.  Dynamic mask (Detector.py:234-242): a pixel is "alive" unless it was lit in ALL of the last
