@@ -208,6 +208,19 @@ class Context:
         nn = int(info["n_nms"])
         return info, self._raw1[:nr].copy(), self._nms1[:nn].copy(), self._prob1[:nn].copy()
 
+    def detect_fields(self):
+        """detect() for the per-frame loop, which is latency-bound: the frame's scalars as a plain tuple in FRAME_INFO_DTYPE's
+        field order (one tolist() instead of a record copy and a field lookup per attribute: ~5 us a frame)."""
+        rc = self.L.mdh_detect(self.handle, *self._p1)
+        if rc:
+            check(rc, "mdh_detect")
+        fields = self._info1.tolist()[0]
+        nr = min(fields[0], MDH_MAX_LINES)
+        if nr == 0:
+            return fields, self._empty4, self._empty4, self._empty1
+        nn = fields[1]
+        return fields, self._raw1[:nr].copy(), self._nms1[:nn].copy(), self._prob1[:nn].copy()
+
     def process_batch(self, frames, K=None, on_device=False):
         """frames: (K,H,W) uint8 ndarray (host) or an integer device pointer with K given."""
         if on_device:

@@ -87,6 +87,7 @@ struct Slot {
     u64* d_dst = nullptr;
     int *d_rowcount = nullptr, *d_litcount = nullptr, *d_bbox = nullptr;
     unsigned* d_workcnt = nullptr;   // [K] listed morphology blocks per frame (tail of the d_rowcount block)
+    unsigned* d_dense = nullptr;     // [1 + K] count + list of the pass's dense frames (k_morph_close_dense's work), same block
     int* d_lines = nullptr;
     // result block [off (K+1) | nraw (K) | lit counts (K) | gap (K) | frame scalars (K) | packed segments]: same layout on
     // the device and in pinned host memory, so the scalars and the head of the packed segments travel in ONE copy
@@ -459,10 +460,11 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_dst, K * words));
         // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
         // (+ K: the per-frame counts of the morphology work list, d_workcnt, cleared with the rest)
-        TRY(dev_alloc(s.d_rowcount, K * c->H + 6 * K));
+        TRY(dev_alloc(s.d_rowcount, K * c->H + 7 * K + 1));
         s.d_litcount = s.d_rowcount + K * c->H;
         s.d_bbox = s.d_litcount + K;
         s.d_workcnt = (unsigned*)(s.d_bbox + 4 * K);
+        s.d_dense = s.d_workcnt + K;
         TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
         {
             auto a16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -850,7 +852,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     const bool m3 = c->cfg.detector == MDH_DET_M3;
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
-                       (unsigned)((size_t)c->Kmax * c->H + 6 * (size_t)c->Kmax), sl.d_bandflag, (unsigned)((size_t)K * nb * c->WW),
+                       (unsigned)((size_t)c->Kmax * c->H + 7 * (size_t)c->Kmax + 1), sl.d_bandflag, (unsigned)((size_t)K * nb * c->WW),
                        (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
@@ -971,8 +973,13 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         } else {
         hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_bandflag,
                            sl.d_worklist, sl.d_workcnt, g);
+        // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
+        // waves leave after one load when the pass has none (MDH_MORPH_DENSE=0: everything through the list, A/B and parity testing)
+        static const bool dense = !(getenv("MDH_MORPH_DENSE") && atoi(getenv("MDH_MORPH_DENSE")) == 0);
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
-                           sl.d_nzlist, sl.d_nzcount, g);
+                           sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr);
+        if (dense)
+            hipLaunchKernelGGL(k_morph_close_dense, dim3(2048), dim3(64), 0, post, sl.d_bbits, sl.d_dense, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
         }
         span_end(c, post);
         EV_REC(c, sl.ev_close, post);

@@ -378,6 +378,22 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_U16
 #define WIDE_U16 4  // frames per load burst of the 16-pixels-per-lane kernel (A/B builds: -DWIDE_U16=8)
 #endif
+#ifndef WIDE_MAX3
+#define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
+#endif
+#ifndef WIDE_ONEBUF
+#define WIDE_ONEBUF 0  // one load buffer instead of two (A/B builds; fewer registers, but half the bytes in flight per wave)
+#endif
+// Three-input packed maximum.  gfx950 has no packed integer max3, but it has v_pk_maximum3_f16, and for the values this kernel
+// holds (0..255 in each 16-bit half) the bit patterns are non-negative f16 denormals, whose IEEE order is their integer order;
+// the kernels run with f16 denormals preserved (.amdhsa_float_denorm_mode_16_64 3, the HIP default), so the instruction returns
+// exactly the integer maximum.  (tests/test_gpu_parity.py walks every window length against the oracle.)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk_max3_u8(u16x2 a, u16x2 b, u16x2 c) {
+    const h16x2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b)),
+                                                  __builtin_bit_cast(h16x2, c));
+    return __builtin_bit_cast(u16x2, m);
+}
 // Per-frame protocol only (all null otherwise): see k_stack_threshold_wide.
 struct LeanArgs {
     uint8_t* copy_dst;          // ring slot that receives the copy of frame 0
@@ -469,6 +485,12 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     // yet overwritten only shrinks (suffix maxima, taken once when the refill starts: R_k = max(old_{k+1}.., oth)) and the
     // part already overwritten only grows (running prefix maximum P): window max = max(P, R_k).
     u16x2 gmax[NG][RW], oth[RW], pre[RW], suf[GS > 1 ? GS - 1 : 1][RW];
+    // WIDE_MAX3: with a three-input maximum the suffix maxima need not be kept: two instructions per frame instead of three and
+    // one kept temporary (T = max of the group's last two old slots and the other groups) instead of three suffix registers per
+    // pair (56 -> 32 registers of max state at n = 8).
+    constexpr bool MAX3 = WIDE_MAX3 != 0 && GS == 4;
+    constexpr bool ONEBUF = WIDE_ONEBUF != 0 && PPL == 16 && (N % U == 0);
+    u16x2 t23[RW];
     // Window sums: two 16-bit fields per register, updated with plain 32-bit adds / subtracts (a field never carries or
     // borrows: 255 * (N + 1) < 2^16, and the value leaving the window is part of the sum).  v_add_u32 / v_sub_u32 issue at
     // twice the rate of the packed 16-bit forms on gfx950 (tools/valu_rate.hip).
@@ -525,10 +547,12 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
             const int ub = bi * U;
             // prefetch the following burst (wraps into the next period)
             const int nb_first = (bi + 1 < NB) ? sb + (bi + 1) * U : sb + N;
+            if constexpr (!ONEBUF) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool in_period = (bi + 1 < NB) ? ((bi + 1) * U + u < N) : (u < N);
                 if (in_period) nxt[u] = fetch(min(i0 + nb_first + u + N - 1, e_max));
+            }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -542,6 +566,9 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         if constexpr (LEAN) {
                             if (copy_dst != nullptr && i == 0 && gw < words) *(dvec*)(copy_dst + off) = cur[u];
                         }
+                        // ONEBUF: the buffer of this frame is free once it is unpacked; the frame U steps ahead is fetched into
+                        // it right away (U - 1 frames of arithmetic, times the waves of the SIMD, cover the latency)
+                        if constexpr (ONEBUF) cur[u] = fetch(min(i0 + s + U + N - 1, e_max));
                         // b = (max - floor(sum / len) > T)  <=>  sum + T * len - max * len < 0.  The left side is within
                         // [-255 len, 510 len], i.e. inside int16 for len <= 16 (this kernel's N), so b is the sign bit of
                         // one packed multiply-add whose addend is sum + T * len (T >= 256 can never fire; clamping it
@@ -557,6 +584,49 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
 #pragma unroll
                         for (int r = 0; r < RW; ++r) {
                             sum[r] = sum[r] + a[r].u - win[slot][r].u;
+                            u16x2 m;
+                            if constexpr (MAX3) {
+                                const int g0 = grp * GS;
+                                if (kpos == 0) {
+                                    if constexpr (NG > 2) {  // maxima of the other groups, once per refill
+                                        u16x2 o3[NG - 1];
+                                        int c = 0;
+#pragma unroll
+                                        for (int h = 0; h < NG; ++h)
+                                            if (h != grp) o3[c++] = gmax[h][r];
+                                        u16x2 o = o3[0];
+                                        int k2 = 1;
+#pragma unroll
+                                        for (; k2 + 1 < NG - 1; k2 += 2) o = pk_max3_u8(o, o3[k2], o3[k2 + 1]);
+                                        if (k2 < NG - 1) o = __builtin_elementwise_max(o, o3[k2]);
+                                        oth[r] = o;
+                                    }
+                                    pre[r] = a[r].v;
+                                } else {
+                                    pre[r] = __builtin_elementwise_max(pre[r], a[r].v);
+                                }
+                                const u16x2 zero2 = {0, 0};
+                                const u16x2 o = NG > 2 ? oth[r] : (NG == 2 ? gmax[grp == 0 ? 1 : 0][r] : zero2);
+                                if (kpos == 0 && gsz >= 3) {
+                                    // T = max(old slots 2 .. gsz-1 of the group, other groups): serves this frame and the next
+                                    u16x2 T = win[g0 + 2][r].v;
+                                    if (gsz == 4) T = NG > 1 ? pk_max3_u8(T, win[g0 + 3][r].v, o) : __builtin_elementwise_max(T, win[g0 + 3][r].v);
+                                    else if (NG > 1) T = __builtin_elementwise_max(T, o);
+                                    t23[r] = T;
+                                    m = pk_max3_u8(a[r].v, win[g0 + 1][r].v, T);
+                                } else if (kpos == 1 && gsz >= 3) {
+                                    m = __builtin_elementwise_max(pre[r], t23[r]);
+                                } else {
+                                    // at most one old slot of the group is left (kpos >= gsz - 2)
+                                    const bool one_old = kpos == gsz - 2;
+                                    if (one_old && NG > 1) m = pk_max3_u8(pre[r], win[g0 + gsz - 1][r].v, o);
+                                    else if (one_old) m = __builtin_elementwise_max(pre[r], win[g0 + gsz - 1][r].v);
+                                    else if (NG > 1) m = __builtin_elementwise_max(pre[r], o);
+                                    else m = pre[r];
+                                }
+                                win[slot][r] = a[r];
+                                if (kpos == gsz - 1) gmax[grp][r] = pre[r];
+                            } else {
                             if (kpos == 0) {  // the refill of group grp starts: maxima of the other groups, suffix maxima of this one
                                 if constexpr (NG > 1) {
                                     u16x2 o = gmax[grp == 0 ? 1 : 0][r];
@@ -580,10 +650,11 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                                 pre[r] = __builtin_elementwise_max(pre[r], a[r].v);
                             }
                             win[slot][r] = a[r];
-                            u16x2 m = pre[r];
+                            m = pre[r];
                             if (kpos < gsz - 1) m = __builtin_elementwise_max(m, suf[kpos][r]);
                             else if (NG > 1) m = __builtin_elementwise_max(m, oth[r]);
                             if (kpos == gsz - 1) gmax[grp][r] = pre[r];
+                            }
                             // sum < (max - T) * len  <=>  bit 15 of sum + (max - T) * (-len) mod 2^16 (all terms < 2^15 for
                             // n <= 128); written as a multiply-add so that it maps to one v_pk_mad_u16
                             PK d, st;
@@ -614,8 +685,10 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                     }
                 }
             }
+            if constexpr (!ONEBUF) {
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            }
         }
     }
     if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
@@ -739,17 +812,13 @@ __global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict
     if (keep) worklist[(size_t)i * (nb * g.WW) + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
 }
 
-// One thread owns one listed block (a word column x a band of RB rows) and slides down it with 3-row pipelines.
-__device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbits, unsigned item, ActWord* __restrict__ act_ring,
+// One thread owns one block (a word column x a band of ROWS rows) and slides down it with 3-row pipelines.  `load_row(yc)` returns
+// the 128-bit window of image row yc around word column w (load_win_act's layout); `live` = the thread's column exists (the dense
+// kernel keeps the lanes beyond the last column in step for its lane exchanges).
+template <int ROWS, class Loader>
+__device__ __forceinline__ void morph_close_band(Loader&& load_row, int i, int w, int y0, bool live, ActWord* __restrict__ act_ring,
                                                  unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, const PassGeom& g) {
-  const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
-  {
-    const int i = item / (unsigned)(nb * g.WW);
-    const int tid = item - (unsigned)i * (unsigned)(nb * g.WW);
-    const int band = tid / g.WW, w = tid - band * g.WW;
-    const int y0 = band * MORPH_RB;
     const Win q = make_win(w, g.W);
-    const ActWord* src = bbits + (size_t)i * g.H * g.WW;
     const long long t = g.t_base + 1 + i;
     ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
     // The median of a row needs >= 5 set samples in some 3x3 window, i.e. >= 5 set bits in the three 128-bit row windows it is
@@ -764,11 +833,11 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
     const u128 ones = ~(u128)0;
     const int mx = (w == 0 || 64 * (w + 1) + 3 > g.W - 1) ? 2 : 1;
 #pragma unroll
-    for (int it = 0; it < MORPH_RB + 6; ++it) {
+    for (int it = 0; it < ROWS + 6; ++it) {
         const int yy = y0 - 3 + it;
         const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
         u128 mC = 0, dC = 0;
-        const u128 brow = load_win_act(src + (size_t)yc * g.WW, w, g.WW, (u64)t);
+        const u128 brow = load_row(yc);
         const int pC = __popcll((u64)brow) + __popcll((u64)(brow >> 64));
         const int ym = yy - 1;  // row whose median is complete now
         const int yd = yy - 2;
@@ -786,7 +855,7 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
         const int ya = yy - 3;
         {
             u64 a = 0;
-            if (ya >= y0 && ya < g.H) a = (u64)((dA & dB & eC & q.valid) >> 3);
+            if (live && ya >= y0 && ya < g.H) a = (u64)((dA & dB & eC & q.valid) >> 3);
             // Only words with lit pixels are stored, and listed for the sparse dynamic-mask pass: one append per wave and row step
             // (the lanes of a wave walk their items in lockstep), not one same-address atomic per word.
             const u64 have = __ballot(a != 0);
@@ -807,7 +876,59 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
         mA = mB; mB = mC;
         dA = dB; dB = eC;
     }
-  }
+}
+__device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbits, unsigned item, ActWord* __restrict__ act_ring,
+                                                 unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, const PassGeom& g) {
+    const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const int i = item / (unsigned)(nb * g.WW);
+    const int tid = item - (unsigned)i * (unsigned)(nb * g.WW);
+    const int band = tid / g.WW, w = tid - band * g.WW;
+    const ActWord* src = bbits + (size_t)i * g.H * g.WW;
+    const u64 t = (u64)(g.t_base + 1 + i);
+    morph_close_band<MORPH_RB>([&](int yc) { return load_win_act(src + (size_t)yc * g.WW, w, g.WW, t); }, i, w, band * MORPH_RB, true,
+                               act_ring, nzlist, nzcount, g);
+}
+// Dense binaries (8K at m3det_high: noise gets through the lowered threshold and EVERY block of a frame is listed).  The list
+// kernel then fetches each word of b five times (three tagged 16-byte loads per row step, 14 row steps per 8 output rows) and is
+// bound by those loads.  A frame with at least half of its blocks listed is left to this kernel instead: a wave takes 64
+// ADJACENT word columns of a band of 16 rows, so a lane loads its own word only and gets the three bits it needs from either
+// neighbour with one DPP wave shift each (lanes 0 and 63 fetch theirs), and the halo is 6 rows in 22 instead of 6 in 14: 1.4
+// loads per word instead of 5.25.  Blocks the list would not have named produce zeros here and store nothing -- same result.
+#define MORPH_DENSE_ROWS 16
+__global__ void __launch_bounds__(64) k_morph_close_dense(const ActWord* __restrict__ bbits, const unsigned* __restrict__ dense,
+                                                          ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
+                                                          unsigned* __restrict__ nzcount, PassGeom g) {
+    // dense[0] = number of dense frames of the pass, dense[1..] = their indices (written by k_morph_close, which looks at every
+    // frame's count anyway): a pass without such frames costs this launch one load per wave
+    const unsigned nd = dense[0];
+    if (nd == 0) return;
+    RAISE_WAVE_PRIORITY();
+    const int lane = threadIdx.x;
+    const unsigned cgroups = (unsigned)(g.WW + 63) / 64, bands = (unsigned)(g.H + MORPH_DENSE_ROWS - 1) / MORPH_DENSE_ROWS;
+    const unsigned per_frame = cgroups * bands;
+    for (unsigned item = blockIdx.x; item < nd * per_frame; item += gridDim.x) {
+        const unsigned f = item / per_frame, rest = item - f * per_frame;
+        const unsigned band = rest / cgroups, cg = rest - band * cgroups;
+        const int i = (int)dense[1 + f];
+        const int w = (int)cg * 64 + lane;
+        const bool live = w < g.WW;
+        const int wc = live ? w : g.WW - 1;
+        const ActWord* src = bbits + (size_t)i * g.H * g.WW;
+        const u64 t = (u64)(g.t_base + 1 + i);
+        auto load_row = [&](int yc) -> u128 {
+            const ActWord* row = src + (size_t)yc * g.WW;
+            const u64 c = live ? act_word(row, wc, t) : 0ull;
+            // what the neighbours need of this word: its top three bits (for the lane to the right) and its low three (to the left)
+            const int mine = (int)((unsigned)(c >> 61) | ((unsigned)(c & 7ull) << 3));
+            const unsigned from_left = (unsigned)__builtin_amdgcn_update_dpp(0, mine, 0x138, 0xF, 0xF, false);   // wave_shr:1  lane l <- l - 1
+            const unsigned from_right = (unsigned)__builtin_amdgcn_update_dpp(0, mine, 0x130, 0xF, 0xF, false);  // wave_shl:1  lane l <- l + 1
+            unsigned l3 = from_left & 7u, r3 = (from_right >> 3) & 7u;
+            if (lane == 0) l3 = (live && w > 0) ? (unsigned)(act_word(row, w - 1, t) >> 61) : 0u;
+            if (lane == 63) r3 = (live && w + 1 < g.WW) ? (unsigned)(act_word(row, w + 1, t) & 7ull) : 0u;
+            return (u128)l3 | ((u128)c << 3) | ((u128)r3 << 67);
+        };
+        morph_close_band<MORPH_DENSE_ROWS>(load_row, i, wc, (int)band * MORPH_DENSE_ROWS, live, act_ring, nzlist, nzcount, g);
+    }
 }
 // Every frame's segment of the work list gets the same share of the grid's waves (nwaves / K of them, at least one), which walk
 // it 64 entries at a time: one look at the frame's count per wave.  (Walking all wave-slots of all segments instead -- a count
@@ -815,7 +936,7 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
 __device__ __forceinline__ void morph_close_items(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                   const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
                                                   unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, const PassGeom& g,
-                                                  unsigned first_wave, unsigned nwaves) {
+                                                  unsigned first_wave, unsigned nwaves, unsigned* __restrict__ dense) {
     const unsigned per_frame = (unsigned)(((g.H + MORPH_RB - 1) / MORPH_RB) * g.WW);
     const unsigned K = (unsigned)g.K;
     const unsigned wpf = nwaves >= K ? nwaves / K : 1u;  // waves per frame
@@ -826,6 +947,10 @@ __device__ __forceinline__ void morph_close_items(const ActWord* __restrict__ bb
     if (grp >= groups) return;
     for (unsigned i = grp; i < K; i += groups) {
         const unsigned cnt = workcount[i];
+        if (dense != nullptr && 2u * cnt >= per_frame) {  // k_morph_close_dense's frame: the frame's first wave puts it on that list
+            if (sub == 0 && lane == 0) dense[1 + atomicAdd(&dense[0], 1u)] = i;
+            continue;
+        }
         const unsigned* seg = worklist + (size_t)i * per_frame;
         for (unsigned e = sub * 64 + lane; e < cnt; e += wpf * 64) morph_close_item(bbits, seg[e], act_ring, nzlist, nzcount, g);
     }
@@ -841,9 +966,11 @@ __global__ void __launch_bounds__(64) k_morph_close_frame(const ActWord* __restr
 }
 __global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                     const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
-                                                    unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
+                                                    unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g,
+                                                    unsigned* __restrict__ dense) {
     RAISE_WAVE_PRIORITY();
-    morph_close_items(bbits, worklist, workcount, act_ring, nzlist, nzcount, g, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
+    morph_close_items(bbits, worklist, workcount, act_ring, nzlist, nzcount, g, (blockIdx.x * blockDim.x + threadIdx.x) >> 6,
+                      (gridDim.x * blockDim.x) >> 6, dense);
 }
 
 // a8 + a9 count.  Dynamic mask (Detector.py:234-242): a pixel is "alive" unless it was lit in ALL of the last

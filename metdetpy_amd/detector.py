@@ -44,6 +44,10 @@ class BaseDetector(metaclass=ABCMeta):
         return []
 
 
+_EMPTY = np.array([])
+_EMPTY.flags.writeable = False
+
+
 class _StackView:
     """What callers read from `detector.stack` (SNR_SW): snr, std_roi, timer, n."""
 
@@ -172,11 +176,21 @@ class M3Detector(LineDetector):
     def detect(self):
         if not self._pending:
             raise RuntimeError("detect() called without a preceding update()")
-        info, raw, nms, prob = self._ctx.detect()
+        fields, raw, nms, prob = self._ctx.detect_fields()
         self._pending = False
-        self._absorb_info(info)
-        self.linesp_ext, lines, cls_pred = self._package(info, raw, nms, prob)
-        return lines, cls_pred
+        # (FRAME_INFO_DTYPE's field order; _absorb_info on a record does the same for the batched path)
+        n_raw, n_nms, _, self.bi_threshold, self.bi_threshold_float, snr, self.stack.noise_cur_value, self.dst_sum, _ = fields
+        self.stack.snr = snr if snr != 0 else 0
+        self.stack.timer += 1
+        self.lines_num, self.filtered_line_num = n_raw, n_nms
+        if n_raw > NUM_LINES_TOOMUCH or n_raw == 0:  # nothing found, or the frame is discarded (Detector.py:358-360)
+            self.linesp_ext = _EMPTY
+            return _EMPTY, np.zeros((0, self.num_cls))
+        cls_pred = np.zeros((n_nms, self.num_cls))
+        cls_pred[:, -1] = prob
+        cls_pred[:, 0] = 1 - prob
+        self.linesp_ext = raw
+        return nms, cls_pred
 
     def detect_batch(self, frames, K: Optional[int] = None, on_device: bool = False):
         """K x (update + detect) in one native call.  frames: (K,H,W) uint8 array, or a device pointer with K.

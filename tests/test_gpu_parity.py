@@ -215,6 +215,20 @@ def test_m3_masked_and_ragged_width():
     run_pair([s.next() for _ in range(30)], n, mask, binary_cfg(area=0.25))
 
 
+@pytest.mark.parametrize("shape", [(70, 200), (40, 64 * 65 + 17), (33, 64 * 64), (50, 64 * 128 + 1)])
+def test_m3_dense_binaries_direct_mapped_morphology(shape):
+    """A lowered fixed threshold lets the noise through: every block of a frame is listed, and the batched path hands such frames
+    to k_morph_close_dense (64 adjacent word columns per wave, neighbours' bits through DPP wave shifts, 16-row bands).  Widths
+    below, at and across the 64-column wave boundary, ragged last words; passes that mix dense frames with empty ones."""
+    n = 4
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=3, hough=(10, 10, 2))
+    noise = frames_normal(sum(shape), 14, shape, 30, 2.5)
+    flat = [np.full(shape, 30, np.uint8)]
+    frames = noise[:6] + flat * 7 + noise[6:10] + flat * 5 + noise[10:]
+    run_pair(frames, n, mask, cfg, batch=13, max_batch=13)
+
+
 def test_m3_edge_inputs():
     shape, n = (48, 80), 4
     mask = np.ones(shape, np.uint8)
