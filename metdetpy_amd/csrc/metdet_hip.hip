@@ -787,12 +787,13 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
+    static const int wpb = getenv("MDH_WIN_BLOCK") ? std::max(1, std::min(4, atoi(getenv("MDH_WIN_BLOCK")) / 64)) : 4;  // waves per workgroup
     if (lean.copy_dst)  // per-frame protocol: its own instantiation, the batched one pays nothing for it
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
                            c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
-                           c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
+                           c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
 }
 
 // copy_dst: see k_stack_threshold_wide (per-frame protocol; the caller has made sure a wide-load variant applies)

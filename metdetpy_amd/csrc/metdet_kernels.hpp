@@ -381,8 +381,8 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_MAX3
 #define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
 #endif
-#ifndef WIDE_ONEBUF
-#define WIDE_ONEBUF 0  // one load buffer instead of two (A/B builds; fewer registers, but half the bytes in flight per wave)
+#ifndef WIDE_RAREBITS
+#define WIDE_RAREBITS 1  // gather the result bits only for waves that have one set (A/B builds: -DWIDE_RAREBITS=0)
 #endif
 // Three-input packed maximum.  gfx950 has no packed integer max3, but it has v_pk_maximum3_f16, and for the values this kernel
 // holds (0..255 in each 16-bit half) the bit patterns are non-negative f16 denormals, whose IEEE order is their integer order;
@@ -439,15 +439,16 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     typedef unsigned dvec __attribute__((ext_vector_type(DW)));
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
-    const int gw0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPL;  // a wave covers PPL words
+    const int wpb = (int)(blockDim.x >> 6);  // waves per workgroup (4 by default; MDH_WIN_BLOCK: placement-granularity experiments)
+    const int gw0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * PPL;  // a wave covers PPL words
     if (gw0 >= words) {
-        if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
+        if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * (blockDim.x >> 6));
         return;
     }
     const int i0 = blockIdx.y * Tc;
     const int steps = min(Tc, g.K - i0);
     if (steps <= 0) {
-        if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
+        if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * (blockDim.x >> 6));
         return;
     }
     const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
@@ -487,9 +488,11 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     u16x2 gmax[NG][RW], oth[RW], pre[RW], suf[GS > 1 ? GS - 1 : 1][RW];
     // WIDE_MAX3: with a three-input maximum the suffix maxima need not be kept: two instructions per frame instead of three and
     // one kept temporary (T = max of the group's last two old slots and the other groups) instead of three suffix registers per
-    // pair (56 -> 32 registers of max state at n = 8).
-    constexpr bool MAX3 = WIDE_MAX3 != 0 && GS == 4;
-    constexpr bool ONEBUF = WIDE_ONEBUF != 0 && PPL == 16 && (N % U == 0);
+    // pair (56 -> 32 registers of max state at n = 8; 161 -> 148 VGPRs at n = 8, 252 -> 236 at n = 16).  Measured: 4K / n = 16
+    // 430 k -> 457 k frames/s, 1080p / n = 8 unchanged (that launch is not bound by VALU issue).  The per-frame instantiation
+    // (LEAN) keeps the two-input form: its single-frame launch got 5 us slower with this one (50 -> 55 us, 8.75 k -> 8.2 k frames/s).
+    constexpr bool MAX3 = WIDE_MAX3 != 0 && GS == 4 && !LEAN;
+    constexpr bool RAREBITS = WIDE_RAREBITS != 0 && !LEAN;
     u16x2 t23[RW];
     // Window sums: two 16-bit fields per register, updated with plain 32-bit adds / subtracts (a field never carries or
     // borrows: 255 * (N + 1) < 2^16, and the value leaving the window is part of the sum).  v_add_u32 / v_sub_u32 issue at
@@ -533,9 +536,13 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     // Bursts of U frames; the loads of burst b+1 are issued before burst b is consumed (double buffering), so a
     // wave always has loads in flight while it computes.
     constexpr int NB = (N + U - 1) / U;  // bursts per window period
-    dvec cur[U], nxt[U];
+    // (an even number of bursts per period: the two buffers swap roles by the burst's parity, which is static after unrolling,
+    // instead of being copied.  A single buffer refilled as soon as a frame is unpacked -- 16 registers less -- was measured and
+    // lost 4 % stand-alone and 9 % in the pipeline at 1080p, 40 % at 4K: half the bytes in flight per wave.)
+    constexpr bool PINGPONG = WIDE_MAX3 != 0 && !LEAN && (NB % 2 == 0);
+    dvec buf2[2][U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = fetch(min(i0 + u + N - 1, e_max));
+    for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
     for (int sb = 0; sb < steps; sb += N) {
         // thresholds of the whole window period up front (scalar loads, off the per-frame critical path)
         int Tp[N];
@@ -545,14 +552,14 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
             const int ub = bi * U;
+            dvec(&cur)[U] = buf2[PINGPONG ? (bi & 1) : 0];
+            dvec(&nxt)[U] = buf2[PINGPONG ? ((bi + 1) & 1) : 1];
             // prefetch the following burst (wraps into the next period)
             const int nb_first = (bi + 1 < NB) ? sb + (bi + 1) * U : sb + N;
-            if constexpr (!ONEBUF) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool in_period = (bi + 1 < NB) ? ((bi + 1) * U + u < N) : (u < N);
                 if (in_period) nxt[u] = fetch(min(i0 + nb_first + u + N - 1, e_max));
-            }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -566,9 +573,6 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         if constexpr (LEAN) {
                             if (copy_dst != nullptr && i == 0 && gw < words) *(dvec*)(copy_dst + off) = cur[u];
                         }
-                        // ONEBUF: the buffer of this frame is free once it is unpacked; the frame U steps ahead is fetched into
-                        // it right away (U - 1 frames of arithmetic, times the waves of the SIMD, cover the latency)
-                        if constexpr (ONEBUF) cur[u] = fetch(min(i0 + s + U + N - 1, e_max));
                         // b = (max - floor(sum / len) > T)  <=>  sum + T * len - max * len < 0.  The left side is within
                         // [-255 len, 510 len], i.e. inside int16 for len <= 16 (this kernel's N), so b is the sign bit of
                         // one packed multiply-add whose addend is sum + T * len (T >= 256 can never fire; clamping it
@@ -578,6 +582,7 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[ub + u] * len) * 0x10001u;  // scalar unit
                         const u16x2 NLv = {nlen, nlen};
                         unsigned acc = 0;
+                        unsigned dk[RW];
                         // group / position of the slot the new frame goes to (all static after unrolling)
                         const int grp = slot / GS, kpos = slot % GS;
                         const int gsz = grp == GL ? GSL : GS;
@@ -660,7 +665,20 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                             PK d, st;
                             st.u = sum[r] + tl;
                             d.v = m * NLv + st.v;
-                            acc = (acc >> 1) | (d.u & 0x80008000u);
+                            if constexpr (RAREBITS) {
+                                dk[r] = d.u;
+                                acc |= d.u;
+                            } else {
+                                acc = (acc >> 1) | (d.u & 0x80008000u);
+                            }
+                        }
+                        if constexpr (RAREBITS) {
+                            // a wave of 1024 pixels rarely holds a pixel over the threshold (noise at 4-5 sigma, a streak every few
+                            // dozen waves): the sign bits are only gathered when the OR of the wave's results has one set
+                            if (__ballot((acc & 0x80008000u) != 0) == 0) continue;
+                            acc = 0;
+#pragma unroll
+                            for (int r = 0; r < RW; ++r) acc = (acc >> 1) | (dk[r] & 0x80008000u);
                         }
                         // reg r landed on bit 8+r-(8-RW) ... after RW shifts: low half bits (16-RW)..15 = pixels 0..RW-1,
                         // high half bits (32-RW)..31 = pixels RW..PPL-1
@@ -685,13 +703,13 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                     }
                 }
             }
-            if constexpr (!ONEBUF) {
+            if constexpr (!PINGPONG) {
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
             }
         }
     }
-    if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * 4);
+    if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * (blockDim.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------

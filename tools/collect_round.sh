@@ -10,7 +10,9 @@ python bench.py --workload C3 $S > $O/${TAG}_bench_C3_4k_n16_mask.json 2> $O/err
 python bench.py --workload C3 --batch 512 $S > $O/${TAG}_bench_C3_batch512.json 2>> $O/err_C3
 python bench.py --workload C1s $S > $O/${TAG}_bench_C1s_960x540.json 2> $O/err_C1s
 python bench.py --workload C5 --unique 50 $S > $O/${TAG}_bench_C5_8k_single_gpu.json 2> $O/err_C5
+python bench.py --batch 2048 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch2048.json 2> $O/err_b2048
 python bench.py --batch 1024 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch1024.json 2> $O/err_b1024
+python bench.py --workload C3 --batch 2048 --cpu-seconds 0 > $O/${TAG}_bench_C3_batch2048.json 2>> $O/err_C3
 python bench.py --batch 128 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch128.json 2> $O/err_b128
 python bench.py --host-input --cpu-seconds 0 --steps 200 > $O/${TAG}_bench_C2_host_input.json 2> $O/err_host
 python bench.py --protocol per-frame --cpu-seconds 0 > $O/${TAG}_bench_per_frame_protocol.json 2> $O/err_pf
