@@ -143,7 +143,8 @@ def run_timeshard(a, D, wl, mask, cfg):
         return pool[np.arange(lo, hi) % P]
 
     ranks = [D.rank] if D.world > 1 else list(range(windows))
-    shards = [TimeShard(1, n, mask, 10, cfg, total, read, rank=r, world=windows, device=D.local, max_batch=B, scan_batch=B)
+    shards = [TimeShard(1, n, mask, 10, cfg, total, read, rank=r, world=windows, device=D.local, max_batch=B,
+                        scan_batch=min(B, 256) if a.host_input else B)  # (host frames: every context also holds a ring of its pass)
               for r in ranks]
     import ctypes
     hctx = shards[0].engine.band

@@ -34,6 +34,8 @@ def main():
         tu = td = 0.0
         segs = 0
         N = int(os.environ.get("PF_N", "3000"))
+        busy_t = quiet_t = 0.0  # frames whose Hough stage had something to replay (raw segments came out) / the others
+        busy_n = 0
         t0 = time.perf_counter()
         for k in range(N):
             f = pinned[k % len(pinned)]
@@ -41,11 +43,19 @@ def main():
             det.update(f)
             b = time.perf_counter()
             lines, _ = det.detect()
-            td += time.perf_counter() - b
+            e = time.perf_counter()
+            td += e - b
             tu += b - a
             segs += len(lines)
+            if det.lines_num:
+                busy_t += e - a
+                busy_n += 1
+            else:
+                quiet_t += e - a
         dt = time.perf_counter() - t0
-        out[label] = {"frames_per_s": N / dt, "us_per_frame": dt / N * 1e6, "update_us": tu / N * 1e6, "detect_us": td / N * 1e6, "segments": segs}
+        out[label] = {"frames_per_s": N / dt, "us_per_frame": dt / N * 1e6, "update_us": tu / N * 1e6, "detect_us": td / N * 1e6, "segments": segs,
+                      "frames_with_segments": busy_n, "us_per_frame_with_segments": busy_t / max(busy_n, 1) * 1e6,
+                      "us_per_frame_without_segments": quiet_t / max(N - busy_n, 1) * 1e6}
         if prof:
             out[label]["gpu_span_us"] = {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in ctx.profile_read(True).items() if v[1]}
             ctx.profile_enable(False)
