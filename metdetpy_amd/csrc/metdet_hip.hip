@@ -980,7 +980,10 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
                            sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr);
         if (dense)
-            hipLaunchKernelGGL(k_morph_close_dense, dim3(2048), dim3(64), 0, post, sl.d_bbits, sl.d_dense, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+        {
+            static const int dense_grid = getenv("MDH_DENSE_GRID") ? std::max(64, atoi(getenv("MDH_DENSE_GRID"))) : 8192;  // (2048 waves: 1.9 ms per 128 dense 8K frames, 8192: 1.5 -- a wave is a chain of 22 dependent row loads)
+            hipLaunchKernelGGL(k_morph_close_dense, dim3(dense_grid), dim3(64), 0, post, sl.d_bbits, sl.d_dense, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+        }
         }
         span_end(c, post);
         EV_REC(c, sl.ev_close, post);

@@ -554,6 +554,9 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
             const int ub = bi * U;
             dvec(&cur)[U] = buf2[PINGPONG ? (bi & 1) : 0];
             dvec(&nxt)[U] = buf2[PINGPONG ? ((bi + 1) & 1) : 1];
+            // (measured in round 2c: a workgroup barrier here, to keep the four waves on the same frames so that their loads of a
+            // burst -- consecutive kilobytes of one frame -- reach the memory system together, changes nothing; eight-wave
+            // workgroups with it lose 10 %)
             // prefetch the following burst (wraps into the next period)
             const int nb_first = (bi + 1 < NB) ? sb + (bi + 1) * U : sb + N;
 #pragma unroll

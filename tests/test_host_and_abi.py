@@ -34,6 +34,17 @@ def test_struct_layouts_match_header():
     assert "#define MDH_MAX_LINES 512" in hdr and _lib.MDH_MAX_LINES == 512
 
 
+def test_frame_info_field_order_of_the_per_frame_path():
+    """M3Detector.detect() unpacks Context.detect_fields()'s tuple positionally (one tolist() per frame instead of a record copy
+    and a lookup per attribute): the order it assumes is FRAME_INFO_DTYPE's, which is mdh_frame_info's (include/metdet_hip.h)."""
+    assert _lib.FRAME_INFO_DTYPE.names == ("n_raw", "n_nms", "lit_count", "bi_threshold", "bi_threshold_float", "snr", "sigma",
+                                           "dst_sum", "hough_gap")
+    assert [f[0] for f in _lib.MdhFrameInfo._fields_] == list(_lib.FRAME_INFO_DTYPE.names)
+    rec = np.zeros(1, _lib.FRAME_INFO_DTYPE)
+    rec[0] = (3, 2, 40, 11, 10.7, 2.5, 1.25, 0.01, 8.0)
+    assert rec.tolist()[0] == (3, 2, 40, 11, 10.7, 2.5, 1.25, 0.01, 8.0)
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback: without a visible GPU the constructor raises instead of silently computing elsewhere."""
     import ctypes as C
