@@ -44,7 +44,7 @@ WORKLOADS = {
     "C2": dict(H=1080, W=1920, n=8, seed=20220413, batch=4096, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
     "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=1024, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
     "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2048, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
-    "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=128, sensitivity="high",
+    "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=512, sensitivity="high",
                desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
     "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=256, src=(2160, 3840),
                 desc="config-1 substitute: synthetic 3840x2160x3 BGR clip in HBM -> resize 960x540 + gray + mask-east (loader "
@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--hough-mode", default="exact", choices=["exact", "accumulator"], help="accumulator: the order-free "
                     "full-accumulator transform (MDH_HOUGH_ACCUMULATOR) instead of the exact replay of cv2.HoughLinesP; parity is then "
                     "the tolerance rule of SURVEY 8d (collector records matched against the exact mode's), not bit-exactness")
+    ap.add_argument("--sensitivity", default=None, choices=["low", "normal", "high"], help="override the workload's detector cfg "
+                    "(experiments: C5's frame size at m3det_normal thresholds)")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight in the timed region (0 = as many as the library "
                     "allows; 1 = one at a time: nothing overlaps, the kernel spans are the kernels' own durations)")
     ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive "
@@ -551,7 +553,7 @@ def main():
     wl = WORKLOADS[a.workload]
     H, W, n = wl["H"], wl["W"], wl["n"]
     global SENSITIVITY, DETECTOR, HOUGH_MODE
-    SENSITIVITY = wl.get("sensitivity", "normal")
+    SENSITIVITY = a.sensitivity or wl.get("sensitivity", "normal")
     DETECTOR = a.detector
     HOUGH_MODE = a.hough_mode
     if DETECTOR == "classic":

@@ -1,12 +1,11 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02ak; mkdir -p $O
-B="--cpu-seconds 0 --parity-frames 0 --standalone-passes 8"
-run() { python bench.py $2 $B --steps $3 > $O/$1.json 2>> $O/err; }
-for rep in 1 2; do
-  run C5_g2048_$rep "--workload C5 --unique 50" 150
-  MDH_DENSE_GRID=8192 run C5_g8192_$rep "--workload C5 --unique 50" 150
-  MDH_DENSE_GRID=16384 run C5_g16384_$rep "--workload C5 --unique 50" 150
-  MDH_DENSE_GRID=4096 run C5_g4096_$rep "--workload C5 --unique 50" 150
-done
-MDH_DENSE_GRID=8192 python bench.py --mode bands --workload C5 --unique 50 --cpu-seconds 0 > $O/bands_g8192.json 2>> $O/err
-tail -3 $O/err
+TAG=r02d
+O=gpurun_out/collect_$TAG; mkdir -p $O
+python bench.py --workload C5 --unique 50 --cpu-seconds 6 > $O/${TAG}_bench_C5_8k_single_gpu.json 2> $O/err_C5
+python bench.py --workload C5 --unique 50 --batch 128 --cpu-seconds 0 > $O/${TAG}_bench_C5_batch128.json 2>> $O/err_C5
+python bench.py --mode bands --workload C5 --unique 50 --batch 256 --cpu-seconds 0 > $O/${TAG}_bench_mode_bands_C5_8bands_one_gpu.json 2> $O/err_bands
+python bench.py --workload C5 --unique 50 --batch 128 --hough-mode accumulator --cpu-seconds 0 > $O/${TAG}_bench_C5_hough_accumulator.json 2>> $O/err_acc
+python bench.py --protocol per-frame --cpu-seconds 0 > $O/${TAG}_bench_per_frame_protocol.json 2> $O/err_pf
+python tools/bench_per_frame.py > $O/${TAG}_per_frame_protocol.json 2>> $O/err_pf
+WL=C5 python tools/hough_frame_times.py > $O/${TAG}_hough_frame_times_C5.txt 2>&1
+tail -2 $O/err_*
