@@ -460,11 +460,11 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_dst, K * words));
         // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
         // (+ K: the per-frame counts of the morphology work list, d_workcnt, cleared with the rest)
-        TRY(dev_alloc(s.d_rowcount, K * c->H + 7 * K + 1));
+        TRY(dev_alloc(s.d_rowcount, K * c->H + (6 + WORKCNT_STRIDE) * K + 1));
         s.d_litcount = s.d_rowcount + K * c->H;
         s.d_bbox = s.d_litcount + K;
         s.d_workcnt = (unsigned*)(s.d_bbox + 4 * K);
-        s.d_dense = s.d_workcnt + K;
+        s.d_dense = s.d_workcnt + (size_t)WORKCNT_STRIDE * K;
         TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
         {
             auto a16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -793,7 +793,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
                            c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
+                           c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean);
 }
 
 // copy_dst: see k_stack_threshold_wide (per-frame protocol; the caller has made sure a wide-load variant applies)
@@ -853,7 +853,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     const bool m3 = c->cfg.detector == MDH_DET_M3;
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
-                       (unsigned)((size_t)c->Kmax * c->H + 7 * (size_t)c->Kmax + 1), sl.d_bandflag, (unsigned)((size_t)K * nb * c->WW),
+                       (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag, (unsigned)((size_t)K * nb * c->WW),
                        (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
@@ -972,6 +972,10 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
             hipLaunchKernelGGL(k_morph_close_frame, dim3((unsigned)((nb * c->WW + 63) / 64)), dim3(64), 0, post, sl.d_bbits, sl.d_bandflag, c->d_act,
                                sl.d_nzlist, sl.d_nzcount, g);
         } else {
+        static const bool all_dense = getenv("MDH_ALL_DENSE") != nullptr;  // experiment: no block counters, every frame direct-mapped
+        if (all_dense) {
+            hipLaunchKernelGGL(k_morph_close_dense, dim3(8192), dim3(64), 0, post, sl.d_bbits, (const unsigned*)nullptr, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+        } else {
         hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_bandflag,
                            sl.d_worklist, sl.d_workcnt, g);
         // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
@@ -983,6 +987,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         {
             static const int dense_grid = getenv("MDH_DENSE_GRID") ? std::max(64, atoi(getenv("MDH_DENSE_GRID"))) : 8192;  // (2048 waves: 1.9 ms per 128 dense 8K frames, 8192: 1.5 -- a wave is a chain of 22 dependent row loads)
             hipLaunchKernelGGL(k_morph_close_dense, dim3(dense_grid), dim3(64), 0, post, sl.d_bbits, sl.d_dense, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+        }
         }
         }
         span_end(c, post);

@@ -17,6 +17,8 @@ typedef unsigned __int128 u128;
 
 #define NUM_ANGLE 180
 #define MAX_LINES 512
+#define WORKCNT_STRIDE 32  // the per-frame counts of the morphology work list sit one 128-byte line apart: packed, the appends of 32
+                           // frames met in ONE L2 channel (k_morph_select 2.1 ms per pass of 512 dense 8K frames, rocprofv3 round 2c)
 #define MORPH_RB 8  // rows per band of the morphology kernel (and granularity of the "band has set bits" flags)
 
 // ------------------------------------------------------------------------------------------------
@@ -701,7 +703,7 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         }
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             bbits[(size_t)i * words + gw] = ActWord{v, (u64)(g.t_base + 1 + i)};
-                            atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
+                            if (blockcnt != nullptr) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
                         }
                     }
                 }
@@ -828,7 +830,7 @@ __global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict
     if (!m) return;
     const int lane = threadIdx.x & 63;
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&workcount[i], (unsigned)__popcll(m));
+    if (lane == 0) base = atomicAdd(&workcount[(size_t)i * WORKCNT_STRIDE], (unsigned)__popcll(m));
     base = __shfl(base, 0);
     if (keep) worklist[(size_t)i * (nb * g.WW) + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
 }
@@ -921,7 +923,7 @@ __global__ void __launch_bounds__(64) k_morph_close_dense(const ActWord* __restr
                                                           unsigned* __restrict__ nzcount, PassGeom g) {
     // dense[0] = number of dense frames of the pass, dense[1..] = their indices (written by k_morph_close, which looks at every
     // frame's count anyway): a pass without such frames costs this launch one load per wave
-    const unsigned nd = dense[0];
+    const unsigned nd = dense != nullptr ? dense[0] : (unsigned)g.K;  // (null: every frame of the pass -- MDH_ALL_DENSE experiment)
     if (nd == 0) return;
     RAISE_WAVE_PRIORITY();
     const int lane = threadIdx.x;
@@ -930,7 +932,7 @@ __global__ void __launch_bounds__(64) k_morph_close_dense(const ActWord* __restr
     for (unsigned item = blockIdx.x; item < nd * per_frame; item += gridDim.x) {
         const unsigned f = item / per_frame, rest = item - f * per_frame;
         const unsigned band = rest / cgroups, cg = rest - band * cgroups;
-        const int i = (int)dense[1 + f];
+        const int i = dense != nullptr ? (int)dense[1 + f] : (int)f;
         const int w = (int)cg * 64 + lane;
         const bool live = w < g.WW;
         const int wc = live ? w : g.WW - 1;
@@ -967,7 +969,7 @@ __device__ __forceinline__ void morph_close_items(const ActWord* __restrict__ bb
     const unsigned lane = threadIdx.x & 63;
     if (grp >= groups) return;
     for (unsigned i = grp; i < K; i += groups) {
-        const unsigned cnt = workcount[i];
+        const unsigned cnt = workcount[(size_t)i * WORKCNT_STRIDE];
         if (dense != nullptr && 2u * cnt >= per_frame) {  // k_morph_close_dense's frame: the frame's first wave puts it on that list
             if (sub == 0 && lane == 0) dense[1 + atomicAdd(&dense[0], 1u)] = i;
             continue;
