@@ -46,7 +46,7 @@ WORKLOADS = {
     "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2048, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
     "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=512, sensitivity="high",
                desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
-    "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=256, src=(2160, 3840),
+    "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=512, src=(2160, 3840),
                 desc="config-1 substitute: synthetic 3840x2160x3 BGR clip in HBM -> resize 960x540 + gray + mask-east (loader "
                      "restatement on the GPU) -> detector -> native collector"),
 }
