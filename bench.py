@@ -41,12 +41,12 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s is what a streaming copy reaches)
 
 WORKLOADS = {
-    "C2": dict(H=1080, W=1920, n=8, seed=20220413, batch=4096, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
-    "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=1024, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
-    "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2048, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
-    "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=512, sensitivity="high",
+    "C2": dict(H=1080, W=1920, n=8, seed=20220413, batch=4000, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
+    "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=1000, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
+    "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2000, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
+    "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=500, sensitivity="high",
                desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
-    "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=512, src=(2160, 3840),
+    "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=500, src=(2160, 3840),
                 desc="config-1 substitute: synthetic 3840x2160x3 BGR clip in HBM -> resize 960x540 + gray + mask-east (loader "
                      "restatement on the GPU) -> detector -> native collector"),
 }
@@ -61,7 +61,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per step (and frames resident in HBM per GPU)")
     ap.add_argument("--unique", type=int, default=250, help="period of the synthetic stream in frames, a multiple of the streak "
                     "period: the resident batch is frames[i %% unique], so no streak is cut where the stream wraps (0 = every "
-                    "resident frame distinct; generation is NumPy on the host and dominates the start-up time)")
+                    "resident frame distinct; generation is NumPy on the host and dominates the start-up time).  The default "
+                    "passes (4000 / 2000 / 1000 / 500 frames) are whole multiples of it, so a resubmitted pass CONTINUES the "
+                    "stream (frame 249 -> frame 0 is seamless) instead of starting on a scene cut")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="streams", choices=["streams", "bands", "timeshard"])
     ap.add_argument("--protocol", default="batch", choices=["batch", "per-frame"])

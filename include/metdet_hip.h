@@ -47,7 +47,19 @@ extern "C" {
 #define MDH_SENS_HIGH 2
 
 /* cfg.detector.cfg of the reference (metstruct.py:357-382) plus what LineDetector.__init__ derives on the host. */
+/* ABI guard.  Both configuration structs start with `struct_size` = sizeof(the struct) as the CALLER's header declares it;
+ * mdh_create / mdh_collector_create refuse (NULL, text in mdh_last_error) a struct whose size differs from the library's, so a
+ * host compiled against an older header -- or a stale hand-written binding -- fails loudly instead of having fields read from
+ * beyond its struct.  mdh_abi_version() is bumped whenever a struct or a prototype changes (2: struct_size fields, round 3). */
+#define MDH_ABI_VERSION 2
+int mdh_abi_version(void);
+/* The library runs a pass on up to ten HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
+ * read once when the runtime initialises.  The library never modifies the process environment: export GPU_MAX_HW_QUEUES=12
+ * before the first HIP call for full overlap.  Returns the value the environment holds (0 = unset).  Results never depend on it. */
+int mdh_hw_queues_hint(void);
+
 typedef struct mdh_cfg {
+    uint32_t struct_size;        /* sizeof(mdh_cfg): checked first by mdh_create */
     int32_t detector;            /* MDH_DET_* */
     int32_t adaptive_bi_thre;    /* cfg.binary.adaptive_bi_thre */
     int32_t init_value;          /* cfg.binary.init_value (used when not adaptive, Detector.py:208) */
@@ -246,6 +258,8 @@ int mdh_mute_hough_until(mdh_ctx* ctx, int64_t t);
  * Host code, no GPU needed.  Consumes (frame, lines, cates) exactly as MeteorCollector.update does and queues the series it
  * finishes as mdh_target records (unrounded); metdetpy_amd/collector.py turns them into MDRF records. */
 typedef struct mdh_collector_cfg {
+    uint32_t struct_size;                /* sizeof(mdh_collector_cfg): checked first by mdh_collector_create */
+    uint32_t reserved;                   /* 0 */
     double min_len, max_interval;        /* MeteorCfg.min_len, .max_interval (seconds) */
     double time_range[2], speed_range[2], drct_range[2];
     double det_thre;

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MDH_LIB") or os.path.join(_HERE, "libmetdet_hip.so") 
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
+MDH_ABI_VERSION = 2
 MDH_HOUGH_EXACT, MDH_HOUGH_ACCUMULATOR = 0, 1
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 MDH_ROLE_FULL, MDH_ROLE_BAND, MDH_ROLE_HOUGH = 0, 1, 2
@@ -23,11 +24,15 @@ SENSITIVITY_ID = {"low": 0, "normal": 1, "high": 2}
 
 
 class MdhCfg(C.Structure):
-    _fields_ = [("detector", C.c_int32), ("adaptive_bi_thre", C.c_int32), ("init_value", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("detector", C.c_int32), ("adaptive_bi_thre", C.c_int32), ("init_value", C.c_int32),
                 ("sensitivity", C.c_int32), ("interval", C.c_int32), ("roi", C.c_int32 * 4),
                 ("hough_threshold", C.c_int32), ("hough_min_len", C.c_int32), ("hough_max_gap", C.c_int32),
                 ("dy_mask", C.c_int32), ("max_batch", C.c_int32), ("role", C.c_int32), ("mask_area", C.c_double),
                 ("hough_mode", C.c_int32), ("reserved", C.c_int32)]
+
+    def __init__(self, *a, **kw):  # the ABI guard (include/metdet_hip.h): the library refuses any other size
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(MdhCfg)
 
 
 class MdhFrameInfo(C.Structure):
@@ -37,10 +42,15 @@ class MdhFrameInfo(C.Structure):
 
 
 class MdhCollectorCfg(C.Structure):
-    _fields_ = [("min_len", C.c_double), ("max_interval", C.c_double), ("time_range", C.c_double * 2),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("min_len", C.c_double), ("max_interval", C.c_double),
+                ("time_range", C.c_double * 2),
                 ("speed_range", C.c_double * 2), ("drct_range", C.c_double * 2), ("det_thre", C.c_double), ("thre2", C.c_double),
                 ("fps", C.c_double), ("exp_frame", C.c_int32), ("runtime_w", C.c_int32), ("runtime_h", C.c_int32),
                 ("num_cls", C.c_int32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(MdhCollectorCfg)
 
 
 TARGET_DTYPE = np.dtype([("flag", "<i4"), ("group", "<i4"), ("start_frame", "<i8"), ("end_frame", "<i8"),
@@ -64,7 +74,7 @@ EXPORTS = [
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
     "mdh_inject_sums", "mdh_mute_hough_until", "mdh_hough_planes_submit",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
-    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy"
+    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint"
 ]
 
 _lib = None
@@ -82,6 +92,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MetDetHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "or `make -C metdetpy_amd/csrc` (there is no CPU fallback)")
+    # host side of the boundary: the library's streams want their own hardware queues (HIP's default is 4; read once when the
+    # runtime initialises, i.e. at the process's first HIP call).  The library itself never touches the environment.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
     L.mdh_create.argtypes = [i32, i32, i32, i32, C.POINTER(MdhCfg)]
@@ -136,6 +149,9 @@ def load():
     L.mdh_seek.argtypes = [vp, i64, i64, dbl, dbl, dbl, i32]
     L.mdh_inject_sums.argtypes = [vp, i64, i64, i64]
     L.mdh_mute_hough_until.argtypes = [vp, i64]
+    if not hasattr(L, "mdh_abi_version") or L.mdh_abi_version() != MDH_ABI_VERSION:
+        raise MetDetHipError(f"{LIB_PATH} implements another ABI version than this binding ({MDH_ABI_VERSION}): rebuild it "
+                             "(`make -C metdetpy_amd/csrc -B`)")
     _lib = L
     return L
 

@@ -228,6 +228,12 @@ struct mdh_ctx {
 };
 
 extern "C" const char* mdh_last_error(void) { return g_err.c_str(); }
+extern "C" int mdh_abi_version(void) { return MDH_ABI_VERSION; }
+// GPU_MAX_HW_QUEUES as the process environment has it (0: unset, the runtime's default of 4 applies); the library wants >= 12
+extern "C" int mdh_hw_queues_hint(void) {
+    const char* v = getenv("GPU_MAX_HW_QUEUES");
+    return v ? atoi(v) : 0;
+}
 extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KERNELS) ? kKernelNames[k] : ""; }
 extern "C" int64_t mdh_frames_seen(const mdh_ctx* c) { return c ? c->t : -1; }
 extern "C" int mdh_in_flight(const mdh_ctx* c) { return c ? c->in_flight : -1; }
@@ -325,15 +331,27 @@ static int perm_table(int device, const unsigned short** out) {
             st = (uint64_t)(unsigned)st * 4164903690ull + (st >> 32);  // RNG::next(): multiply-with-carry
             rnd[k] = (unsigned)st;
         }
+        // built on a private stream and waited for with a stream synchronisation: other contexts' passes in flight on this
+        // device are not stalled (a device-wide synchronisation would), and the temporaries are released on every path
         unsigned* d_rnd = nullptr;
         unsigned short* d_perm = nullptr;
-        HIPCHK(hipMalloc((void**)&d_rnd, sizeof(unsigned) * n_max));
-        HIPCHK(hipMalloc((void**)&d_perm, sizeof(unsigned short) * ((size_t)n_max * (n_max + 1) / 2)));
-        HIPCHK(hipMemcpy(d_rnd, rnd.data(), sizeof(unsigned) * n_max, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_perm_build, dim3(n_max), dim3(64), 0, 0, d_rnd, d_perm, n_max);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipFree(d_rnd));
+        hipStream_t st_build = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st_build, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_rnd, sizeof(unsigned) * n_max);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_perm, sizeof(unsigned short) * ((size_t)n_max * (n_max + 1) / 2));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rnd, rnd.data(), sizeof(unsigned) * n_max, hipMemcpyHostToDevice, st_build);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_perm_build, dim3(n_max), dim3(64), 0, st_build, d_rnd, d_perm, n_max);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st_build);
+        if (d_rnd) hipFree(d_rnd);
+        if (st_build) hipStreamDestroy(st_build);
+        if (e != hipSuccess) {
+            if (d_perm) hipFree(d_perm);
+            set_err(std::string("perm_table: ") + hipGetErrorString(e));
+            return MDH_E_HIP;
+        }
         g_perm[device] = d_perm;
     }
     *out = g_perm[device];
@@ -410,6 +428,7 @@ static int create_impl(mdh_ctx* c) {
     TRY(dev_alloc(c->d_read_count, 4));
     TRY(host_alloc(c->h_read_flag, 16));
     c->h_read_flag[0] = 0;
+    if (pix) TRY(host_alloc(c->h_inject, (size_t)2 * 64 * NSLOT_MAX));  // staging of mdh_inject_sums entries (at most 64 pending)
     for (int hi = 0; hi < c->nhset && hough; ++hi) {
         HoughSet& h = c->hset[hi];
         h.pool = (int)std::min<size_t>(K, 256);  // one hybrid workgroup per CU (it takes the whole LDS)
@@ -522,7 +541,15 @@ static bool env_on(const char* name) {
 }
 
 extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh_cfg* cfg) {
-    if (!cfg || H <= 0 || W <= 0 || H > 32767 || W > 32767 || n_window < 1 || n_window > MDH_MAX_WINDOW) {
+    if (!cfg) { set_err("mdh_create: null cfg"); return nullptr; }
+    if (cfg->struct_size != sizeof(mdh_cfg)) {  // the only field read before this check is the first one
+        set_err("mdh_create: cfg.struct_size is " + std::to_string(cfg->struct_size) + ", this library's mdh_cfg has " +
+                std::to_string(sizeof(mdh_cfg)) + " bytes (ABI version " + std::to_string(MDH_ABI_VERSION) +
+                "): the caller was built against another include/metdet_hip.h");
+        return nullptr;
+    }
+    if (cfg->reserved != 0) { set_err("mdh_create: cfg.reserved must be 0"); return nullptr; }
+    if (H <= 0 || W <= 0 || H > 32767 || W > 32767 || n_window < 1 || n_window > MDH_MAX_WINDOW) {
         set_err("mdh_create: bad geometry or window (need 1 <= n <= 255, 0 < H,W <= 32767)");
         return nullptr;
     }
@@ -564,9 +591,9 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     // The context uses up to ten streams that should progress independently; the HIP runtime multiplexes streams onto
     // GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue serialise behind each other's event
     // waits.  Correctness never depends on it (every dependency is an explicit event), only overlap does.  The variable is
-    // read when the runtime initialises, so this only takes effect when the library makes the process's first HIP call;
-    // hosts that touch HIP earlier export GPU_MAX_HW_QUEUES=12 themselves (bench.py does).
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    // read when the runtime initialises and belongs to the HOST process: the library does not touch the environment; hosts
+    // that want the overlap export GPU_MAX_HW_QUEUES=12 before their first HIP call (bench.py does), and
+    // mdh_hw_queues_hint() tells them what the library saw.
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_err("mdh_create: no HIP device visible -- libmetdet_hip needs an AMD GPU (there is no CPU fallback)");
@@ -873,12 +900,12 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
         span_end(c, c->nstream);
         if (!c->injected.empty()) {
             // sums the caller knows better (mdh_inject_sums) replace what the kernel made of an incomplete window
+            int staged = 0;  // at most 64 entries exist, so at most 64 are staged per pass
             for (int j = 0; j < nj; ++j) {
                 const int64_t t = t_base + 1 + sl.h_jobs[j].frame;
                 for (size_t q = 0; q < c->injected.size(); ++q) {
                     if (c->injected[q].first != t) continue;
-                    if (!c->h_inject) HIPCHK(hipHostMalloc((void**)&c->h_inject, sizeof(long long) * 2 * 64 * NSLOT_MAX));
-                    long long* stage = c->h_inject + ((size_t)(&sl - c->slot) * 64 + (size_t)(j % 64)) * 2;
+                    long long* stage = c->h_inject + ((size_t)(&sl - c->slot) * 64 + (size_t)(staged++ % 64)) * 2;
                     stage[0] = c->injected[q].second.first;
                     stage[1] = c->injected[q].second.second;
                     HIPCHK(hipMemcpyAsync(c->d_sums + 2 * j, stage, sizeof(long long) * 2, hipMemcpyHostToDevice, c->nstream));
@@ -1591,6 +1618,13 @@ extern "C" int mdh_inject_sums(mdh_ctx* c, int64_t t, int64_t s1, int64_t s2) {
     if (!c) { set_err("mdh_inject_sums: null context"); return MDH_E_ARG; }
     if (c->role == MDH_ROLE_HOUGH) { set_err("mdh_inject_sums: a MDH_ROLE_HOUGH context has no noise chain"); return MDH_E_STATE; }
     if (t <= c->t) { set_err("mdh_inject_sums: the frame has already been submitted"); return MDH_E_ARG; }
+    {   // only a frame whose sigma is due (Detector.py:82,87) ever looks its entry up: anything else would sit in the table for good
+        const int64_t std_interval = (int64_t)c->cfg.interval * c->n;
+        const bool due = (t > c->n && t % std_interval == 0) || (t > 1 && t <= c->n);
+        if (!due) { set_err("mdh_inject_sums: no noise sigma is due for that frame (t > n and t % (interval * n) == 0, or 1 < t <= n)"); return MDH_E_ARG; }
+    }
+    for (auto& e : c->injected)
+        if (e.first == t) { e.second = {s1, s2}; return MDH_OK; }
     if (c->injected.size() >= 64) { set_err("mdh_inject_sums: too many pending entries"); return MDH_E_STATE; }
     c->injected.push_back({t, {s1, s2}});
     return MDH_OK;
@@ -1959,7 +1993,13 @@ extern "C" int mdh_frame_sums(int device, const uint8_t* frames, int K, uint64_t
 
 // ------------------------------------------------------------------------------------------------ native collector
 extern "C" mdh_collector* mdh_collector_create(const mdh_collector_cfg* cfg) {
-    if (!cfg || !(cfg->fps > 0) || cfg->num_cls < 2 || cfg->exp_frame < 1 || cfg->runtime_w < 1 || cfg->runtime_h < 1) {
+    if (!cfg) { set_err("mdh_collector_create: null cfg"); return nullptr; }
+    if (cfg->struct_size != sizeof(mdh_collector_cfg)) {
+        set_err("mdh_collector_create: cfg.struct_size is " + std::to_string(cfg->struct_size) + ", this library's mdh_collector_cfg has " +
+                std::to_string(sizeof(mdh_collector_cfg)) + " bytes: the caller was built against another include/metdet_hip.h");
+        return nullptr;
+    }
+    if (!(cfg->fps > 0) || cfg->num_cls < 2 || cfg->exp_frame < 1 || cfg->runtime_w < 1 || cfg->runtime_h < 1) {
         set_err("mdh_collector_create: bad configuration");
         return nullptr;
     }

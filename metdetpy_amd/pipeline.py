@@ -35,8 +35,12 @@ def detect_stream(frames: Iterable[np.ndarray], mask: np.ndarray, detector_cfg: 
         if not buf:
             return
         if native_collector and detector_cls is M3Detector:
-            info, _raw, nms, prob = det._ctx.process_batch(np.stack(buf))
+            info, raw, nms, prob = det._ctx.process_batch(np.stack(buf))
             col.update_batch(start_frame + it * rt.exp_frame, it, info, nms, prob)
+            # the detector's public attributes follow the stream as they do in the reference's loop (bi_threshold, stack.snr,
+            # lines_num, dst_sum, linesp_ext: what visu() and a caller looking at the detector mid-stream read)
+            det._absorb_info(info[-1])
+            det.linesp_ext = det._package(info[-1], raw[-1], nms[-1], prob[-1])[0]
             it += len(buf)
             infos.append(info)
             buf.clear()

@@ -29,9 +29,56 @@ def test_header_symbols_are_exported():
 def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(_lib.MdhFrameInfo) == 56 and _lib.FRAME_INFO_DTYPE.itemsize == 56
-    assert C.sizeof(_lib.MdhCfg) == 16 * 4 + 8 + 8
+    assert C.sizeof(_lib.MdhCfg) == 16 * 4 + 8 + 8 and _lib.MdhCfg.struct_size.offset == 0 and _lib.MdhCfg.mask_area.offset == 64
+    assert C.sizeof(_lib.MdhCollectorCfg) == 8 + 11 * 8 + 4 * 4 and _lib.MdhCollectorCfg.struct_size.offset == 0
+    assert re.search(r"#define MDH_ABI_VERSION\s+%d\b" % _lib.MDH_ABI_VERSION, open(os.path.join(ROOT, "include", "metdet_hip.h")).read())
+    assert _lib.load().mdh_abi_version() == _lib.MDH_ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "metdet_hip.h")).read()
     assert "#define MDH_MAX_LINES 512" in hdr and _lib.MDH_MAX_LINES == 512
+
+
+def test_wrong_struct_size_is_refused():
+    """ABI guard: a caller built against another header (round 1/2's mdh_cfg had no struct_size: its first field was `detector`,
+    0 or 1) is refused before any other field is read -- no GPU needed, the check comes first."""
+    import ctypes as C
+    L = _lib.load()
+    cfg = _lib.MdhCfg()
+    cfg.sensitivity, cfg.interval, cfg.mask_area, cfg.hough_threshold = 1, 2, 100.0, 10
+    cfg.roi[2], cfg.roi[3] = 8, 8
+    for bad in (0, 1, 72, 76, 84):
+        cfg.struct_size = bad
+        assert not L.mdh_create(0, 16, 16, 4, C.byref(cfg))
+        assert "struct_size" in _lib.last_error() and "80" in _lib.last_error()
+    ccfg = _lib.MdhCollectorCfg()
+    ccfg.fps, ccfg.num_cls, ccfg.exp_frame, ccfg.runtime_w, ccfg.runtime_h = 25.0, 10, 1, 960, 540
+    ccfg.struct_size = 104
+    assert not L.mdh_collector_create(C.byref(ccfg))
+    assert "struct_size" in _lib.last_error()
+    ccfg.struct_size = C.sizeof(_lib.MdhCollectorCfg)
+    h = L.mdh_collector_create(C.byref(ccfg))
+    assert h
+    L.mdh_collector_destroy(h)
+
+
+def test_integration_md_stub_matches_the_library():
+    """INTEGRATION.md option B is what a maintainer pastes into the reference: its ctypes structs are executed here and compared,
+    field by field, with the binding the tests exercise (round 2's stub ended at mask_area: 72 bytes against the library's 80)."""
+    import ctypes as C
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class _Cfg(C.Structure)"):doc.index("_L.mdh_create.restype")]
+    block = block[:block.index("assert _L.")] if "assert _L." in block else block
+    ns = {"C": C}
+    exec(block, ns)
+    for doc_cls, lib_cls in ((ns["_Cfg"], _lib.MdhCfg), (ns["_Info"], _lib.MdhFrameInfo)):
+        assert C.sizeof(doc_cls) == C.sizeof(lib_cls)
+        assert [(n, getattr(doc_cls, n).offset, getattr(doc_cls, n).size) for n, _ in doc_cls._fields_] == \
+               [(n, getattr(lib_cls, n).offset, getattr(lib_cls, n).size) for n, _ in lib_cls._fields_]
+    assert "struct_size=C.sizeof(_Cfg)" in doc and f"mdh_abi_version() == {_lib.MDH_ABI_VERSION}" in doc
+
+
+def test_inject_sums_contract_is_documented():
+    hdr = open(os.path.join(ROOT, "include", "metdet_hip.h")).read()
+    assert "mdh_hw_queues_hint" in hdr and _lib.load().mdh_hw_queues_hint() >= 0
 
 
 def test_frame_info_field_order_of_the_per_frame_path():
