@@ -480,18 +480,22 @@ def run_streams(a, D, wl, mask):
         run(8)
         per = (time.perf_counter() - t0) / 8
         steps = int(min(20000, max(50, 2.4 / max(per, 1e-5))))
-    if not a.no_profile:
-        ctx.profile_enable(4)  # every 4th pass carries timing events (they cost the pipeline a few per cent when on every pass)
-        ctx.profile_read(reset=True)
     tally[:] = [0, 0, 0]
     D.fence()
     t0 = time.perf_counter()
-    run(steps)
+    run(steps)  # the timed region carries no timing events: they cost the pipeline a few per cent
     D.fence()
     segs, kept, lit = tally
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read(reset=True) if not a.no_profile else {}
-    ctx.profile_enable(False)
+    prof = {}
+    if not a.no_profile and D.rank == 0:
+        # the kernels' spans INSIDE the pipeline (overlapping each other, queueing included): the same pipelined passes again,
+        # untimed, every 4th one carrying HIP events on the library's streams
+        ctx.profile_enable(4)
+        ctx.profile_read(reset=True)
+        run(max(8, min(steps, 24)))
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
     prof_alone = {}
     if not a.no_profile and a.standalone_passes > 0 and D.rank == 0:
         run(2, depth=1)

@@ -133,6 +133,11 @@ int mdh_submit_batch(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device);
 int mdh_collect_batch(mdh_ctx* ctx, mdh_frame_info* info, int32_t* raw_lines, int32_t* nms_lines, double* nonline);
 int mdh_in_flight(const mdh_ctx* ctx);
 int mdh_max_in_flight(const mdh_ctx* ctx);
+/* Diagnostics of the window kernel's output format (sparse + tagged words on a quiet sky; plain dense words when the binaries carry
+ * noise, e.g. 8K at m3det_high: chosen per pass from what the last collected pass reported (half of its frames dense -> dense format; below 1.5 % of the words set -> back);
+ * results are identical either way).  MDH_DENSE=0|1 in the environment pins the format. */
+int64_t mdh_dense_passes(const mdh_ctx* ctx);   /* batched passes queued in the dense format so far */
+double mdh_last_density(const mdh_ctx* ctx);    /* last collected pass: share of frames with a dense binary (sparse pass) or of words with set bits (dense pass) */
 
 /* The binary image `dst` (H*W u8 of {0,255}) of frame `index` of the most recent pass (0 .. frames_in_pass-1;
  * -1 = the last frame).  For visu() and parity tests.  stage: 0 = dst (after the dynamic mask), 1 = the image

@@ -74,7 +74,7 @@ EXPORTS = [
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
     "mdh_inject_sums", "mdh_mute_hough_until", "mdh_hough_planes_submit",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
-    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint"
+    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint", "mdh_dense_passes", "mdh_last_density"
 ]
 
 _lib = None
@@ -149,6 +149,10 @@ def load():
     L.mdh_seek.argtypes = [vp, i64, i64, dbl, dbl, dbl, i32]
     L.mdh_inject_sums.argtypes = [vp, i64, i64, i64]
     L.mdh_mute_hough_until.argtypes = [vp, i64]
+    L.mdh_dense_passes.argtypes = [vp]
+    L.mdh_dense_passes.restype = i64
+    L.mdh_last_density.argtypes = [vp]
+    L.mdh_last_density.restype = dbl
     if not hasattr(L, "mdh_abi_version") or L.mdh_abi_version() != MDH_ABI_VERSION:
         raise MetDetHipError(f"{LIB_PATH} implements another ABI version than this binding ({MDH_ABI_VERSION}): rebuild it "
                              "(`make -C metdetpy_amd/csrc -B`)")
@@ -414,3 +418,12 @@ class Context:
     @property
     def frames_seen(self) -> int:
         return self.L.mdh_frames_seen(self.handle)
+
+    @property
+    def dense_passes(self) -> int:
+        """Batched passes queued in the dense output format of the window kernel so far (diagnostics; results do not depend on it)."""
+        return self.L.mdh_dense_passes(self.handle)
+
+    @property
+    def last_density(self) -> float:
+        return self.L.mdh_last_density(self.handle)

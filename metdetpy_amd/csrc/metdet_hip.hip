@@ -80,6 +80,8 @@ struct Slot {
     unsigned* d_bandflag = nullptr;  // [K][bands][WW]: set bits of b per (8-row band, word column) block
     unsigned *d_nzlist = nullptr, *d_nzcount = nullptr;
     ActWord* d_bbits = nullptr;      // [K][H][WW] b = (diff > T), sparse + tagged: written by the window kernel, read by the morphology
+    u64* d_bplain = nullptr;         // [K][H][WW] the same image as plain words (dense passes; allocated when the first one is queued)
+    bool dense = false;              // the pass in the slot runs in the dense format
     u64* d_planes = nullptr;         // Classic: [K][2][H][WW]
     unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output
     hipEvent_t ev_k1 = nullptr;      // window kernel done (main stream) -> the post stream may start
@@ -208,6 +210,19 @@ struct mdh_ctx {
     // fails half-way the context no longer describes the stream, so it refuses further work instead of producing silently
     // wrong thresholds / windows.
     bool poisoned = false;
+    // Format of b = (diff > T) between the window kernel and the morphology: sparse + tagged (a quiet sky: nothing is written for
+    // 99 % of the wave-frames) or dense + plain (binaries with noise in them: 8K at m3det_high).  Chosen per pass from the share
+    // of words with set bits the last collected pass reported (both formats report it); identical results either way.
+    int dense_cfg = -1;        // MDH_DENSE: 1 = always dense, 0 = never, unset = automatic
+    bool dense_now = false;
+    double dense_leave = 0.015;  // back to the sparse format below this share of words with set bits (MDH_DENSE_LEAVE)
+    int64_t dense_passes = 0;  // passes queued in the dense format (mdh_dense_passes)
+    // hand-over between run_pixels and the window kernel's launcher: dense output wanted (and where), and whether the kernel
+    // that was launched honours it (only the wide-load variants do; the others fall back to the sparse format)
+    bool win_dense = false, win_dense_used = false;
+    u64* win_plain = nullptr;
+    unsigned long long* win_nzwords = nullptr;
+    double last_density = 0;
     int last_slot = -1;        // slot of the most recently collected pass (mdh_get_binary)
     // switches
     bool force_generic = false;     // MDH_FORCE_GENERIC=1: use the n-reads kernel (A/B and parity testing)
@@ -238,6 +253,8 @@ extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KE
 extern "C" int64_t mdh_frames_seen(const mdh_ctx* c) { return c ? c->t : -1; }
 extern "C" int mdh_in_flight(const mdh_ctx* c) { return c ? c->in_flight : -1; }
 extern "C" int mdh_max_in_flight(const mdh_ctx* c) { return c ? c->nslot : -1; }
+extern "C" int64_t mdh_dense_passes(const mdh_ctx* c) { return c ? c->dense_passes : -1; }
+extern "C" double mdh_last_density(const mdh_ctx* c) { return c ? c->last_density : -1; }
 
 template <typename T>
 static int dev_alloc(T*& p, size_t count, bool zero = true) {
@@ -282,7 +299,7 @@ static void free_all(mdh_ctx* c) {
     if (c->h_read_flag) hipHostFree(c->h_read_flag);
     if (c->h_inject) hipHostFree(c->h_inject);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_bbits, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr};
+        void* sdev[] = {s.d_bbits, s.d_bplain, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr};
         for (void* p : sdev)
             if (p) hipFree(p);
         void* shost[] = {s.h_hdr, s.h_res};
@@ -403,11 +420,28 @@ static int create_impl(mdh_ctx* c) {
     HIPCHK(make_stream(&c->pstream[1], "MDH_PRIO_HOUGH"));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    // MDH_HOUGH_CUS = m (experiment switch, default 0 = everywhere): the Hough streams alone are confined to m CUs of every XCD,
+    // every other stream -- the window kernel's too -- keeps the whole machine.  (MDH_POST_CUS above takes the reserved CUs AWAY
+    // from the window kernel; this one only keeps the Hough workgroups, which cost a CU a window workgroup while they are
+    // resident, off most of the CUs.)
+    int hough_cus = 0;
+    if (const char* v = getenv("MDH_HOUGH_CUS")) hough_cus = atoi(v);
+    if (ncu != 256 || hough_cus < 1 || hough_cus > 31) hough_cus = 0;
+    uint32_t mask_hough[8] = {0};
+    for (int x = 0; x < 8; ++x)
+        for (int j = 0; j < hough_cus; ++j) {
+            const int bit = 32 * x + ((x + 8 * j + 4 * (j / 4)) & 31);
+            mask_hough[bit >> 5] |= 1u << (bit & 31);
+        }
+    auto make_hough_stream = [&](hipStream_t* st) -> hipError_t {
+        if (hough_cus > 0) return hipExtStreamCreateWithCUMask(st, 8, mask_hough);
+        return make_stream(st, "MDH_PRIO_HOUGH");
+    };
     for (int hi = 0; hi < c->nhset; ++hi) {
         HoughSet& h = c->hset[hi];
-        HIPCHK(make_stream(&h.stream[0], "MDH_PRIO_HOUGH"));
-        HIPCHK(make_stream(&h.stream[1], "MDH_PRIO_HOUGH"));
-        HIPCHK(make_stream(&h.stream[2], "MDH_PRIO_HOUGH"));
+        HIPCHK(make_hough_stream(&h.stream[0]));
+        HIPCHK(make_hough_stream(&h.stream[1]));
+        HIPCHK(make_hough_stream(&h.stream[2]));
         HIPCHK(hipEventCreateWithFlags(&h.ev_big, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h.ev_big2, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h.ev_cls, hipEventDisableTiming));
@@ -475,7 +509,7 @@ static int create_impl(mdh_ctx* c) {
             TRY(dev_alloc(s.d_bandflag, K * nb * c->WW));
             TRY(dev_alloc(s.d_nzlist, K * words, false));
         }
-        TRY(dev_alloc(s.d_nzcount, 2));  // [0] listed words, [1] listed morphology blocks
+        TRY(dev_alloc(s.d_nzcount, 4));  // [0] listed words, [1] listed morphology blocks, [2..3] u64: words of b with set bits (window kernel)
         TRY(dev_alloc(s.d_dst, K * words));
         // one block [rowcount K*H | litcount K | bbox 4K] so that a single memset clears all three per pass
         // (+ K: the per-frame counts of the morphology work list, d_workcnt, cleared with the rest)
@@ -487,7 +521,7 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_lines, K * (size_t)MAX_LINES * 4));
         {
             auto a16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-            const size_t o_nraw = a16(sizeof(int) * (K + 1)), o_lit = o_nraw + a16(sizeof(int) * K), o_gap = o_lit + a16(sizeof(int) * K);
+            const size_t o_nraw = a16(sizeof(int) * (K + 3)),  /* off[K+1..K+2]: the pass's count of b words with set bits */ o_lit = o_nraw + a16(sizeof(int) * K), o_gap = o_lit + a16(sizeof(int) * K);
             const size_t o_fs = o_gap + a16(sizeof(double) * K), o_lines = o_fs + a16(sizeof(FrameScalars) * K);
             const size_t total = o_lines + sizeof(int) * 4 * K * (size_t)MAX_LINES;
             TRY(dev_alloc(s.d_res, total));
@@ -508,9 +542,13 @@ static int create_impl(mdh_ctx* c) {
 #undef TRY
     HIPCHK(hipFuncSetAttribute((const void*)k_hough_ppht, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (HOUGH_MAX_LIST + 61440 / 2 + 64) * (int)sizeof(unsigned)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_hough3, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
-    HIPCHK(hipFuncSetAttribute((const void*)k_hough3_hybrid, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
-    HIPCHK(hipFuncSetAttribute((const void*)k_hough_single, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // (the <true> instantiations carry the phase clocks of MDH_HOUGH_DEBUG and run only then)
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough3_hybrid<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough_single<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough3_hybrid<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_large));
+    HIPCHK(hipFuncSetAttribute((const void*)k_hough_single<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     // trig table exactly as OpenCV builds it: (float)(cos((double)n * theta) * irho), theta = (float)(pi/180), irho = 1
     float trig[2 * NUM_ANGLE];
@@ -635,6 +673,9 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
     if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_POLL")) c->lean_poll = atoi(v) != 0;
+    if (const char* v = getenv("MDH_DENSE")) c->dense_cfg = atoi(v) != 0;
+    if (const char* v = getenv("MDH_DENSE_LEAVE")) c->dense_leave = atof(v);
+    c->dense_now = c->dense_cfg == 1;
 
     if (create_impl(c) != MDH_OK) {
         std::string keep = g_err;
@@ -723,6 +764,20 @@ static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
     return g;
 }
 
+// Alignment the frames of the pass being queued allow the window kernel's loads: wide loads need contiguous 64-byte words
+// (W % 64 == 0) and aligned frame bases.  >= 8 with 2 <= n <= 16: a wide-load variant runs (the only ones with a dense output).
+static unsigned pass_alignment(const mdh_ctx* c, int K) {
+    unsigned align = 16;
+    if (c->W % 64 != 0 || c->force_bytes || c->force_generic) align = 1;
+    for (int e = 0; e < c->n - 1 + K && align > 1; ++e)
+        while (align > 1 && ((uintptr_t)c->h_ptrtab[e] & (align - 1))) align >>= 1;
+    return align;
+}
+static bool wide_kernel_applies(const mdh_ctx* c, int K) {  // (the 16-pixels-per-lane variants: the ones with a dense output)
+    static const int wide16_max_n = getenv("MDH_WIDE16_MAXN") ? atoi(getenv("MDH_WIDE16_MAXN")) : 16;
+    return pass_alignment(c, K) >= 16 && c->n >= 2 && c->n <= std::min(16, wide16_max_n) && !c->force_ppl8;
+}
+
 // Stage K frames (absolute timers t_base+1 .. t_base+K): build the pointer table [hist (n-1) | pass frames (K)].
 static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int on_device) {
     const int64_t t_base = sl.t_base;
@@ -733,6 +788,7 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
         const int64_t rs = (t_base + i) % c->R;
         c->h_ptrtab[c->n - 1 + i] = on_device ? frames + (size_t)i * c->HW : c->d_ring + (size_t)rs * c->HW;
     }
+    if (sl.dense && !wide_kernel_applies(c, K)) sl.dense = false;  // (decided before k_pass_prepare: the sparse format wants its block counters zeroed)
     if (c->lean_direct) {
         // no copy commands at all: the table entry of the frame is the caller's (pinned) buffer, the table itself stays in
         // the slot's pinned header, and no sigma is due (checked by the caller), so there are no jobs
@@ -817,10 +873,15 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     static const int wpb = getenv("MDH_WIN_BLOCK") ? std::max(1, std::min(4, atoi(getenv("MDH_WIN_BLOCK")) / 64)) : 4;  // waves per workgroup
     if (lean.copy_dst)  // per-frame protocol: its own instantiation, the batched one pays nothing for it
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
-                           c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean);
+                           c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean, (unsigned long long*)nullptr);
+    else if (PPL == 16 && c->win_dense)  // dense output format: 16-pixels-per-lane variants only (its own instantiation as well)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, 16, false, true>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
+                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean);
+                           c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean,
+                           c->win_nzwords);
+    c->win_dense_used = PPL == 16 && c->win_dense && !lean.copy_dst;
 }
 
 // copy_dst: see k_stack_threshold_wide (per-frame protocol; the caller has made sure a wide-load variant applies)
@@ -831,11 +892,7 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g, const LeanArgs
                            c->d_bbits, c->d_bandflag, g);
         return;
     }
-    // wide loads need contiguous 64-byte words (W % 64 == 0) and aligned frame bases
-    unsigned align = 16;
-    if (c->W % 64 != 0 || c->force_bytes) align = 1;
-    for (int e = 0; e < c->n - 1 + g.K && align > 1; ++e)
-        while (align > 1 && ((uintptr_t)c->h_ptrtab[e] & (align - 1))) align >>= 1;
+    const unsigned align = pass_alignment(c, g.K);
     // 16 pixels per lane up to n = 16 (252 VGPRs at n = 16: still two waves per SIMD; 4K / n = 16: 1.35 -> 0.92 ms per 512 frames)
     static const int wide16_max_n = getenv("MDH_WIDE16_MAXN") ? atoi(getenv("MDH_WIDE16_MAXN")) : 16;  // A/B switch
     if (align >= 16 && g.n >= 2 && g.n <= std::min(16, wide16_max_n) && !c->force_ppl8) {
@@ -880,7 +937,8 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     const bool m3 = c->cfg.detector == MDH_DET_M3;
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
-                       (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag, (unsigned)((size_t)K * nb * c->WW),
+                       (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag,
+                       sl.dense ? 0u : (unsigned)((size_t)K * nb * c->WW),  // (the dense format has no block counters)
                        (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
@@ -956,6 +1014,10 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         span_begin(c, KK_STACK_THR, c->stream);
         static const bool skip_window = getenv("MDH_SKIP_WINDOW") != nullptr;  // timing experiments only: results are wrong
         LeanArgs copy_dst{};
+        c->win_dense = sl.dense && !c->lean;
+        c->win_dense_used = false;
+        c->win_plain = sl.d_bplain;
+        c->win_nzwords = c->lean ? nullptr : (unsigned long long*)(sl.d_nzcount + 2);
         if (c->lean_direct) {  // the threshold is the detector's running one (no sigma due), the frame's ring copy is the kernel's job
             c->d_thr = &c->d_state->thr;
             c->read_seq += 1;
@@ -995,7 +1057,12 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // (dst of this slot is all-zero again: k_pass_prepare ran before ev_noise, which the window kernel waited for)
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_MORPH, post);
-        if (c->lean && K == 1) {
+        if (c->win_dense_used) {
+            c->dense_passes += 1;
+            // dense format: every frame through the 64-bit direct-mapped kernel, no work lists
+            static const int plain_grid = getenv("MDH_PLAIN_GRID") ? std::max(64, atoi(getenv("MDH_PLAIN_GRID"))) : 8192;
+            hipLaunchKernelGGL(k_morph_close_plain, dim3(plain_grid), dim3(64), 0, post, sl.d_bplain, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+        } else if (c->lean && K == 1) {
             hipLaunchKernelGGL(k_morph_close_frame, dim3((unsigned)((nb * c->WW + 63) / 64)), dim3(64), 0, post, sl.d_bbits, sl.d_bandflag, c->d_act,
                                sl.d_nzlist, sl.d_nzcount, g);
         } else {
@@ -1094,8 +1161,9 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
                        c->lean_direct ? c->d_state : nullptr, sl.seq_armed ? sl.h_seq : nullptr, sl.seq_no,
                        1, sl.d_bandflag, (unsigned)(nb * c->WW)};
         sl.lean_clean = true;
-        hipLaunchKernelGGL(k_hough_single, dim3(1), dim3(HOUGH3_THREADS), std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned)),
-                           hstream[0], P, R);
+        const size_t lds_single = std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned));
+        if (P.dbg_phase) hipLaunchKernelGGL(k_hough_single<true>, dim3(1), dim3(HOUGH3_THREADS), lds_single, hstream[0], P, R);
+        else hipLaunchKernelGGL(k_hough_single<false>, dim3(1), dim3(HOUGH3_THREADS), lds_single, hstream[0], P, R);
         span_end(c, hstream[0]);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(sl.ev_done, hstream[0]));
@@ -1109,7 +1177,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         HIPCHK(hipMemsetAsync(sl.d_nraw, 0, sizeof(int) * K, hstream[0]));
         EV_REC(c, hs.ev_big, hstream[0]);
     } else {
-        HIPCHK(hipMemsetAsync(hs.d_tier_count, 0, sizeof(int) * HOUGH_TIERS, hstream[0]));
+        // (hs.d_tier_count is zero: allocated so, and k_pack_lines of the set's previous pass left it so)
         hipLaunchKernelGGL(k_hough_classify, dim3((K + 3) / 4), dim3(256), 0, hstream[0], P);
         EV_REC(c, hs.ev_cls, hstream[0]);
         EV_WAIT(c, hstream[1], hs.ev_cls);
@@ -1119,6 +1187,16 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
             P.fcount = hs.d_tier_count + t;
         };
         P.lds_bytes = c->lds_large;
+        auto launch_h3 = [&](bool hybrid, int grid, hipStream_t st) {
+            const bool tm = P.dbg_phase != nullptr;
+            if (hybrid) {
+                if (tm) hipLaunchKernelGGL(k_hough3_hybrid<true>, dim3(grid), dim3(HOUGH3_THREADS), P.lds_bytes, st, P);
+                else hipLaunchKernelGGL(k_hough3_hybrid<false>, dim3(grid), dim3(HOUGH3_THREADS), P.lds_bytes, st, P);
+            } else {
+                if (tm) hipLaunchKernelGGL(k_hough3<true>, dim3(grid), dim3(HOUGH3_THREADS), P.lds_bytes, st, P);
+                else hipLaunchKernelGGL(k_hough3<false>, dim3(grid), dim3(HOUGH3_THREADS), P.lds_bytes, st, P);
+            }
+        };
         static const int grid_l = getenv("MDH_HOUGH_GRID_LARGE") ? atoi(getenv("MDH_HOUGH_GRID_LARGE")) : 256;
         static const int grid_s = getenv("MDH_HOUGH_GRID_SMALL") ? atoi(getenv("MDH_HOUGH_GRID_SMALL")) : 1024;
         // The hybrid frames are the longest replays of a pass (a 2000-point 4K streak: 0.6-0.8 ms against 0.1-0.3 ms for a
@@ -1129,10 +1207,10 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         hipStream_t lstream = split ? hs.stream[2] : hstream[1];
         if (!c->lean && !split) {
             tier(1);
-            hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_l)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+            launch_h3(false, std::min(K, grid_l), hstream[1]);
         }
         tier(2);
-        hipLaunchKernelGGL(k_hough3_hybrid, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        launch_h3(true, std::min(K, hs.pool), hstream[1]);
         tier(3);
         hipLaunchKernelGGL(k_hough_ppht, dim3(std::min(K, hs.pool_list)), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned),
                            hstream[1], P);
@@ -1140,13 +1218,13 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         if (!c->lean && split) {
             EV_WAIT(c, lstream, hs.ev_cls);
             tier(1);
-            hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_l)), dim3(HOUGH3_THREADS), P.lds_bytes, lstream, P);
+            launch_h3(false, std::min(K, grid_l), lstream);
             EV_REC(c, hs.ev_big2, lstream);
             large_split = true;
         }
         tier(0);
         P.lds_bytes = P.lds_small;
-        hipLaunchKernelGGL(k_hough3, dim3(std::min(K, grid_s)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[0], P);
+        launch_h3(false, std::min(K, grid_s), hstream[0]);
         (void)Kmax;
     }
     EV_WAIT(c, hstream[0], hs.ev_big);
@@ -1156,7 +1234,10 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     // pack the segments and send the head of the packed array along with the scalars; collect_pass fetches the rest only
     // when a pass holds more than PACK_HEAD segments per frame on average
     hipLaunchKernelGGL(k_pack_lines, dim3(1), dim3(1024), 0, hstream[0], (const int4*)sl.d_lines, sl.d_nraw, K, MAX_LINES,
-                       (int4*)sl.d_packed, sl.d_off, sl.d_litcount, sl.d_litcopy);
+                       (int4*)sl.d_packed, sl.d_off, sl.d_litcount, sl.d_litcopy,
+                       // the format cue: dense pass -> words of b with set bits (u64); sparse pass -> its number of dense frames
+                       sl.dense ? (const unsigned*)(sl.d_nzcount + 2) : (const unsigned*)sl.d_dense,
+                       skip_hough ? (int*)nullptr : hs.d_tier_count);
     // ONE copy: offsets, counts, gaps, frame scalars and the head of the packed segments
     HIPCHK(hipMemcpyAsync(sl.h_res, sl.d_res, sl.res_lines_off + sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K,
                           hipMemcpyDeviceToHost, hstream[0]));
@@ -1267,6 +1348,18 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     c->prof = c->prof_every > 0 && c->pass_seq % c->prof_every == 0;
     sl.K = K;
     sl.t_base = c->t;
+    sl.dense = false;
+    if (c->dense_now && c->cfg.detector == MDH_DET_M3 && c->role != MDH_ROLE_HOUGH && K > 1) {
+        if (!sl.d_bplain) {  // first dense pass on this slot (an allocation synchronises the device: once per slot)
+            if (hipMalloc((void**)&sl.d_bplain, sizeof(u64) * (size_t)c->Kmax * c->words) != hipSuccess) {
+                (void)hipGetLastError();
+                sl.d_bplain = nullptr;  // no memory for the second format: stay with the sparse one
+                c->dense_now = false;
+                c->dense_cfg = 0;
+            }
+        }
+        sl.dense = sl.d_bplain != nullptr;
+    }
     sl.was_clean = sl.lean_clean;
     sl.lean_clean = false;
     sl.seq_armed = false;
@@ -1313,6 +1406,22 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
     c->host_us[0] += now_us() - t0;
     host_log("submit end", c->pass_seq - 1);
     return MDH_OK;
+}
+
+// The format of the passes queued from now on, from what the pass just collected reported (hysteresis; both formats give the
+// same results): a sparse pass reports its number of DENSE FRAMES (at least half of the morphology blocks listed: k_morph_close),
+// a dense pass the number of words of b with set bits.
+static void format_cue(mdh_ctx* c, const Slot& sl) {
+    const int K = sl.K;
+    if (!sl.dense) {
+        const double share = (double)(unsigned)sl.h_off[K + 1] / (double)K;  // frames whose binary was dense
+        c->last_density = share;
+        if (c->dense_cfg < 0 && !c->dense_now && share >= 0.5) c->dense_now = true;
+    } else {
+        const unsigned long long nzw = (unsigned long long)(unsigned)sl.h_off[K + 1] | ((unsigned long long)(unsigned)sl.h_off[K + 2] << 32);
+        c->last_density = (double)nzw / ((double)K * (double)c->words);
+        if (c->dense_cfg < 0 && c->dense_now && c->last_density < c->dense_leave) c->dense_now = false;
+    }
 }
 
 // Wait for the oldest pass in flight and hand its results to the caller.
@@ -1370,6 +1479,7 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
             o.hough_gap = sl.h_gap[i];
         }
     }
+    if (!sl.host_complete && c->role != MDH_ROLE_HOUGH) format_cue(c, sl);
     c->host_us[1] += t1 - t0;
     c->host_us[2] += t2 - t1;
     c->host_us[3] += now_us() - t2;
@@ -1565,6 +1675,8 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     HIPCHK(hipGetLastError());
     if (!out_on_device) HIPCHK(hipMemcpyAsync(dst_rows, dev_out, out_words * sizeof(u64), hipMemcpyDeviceToHost, post));
     HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, post));
+    HIPCHK(hipMemcpyAsync(sl.h_off + K + 1, sl.dense ? (const void*)(sl.d_nzcount + 2) : (const void*)sl.d_dense, 2 * sizeof(unsigned),
+                          hipMemcpyDeviceToHost, post));  // the format cue (see k_pack_lines)
     HIPCHK(hipEventRecord(sl.ev_done, post));
     const int si = (int)(&sl - c->slot);
     hs.last_slot = si;
@@ -1574,6 +1686,7 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     c->band_slot = nullptr;
     HIPCHK(hipEventSynchronize(sl.ev_done));
     spans_collect(c, sl);
+    format_cue(c, sl);
     if (info) {
         for (int i = 0; i < K; ++i) {
             mdh_frame_info& o = info[i];

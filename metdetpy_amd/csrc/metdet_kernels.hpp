@@ -16,6 +16,7 @@ typedef unsigned long long u64;
 typedef unsigned __int128 u128;
 
 #define NUM_ANGLE 180
+#define HOUGH_TIERS 4  // launches a pass's frames are routed to (k_hough_classify)
 #define MAX_LINES 512
 #define WORKCNT_STRIDE 32  // the per-frame counts of the morphology work list sit one 128-byte line apart: packed, the appends of 32
                            // frames met in ONE L2 channel (k_morph_select 2.1 ms per pass of 512 dense 8K frames, rocprofv3 round 2c)
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
                                                         double coef_a, double coef_b, unsigned* __restrict__ nzcount) {
     RAISE_WAVE_PRIORITY();
     // the slot's list counters ([0] lit words, [1] morphology blocks): k_pass_prepare, earlier on this stream, was their last reader
-    if (nzcount && threadIdx.x < 2) nzcount[threadIdx.x] = 0;
+    if (nzcount && threadIdx.x < 4) nzcount[threadIdx.x] = 0;  // ([2..3]: the window kernel's count of words with set bits)
     // jobres[0] = state on entry, jobres[j+1] = state after job j
     if (threadIdx.x == 0) {
         ScalarState s = *st;
@@ -380,6 +381,9 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_U16
 #define WIDE_U16 4  // frames per load burst of the 16-pixels-per-lane kernel (A/B builds: -DWIDE_U16=8)
 #endif
+#ifndef WIDE_U16_BIGN
+#define WIDE_U16_BIGN WIDE_U16  // the same for windows of more than 8 frames (A/B builds: -DWIDE_U16_BIGN=2: 16 registers less at n = 16)
+#endif
 #ifndef WIDE_MAX3
 #define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
 #endif
@@ -416,11 +420,19 @@ __device__ __forceinline__ void lean_wave_done(const LeanArgs& lean, unsigned to
         }
     }
 }
-template <int N, int PPL, bool LEAN>
+template <int N, int PPL, bool LEAN, bool DENSE = false>
 __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                               unsigned* __restrict__ blockcnt, PassGeom g, int Tc,
-                                                              LeanArgs lean) {
+                                                              LeanArgs lean, unsigned long long* __restrict__ nzwords) {
+    // DENSE (its own instantiation: the sparse one must not pay a register for it; batched passes on streams whose binaries are dense: 8K at m3det_high, where the lowered threshold lets noise
+    // through and 9 % of the words carry a bit): EVERY word of b is written, plainly -- u64 [K][H][WW] in the same buffer, no
+    // tags, no block counters, 128 contiguous bytes per wave and frame -- and k_morph_close_plain reads it.  The sparse-tagged
+    // output that wins on a quiet sky (nothing written at all for 99 % of the wave-frames) costs such a stream a 16-byte store
+    // plus a same-line atomic for four wave-frames in five (rocprofv3 PMC, round 2: 12x the bytes written, 2.5x the waiting).
+    // nzwords (DENSE only): words with set bits the launch produced (one atomic per wave at the end): the host's cue to go back
+    // to the sparse format (the sparse format's cue for the other direction is the pass's count of dense frames, k_morph_close).
+    unsigned nz_mine = 0;  // (wave-uniform: a scalar register)
     // lean.copy_dst (per-frame protocol only, otherwise null): frame 0 of the pass is read straight from the caller's pinned
     // HOST buffer (its table entry is a host address: the loads cross PCIe) and the kernel leaves the copy the next windows
     // reach back to in the ring slot copy_dst -- no DMA command, and no DMA-to-compute hand-over, in front of the frame's
@@ -437,7 +449,8 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     constexpr int RW = PPL / 2;   // packed pair registers per window entry
     constexpr int DW = PPL / 4;   // dwords per load
     constexpr int LPW = 64 / PPL; // lanes per 64-pixel word
-    constexpr int U = PPL == 16 ? (N < WIDE_U16 ? N : WIDE_U16) : (N < 8 ? N : 8);
+    constexpr int UW = N > 8 ? WIDE_U16_BIGN : WIDE_U16;
+    constexpr int U = PPL == 16 ? (N < UW ? N : UW) : (N < 8 ? N : 8);
     typedef unsigned dvec __attribute__((ext_vector_type(DW)));
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
@@ -494,7 +507,7 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     // 430 k -> 457 k frames/s, 1080p / n = 8 unchanged (that launch is not bound by VALU issue).  The per-frame instantiation
     // (LEAN) keeps the two-input form: its single-frame launch got 5 us slower with this one (50 -> 55 us, 8.75 k -> 8.2 k frames/s).
     constexpr bool MAX3 = WIDE_MAX3 != 0 && GS == 4 && !LEAN;
-    constexpr bool RAREBITS = WIDE_RAREBITS != 0 && !LEAN;
+    constexpr bool RAREBITS = WIDE_RAREBITS != 0 && !LEAN && !DENSE;  // (the dense format stores every frame's word: nothing to skip)
     u16x2 t23[RW];
     // Window sums: two 16-bit fields per register, updated with plain 32-bit adds / subtracts (a field never carries or
     // borrows: 255 * (N + 1) < 2^16, and the value leaving the window is part of the sum).  v_add_u32 / v_sub_u32 issue at
@@ -534,6 +547,11 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
         }
     }
     const int e_max = g.K + N - 2;
+#ifndef WIDE_FOLD_TL
+#define WIDE_FOLD_TL (DENSE || N >= 12)  // (sparse, n = 8: +5 registers with it, one step over three-waves-plus-a-Hough-wave per SIMD; n = 9..11: 164 -> 181, three waves per SIMD -> two; from n = 12 on two waves either way: 4K / n = 16 +2.5 %)
+#endif
+    constexpr bool FOLD_TL = WIDE_FOLD_TL;
+    unsigned tl_cur = 0;  // the (T * len) * 0x10001 the sums carry at the moment (wave-uniform)
     const int len0 = window_len(g, i0);  // window_len(g, i0 + s) = min(n, len0 + s), in 32-bit scalar arithmetic
     // Bursts of U frames; the loads of burst b+1 are issued before burst b is consumed (double buffering), so a
     // wave always has loads in flight while it computes.
@@ -585,6 +603,16 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                         const int len = min(g.n, len0 + s);  // window_len(g, i)
                         const unsigned short nlen = (unsigned short)(0 - len);
                         const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[ub + u] * len) * 0x10001u;  // scalar unit
+                        // FOLD_TL: the addend T * len lives INSIDE the running sums (round 3: one add per pixel pair and frame less): it
+                        // changes with the threshold -- at most at every (interval * n)-th frame -- and with the window length
+                        // during the first n frames of a stream; then every sum takes the difference (32-bit arithmetic on two
+                        // 16-bit fields: exact, the fields stay below 2^16: 255 * 17 + 256 * 16).
+                        if (FOLD_TL && tl != tl_cur) {
+                            const unsigned delta = tl - tl_cur;
+#pragma unroll
+                            for (int r = 0; r < RW; ++r) sum[r] += delta;
+                            tl_cur = tl;
+                        }
                         const u16x2 NLv = {nlen, nlen};
                         unsigned acc = 0;
                         unsigned dk[RW];
@@ -668,7 +696,7 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
                             // sum < (max - T) * len  <=>  bit 15 of sum + (max - T) * (-len) mod 2^16 (all terms < 2^15 for
                             // n <= 128); written as a multiply-add so that it maps to one v_pk_mad_u16
                             PK d, st;
-                            st.u = sum[r] + tl;
+                            st.u = FOLD_TL ? sum[r] : sum[r] + tl;
                             d.v = m * NLv + st.v;
                             if constexpr (RAREBITS) {
                                 dk[r] = d.u;
@@ -701,9 +729,14 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
 #pragma unroll
                             for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
                         }
+                        if constexpr (DENSE) {
+                            nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0));
+                            if (q == 0 && gw < words) ((u64*)bbits)[(size_t)i * words + gw] = v;
+                        } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             bbits[(size_t)i * words + gw] = ActWord{v, (u64)(g.t_base + 1 + i)};
                             if (blockcnt != nullptr) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
+                        }
                         }
                     }
                 }
@@ -715,6 +748,9 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
         }
     }
     if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * (blockDim.x >> 6));
+    if constexpr (DENSE) {
+        if (nzwords != nullptr && lane == 0 && nz_mine) atomicAdd(nzwords, (unsigned long long)nz_mine);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -953,6 +989,126 @@ __global__ void __launch_bounds__(64) k_morph_close_dense(const ActWord* __restr
         morph_close_band<MORPH_DENSE_ROWS>(load_row, i, wc, (int)band * MORPH_DENSE_ROWS, live, act_ring, nzlist, nzcount, g);
     }
 }
+// Plain dense binaries (the window kernel's dense output: u64 [K][H][WW], every word written): the same
+// act = close3x3(median3(b)) on 64-BIT words.  A wave takes 62 adjacent word columns of a band of MORPH_PLAIN_ROWS rows plus one
+// halo column on either side (lane l <-> word w0 - 1 + l); a lane works on its own word only and gets the ONE bit a 3x3 stage
+// needs from either neighbour with a DPP wave shift of its edge bits -- once per stage (b for the median, the OR of three
+// median rows for the dilate, the dilated row for the erode), because a lane cannot compute its neighbour's intermediate bits
+// as the 128-bit windows of morph_close_band do (64 + 3 + 3 bits, every stage on twice the registers).  The halo lanes compute
+// their whole word like any other: their outer edge is wrong and never looked at, their inner edge depends on their own word and
+// on lane 1 / 62 only.  Half the ALU work per word, 8 bytes loaded per word instead of 16, no tag compares.  Same row-skipping
+// rule as morph_close_band (a median row needs >= 5 set samples in its three 66-bit row windows), same stores and list appends.
+#define MORPH_PLAIN_ROWS 16
+#define MORPH_PLAIN_COLS 62
+__device__ __forceinline__ void edge_bits(u64 c, unsigned& lbit, unsigned& rbit) {
+    const int mine = (int)((unsigned)(c >> 63) | ((unsigned)(c & 1ull) << 1));
+    const unsigned from_left = (unsigned)__builtin_amdgcn_update_dpp(0, mine, 0x138, 0xF, 0xF, false);   // wave_shr:1  lane l <- l - 1
+    const unsigned from_right = (unsigned)__builtin_amdgcn_update_dpp(0, mine, 0x130, 0xF, 0xF, false);  // wave_shl:1  lane l <- l + 1
+    lbit = from_left & 1u;          // the left neighbour's top bit
+    rbit = (from_right >> 1) & 1u;  // the right neighbour's bottom bit
+}
+__global__ void __launch_bounds__(64) k_morph_close_plain(const u64* __restrict__ bplain, ActWord* __restrict__ act_ring,
+                                                          unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+    const int lane = threadIdx.x;
+    const unsigned cgroups = (unsigned)(g.WW + MORPH_PLAIN_COLS - 1) / MORPH_PLAIN_COLS;
+    const unsigned bands = (unsigned)(g.H + MORPH_PLAIN_ROWS - 1) / MORPH_PLAIN_ROWS;
+    const unsigned per_frame = cgroups * bands;
+    const size_t words = (size_t)g.H * g.WW;
+    for (unsigned item = blockIdx.x; item < (unsigned)g.K * per_frame; item += gridDim.x) {
+        const unsigned i = item / per_frame, rest = item - i * per_frame;
+        const unsigned band = rest / cgroups, cg = rest - band * cgroups;
+        const int w = (int)cg * MORPH_PLAIN_COLS - 1 + lane;
+        const bool live = w >= 0 && w < g.WW;
+        const bool outl = live && lane >= 1 && lane <= MORPH_PLAIN_COLS;
+        const int wc = live ? w : 0;
+        const bool first_w = w == 0, last_w = w == g.WW - 1;
+        const int pl = (g.W - 1) & 63;                                    // position of pixel W-1 in the last word
+        const u64 vm = !live ? 0ull : ((last_w && pl != 63) ? ((2ull << pl) - 1) : ~0ull);  // pixels that exist
+        const u64 top = 1ull << pl;
+        const int mx = (first_w || last_w) ? 2 : 1;
+        const int y0 = (int)band * MORPH_PLAIN_ROWS;
+        const u64* src = bplain + (size_t)i * words;
+        const long long t = g.t_base + 1 + (long long)i;
+        ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * words;
+        u64 bA = 0, bB = 0;            // raw rows yy-2, yy-1
+        unsigned eA = 0, eB = 0;       // their neighbours' edge bits: bit 0 = left neighbour's top bit, bit 1 = right neighbour's bottom bit
+        int pA = 0, pB = 0;
+        u64 mA = 0, mB = 0;            // median rows
+        u64 dA = ~0ull, dB = ~0ull;    // horizontally eroded dilate rows
+        auto hsum = [&](u64 b, unsigned e, u64& h0, u64& h1) {  // horizontal 3-sum with the image border replicated
+            unsigned lb = e & 1u, rb = (e >> 1) & 1u;
+            if (first_w) lb = (unsigned)(b & 1ull);
+            u64 L = (b << 1) | (u64)lb, Rr = (b >> 1) | ((u64)rb << 63);
+            if (last_w) Rr |= b & top;
+            h0 = L ^ b ^ Rr;
+            h1 = (L & b) | (L & Rr) | (b & Rr);
+        };
+#pragma unroll 2
+        for (int it = 0; it < MORPH_PLAIN_ROWS + 6; ++it) {
+            const int yy = y0 - 3 + it;
+            const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
+            const u64 brow = live ? src[(size_t)yc * g.WW + wc] : 0ull;
+            unsigned lb, rb;
+            edge_bits(brow, lb, rb);
+            const unsigned eC = lb | (rb << 1);
+            const int pC = __popcll(brow) + (int)lb + (int)rb;
+            const int ym = yy - 1, yd = yy - 2, ya = yy - 3;
+            u64 mC = 0;
+            if ((pA + pB + pC) * mx >= 5 && ym >= 0 && ym < g.H) {  // (a row outside the image never wins the dilate: its median stays 0)
+                u64 a0, a1, b0, b1, c0, c1;
+                hsum(bA, eA, a0, a1);
+                hsum(bB, eB, b0, b1);
+                hsum(brow, eC, c0, c1);
+                const u64 s0 = a0 ^ b0 ^ c0, k0 = (a0 & b0) | (a0 & c0) | (b0 & c0);
+                const u64 s1 = a1 ^ b1 ^ c1, k1 = (a1 & b1) | (a1 & c1) | (b1 & c1);
+                const u64 t1 = k0 ^ s1, c2 = k0 & s1, u2 = c2 ^ k1, u3 = c2 & k1;
+                mC = (u3 | (u2 & (t1 | s0))) & vm;  // at least 5 of the 9 samples set
+            }
+            // dilate row yd: the OR of three median rows, then ONE horizontal OR-3 (OR commutes)
+            const u64 v = mA | mB | mC;
+            if (__ballot(v != 0) == 0) {
+                // (almost every row on a noisy sky: the median has removed what the threshold let through.)  No median pixel
+                // anywhere in the wave's three rows: the dilated row is zero in every lane, its horizontal erosion is a per-lane
+                // constant -- zero wherever a pixel exists -- so nothing can come out for row ya, and two of the three edge
+                // exchanges and all of the dilate / erode logic are skipped
+                bA = bB; bB = brow;
+                eA = eB; eB = eC;
+                pA = pB; pB = pC;
+                mA = mB; mB = 0;
+                dA = dB; dB = (yd >= 0 && yd < g.H) ? ~vm : ~0ull;
+                continue;
+            }
+            edge_bits(v, lb, rb);
+            const u64 dC = (v | (v << 1) | (v >> 1) | (u64)lb | ((u64)rb << 63)) & vm;
+            // erode, horizontal part: positions outside the image count as 1; a dilate row outside the image never wins
+            const bool dC_in = yd >= 0 && yd < g.H;
+            const u64 e = (dC_in ? dC : ~0ull) | ~vm;  // (lanes without a word: all ones)
+            edge_bits(e, lb, rb);
+            if (first_w) lb = 1u;
+            if (last_w) rb = 1u;
+            const u64 hC = e & ((e << 1) | (u64)lb) & ((e >> 1) | ((u64)rb << 63));
+            u64 a = 0;
+            if (outl && ya >= y0 && ya < g.H) a = dA & dB & hC & vm;
+            const u64 have = __ballot(a != 0);
+            if (have) {
+                const int leader = __builtin_ctzll(have);
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(nzcount, (unsigned)__popcll(have));
+                base = __shfl(base, leader);
+                if (a) {
+                    dst[(size_t)ya * g.WW + w] = ActWord{a, (u64)t};
+                    nzlist[base + __popcll(have & ((1ull << lane) - 1))] = (unsigned)((size_t)i * words + (size_t)ya * g.WW + w);
+                }
+            }
+            bA = bB; bB = brow;
+            eA = eB; eB = eC;
+            pA = pB; pB = pC;
+            mA = mB; mB = mC;
+            dA = dB; dB = hC;
+        }
+    }
+}
 // Every frame's segment of the work list gets the same share of the grid's waves (nwaves / K of them, at least one), which walk
 // it 64 entries at a time: one look at the frame's count per wave.  (Walking all wave-slots of all segments instead -- a count
 // load per slot -- cost the sparse 4K pipeline 10 %: 63 dependent loads per wave to find out that there is nothing to do.)
@@ -1116,9 +1272,14 @@ __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ cou
 // sits in one contiguous block (one device-to-host copy).
 __global__ void __launch_bounds__(1024) k_pack_lines(const int4* __restrict__ lines, const int* __restrict__ nraw, int K,
                                                      int max_lines, int4* __restrict__ packed, int* __restrict__ off,
-                                                     const int* __restrict__ litcount, int* __restrict__ litcopy) {
+                                                     const int* __restrict__ litcount, int* __restrict__ litcopy,
+                                                     const unsigned* __restrict__ nzwords, int* __restrict__ tier_count) {
     RAISE_WAVE_PRIORITY();
     for (int i = threadIdx.x; i < K; i += blockDim.x) litcopy[i] = litcount[i];
+    if (threadIdx.x < 2) off[K + 1 + threadIdx.x] = nzwords ? (int)nzwords[threadIdx.x] : 0;  // words of b with set bits (u64)
+    // the routing counters of the Hough set: every launch that read them is done (this kernel runs behind them), so they are
+    // left at zero for the set's next pass -- one memset command per pass less on the Hough stream
+    if (tier_count && threadIdx.x < HOUGH_TIERS) tier_count[threadIdx.x] = 0;
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1989,7 +2150,6 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
 //   tier 2      three-wave kernel, hybrid: the rho windows that fit in LDS + a pooled global accumulator for the rest
 //   tier 3      one-wave kernel with a global point list (more than HOUGH_MAX_LIST points)
 //   none        fewer points than the vote threshold: no accumulator cell can reach it, so there is no segment
-#define HOUGH_TIERS 4
 #define HOUGH_MAX_LIST 8192
 #define HOUGH3_THREADS 192
 #define HOUGH3_FIXED_DWORDS 64  // mailboxes + scan scratch + line results
@@ -2069,6 +2229,7 @@ struct Hough3 {
     unsigned vinc;         // 1 for a thread with an angle, 0 for the 12 spare lanes (their votes add nothing to a private cell)
     int cbase;             // LDS cell of rho bin r (before the +half shift): r + cbase
     bool in_lds;           // HYBRID: this angle's window lives in LDS
+    bool dead;             // HYBRID: the window does not, and no cell of it can ever hold `threshold` votes: the angle is out of the replay
     int* acc_row;          // HYBRID: this angle's row of the pooled global accumulator, shifted by half
     unsigned* cells;
     // working mask
@@ -2081,13 +2242,14 @@ struct Hough3 {
     unsigned* fix;         // fixed LDS block: [0..7] hit mailbox (2 parities x 4), [8..11] keys, [12..23] line ends, [24] un-vote count, [32..] scan
     unsigned* uv;
     bool touched_global;
-    bool timing;           // MDH_HOUGH_DEBUG: cycles per phase (thread 0's view)
     long long ph[8];       // steps (table, list, mask), votes, hits + barrier, trigger (take back, arg-max), walk, clear, un-vote, lines
     // full-accumulator mode (h3_accumulate): this thread's cached row maximum and whether an un-vote has hit its cell since
     int best_r;
     bool dirty;
 };
-#define H3_T(C, k, t0) do { if ((C).timing) { const long long t1_ = clock64(); (C).ph[k] += t1_ - (t0); (t0) = t1_; } } while (0)
+// (TM: template parameter of the enclosing function -- the timed instantiations run only under MDH_HOUGH_DEBUG; the product's carry
+// no clock reads, no phase counters and no scalar registers for them)
+#define H3_T(C, k, t0) do { if (TM) { const long long t1_ = clock64(); (C).ph[k] += t1_ - (t0); (t0) = t1_; } } while (0)
 
 template <bool HYBRID>
 __device__ __forceinline__ bool h3_bit(const Hough3& C, int x, int y) {
@@ -2124,6 +2286,7 @@ __device__ __forceinline__ unsigned h3_vote_issue(Hough3& C, int x, int y, unsig
         return atomicAdd(&C.cells[c >> 1], (C.vinc & inc) << sh);
     }
     sh = -1;
+    if (C.dead) return (unsigned)(-KEY_BIAS - 2);  // (read as a count: below every threshold)
     return (unsigned)atomicAdd(&C.acc_row[r], (int)inc);
 }
 template <bool HYBRID>
@@ -2141,7 +2304,7 @@ __device__ __forceinline__ void h3_unvote(Hough3& C, int x, int y) {
     if (!HYBRID || C.in_lds) {
         const int c = r + C.cbase;
         atomicSub(&C.cells[c >> 1], C.vinc << ((c & 1) * 16));
-    } else {
+    } else if (!C.dead) {
         C.touched_global = true;
         atomicSub(&C.acc_row[r], 1);
     }
@@ -2168,7 +2331,7 @@ __device__ __forceinline__ int h3_scan(int v, int& total, unsigned* scratch, int
 // k; ends with a barrier after which every wave sees the cleared mask and the taken-back votes of ITS OWN cells.
 // ACC (full-accumulator mode): every lit pixel has voted, so the votes of every cleared pixel are taken back whether or not
 // the segment is long enough -- the accumulator stays the vote count of the pixels still in the mask.
-template <bool HYBRID, bool ACC = false>
+template <bool HYBRID, bool TM, bool ACC = false>
 __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     const HoughParams& P = C.P;
     const int lane = C.lane;
@@ -2189,8 +2352,8 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     const int k = C.wave;  // direction of this wave (wave 2 has none)
     const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
     unsigned* ends = C.fix + 12;  // [k][end_step, end_x, end_y]
-    long long tph = C.timing ? clock64() : 0;
-    if (C.timing) C.ph[7] += 1;  // [15:0] line events, [39:16] vote slots issued, [63:40] sub-groups
+    long long tph = TM ? clock64() : 0;
+    if (TM) C.ph[7] += 1;  // [15:0] line events, [39:16] vote slots issued, [63:40] sub-groups
     if (C.tid == 0) C.fix[24] = 0;  // un-vote list is empty (its last readers passed a barrier since)
     if (k < 2) {
         int gap = 0, last_lit = 0;
@@ -2288,16 +2451,33 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     H3_T(C, 6, tph);
 }
 
+// The count a thread's cell holds right now for point (x, y) (its own earlier operations on the cell have completed: LDS
+// operations of a wave execute in order; a returning atomic on the thread's own row of the pooled accumulator is ordered
+// behind its earlier atomics on the same address).
 template <bool HYBRID>
+__device__ __forceinline__ int h3_cell_now(Hough3& C, int x, int y) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+    if (!HYBRID || C.in_lds) {
+        const int c = r + C.cbase;
+        return (int)((C.cells[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
+    }
+    if (C.dead) return -KEY_BIAS;  // below the winner's count (>= threshold), whatever the angle's true count (< threshold) is
+    return atomicAdd(&C.acc_row[r], 0);
+}
+
+#ifndef H3_SUB
+#define H3_SUB 8  // largest sub-group (A/B builds: -DH3_SUB=16 is round 2's)
+#endif
+template <bool HYBRID, bool TM>
 __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
     const HoughParams& P = C.P;
     const int lane = C.lane;
     const unsigned short* perm = P.perm + (size_t)N * (N - 1) / 2;
     unsigned round = 0;
-    int gsz = 16;
+    int gsz = H3_SUB;
     unsigned nxt = lane < N ? perm[lane] : 0;  // the table entries of the following step are fetched one step ahead
     for (int k0 = 0; k0 < N; k0 += 64) {
-        long long tph = C.timing ? clock64() : 0;
+        long long tph = TM ? clock64() : 0;
         const int kk = k0 + lane;
         const unsigned idx = nxt;
         nxt = kk + 64 < N ? perm[kk + 64] : 0;
@@ -2309,37 +2489,44 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
             // sub-group: the first (up to) `gsz` live points of the step vote back to back.  Votes behind a trigger are wasted
             // (taken back and repeated), and triggers come in bursts (the parallel lines of one streak), so the sub-group
             // shrinks to 4 after a trigger and doubles with every quiet sub-group.
-            int old[16];
+            // Registers (round 3): the kernel shares its SIMDs with the window kernel's waves (148 VGPRs, three per SIMD: 56
+            // registers are left), so a sub-group keeps the raw returns of its atomics only until they are turned into one hit
+            // bit each (round 2 kept sixteen returned counts + sixteen shifts alive across the barrier: 87 VGPRs, and every SIMD
+            // that hosted a Hough wave lost a window wave).  The one count that is needed later -- the trigger point's, for the
+            // arg-max over the angles -- is read back from the cell after the votes behind the trigger have been taken back.
             am = h3_uniform(am);
             u64 rem = am;
-            const int gused = gsz <= 4 ? 4 : (gsz <= 8 ? 8 : 16);  // slots of this sub-group
-            if (C.timing) C.ph[7] += ((long long)min(gused, (int)__popcll(am)) << 16) + (1ll << 40);
+            const int gused = gsz <= 4 ? 4 : (gsz <= 8 || H3_SUB <= 8 ? 8 : 16);  // slots of this sub-group
+            if (TM) C.ph[7] += ((long long)min(gused, (int)__popcll(am)) << 16) + (1ll << 40);
+            unsigned hits = 0;
             {
-                unsigned raw[16];
-                int shv[16];
-                u64 hasm = 0;
+                unsigned raw[H3_SUB];
+                unsigned odd = 0;  // bit j: slot j's cell is the upper half of its dword
+                unsigned hasm = 0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < H3_SUB; ++j) {
                     if (j < gused) {  // (gused is wave-uniform: 4, 8 or 16 slots)
                         const bool has = rem != 0;
                         const int l = has ? __builtin_ctzll(rem) : 0;
                         rem &= rem - 1;
-                        hasm |= (u64)(has ? 1 : 0) << j;
-                        raw[j] = h3_vote_issue<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u, shv[j]);
+                        hasm |= (has ? 1u : 0u) << j;
+                        int sh;
+                        raw[j] = h3_vote_issue<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u, sh);
+                        odd |= (sh > 0 ? 1u : 0u) << j;
                     }
                 }
+                if (TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                H3_T(C, 1, tph);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    old[j] = -KEY_BIAS - 1;
-                    if (j < gused && ((hasm >> j) & 1)) old[j] = h3_vote_value<HYBRID>(raw[j], shv[j]);
+                for (int j = 0; j < H3_SUB; ++j) {
+                    if (j < gused && ((hasm >> j) & 1)) {
+                        int v;
+                        if (!HYBRID || C.in_lds) v = (int)((raw[j] >> (((odd >> j) & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
+                        else v = (int)raw[j];
+                        if (__any(v + 1 >= P.threshold)) hits |= 1u << j;
+                    }
                 }
             }
-            if (C.timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            H3_T(C, 1, tph);
-            unsigned hits = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (__any(old[j] + 1 >= P.threshold)) hits |= 1u << j;
             if (lane == 0) C.fix[(round & 1) * 4 + C.wave] = hits;
             __syncthreads();
             const unsigned Hm = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -2348,36 +2535,35 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
             H3_T(C, 2, tph);
             if (!Hm) {
                 am = rem;
-                gsz = min(16, gsz * 2);
+                gsz = min(H3_SUB, gsz * 2);
                 continue;
             }
             gsz = 4;
             const int trig = __builtin_ctz(Hm);
             // lane of the trigger point; the sub-group's points after it voted too early: take those votes back
             u64 walk = am;
-            int tl = 0, kt = 0;
+            int tl = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < H3_SUB; ++j) {
                 if (walk) {
                     const int l = __builtin_ctzll(walk);
                     walk &= walk - 1;
-                    if (j == trig) {
-                        tl = l;
-                        kt = old[j];
-                    } else if (j > trig && j < gused) {
-                        h3_unvote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l));
-                    }
+                    if (j == trig) tl = l;
+                    else if (j > trig && j < gused) h3_unvote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l));
                 }
             }
-            const unsigned key = ((unsigned)(kt + 1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.tid < 256 ? C.tid : 255));
+            const int tx = __builtin_amdgcn_readlane(px, tl), ty = __builtin_amdgcn_readlane(py, tl);
+            // the count the trigger point's vote produced in this thread's cell: earlier points' votes + its own, now that the
+            // later ones are gone (= the `val` of hough.cpp's scan over n)
+            const int kt1 = h3_cell_now<HYBRID>(C, tx, ty);
+            const unsigned key = ((unsigned)(kt1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.tid < 256 ? C.tid : 255));
             const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(C.vinc ? key : 0u, 0);
             if (lane == 0) C.fix[8 + C.wave] = wmax;
             __syncthreads();
             const unsigned best = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(C.fix[8], C.fix[9]), C.fix[10]));
-            const int tx = __builtin_amdgcn_readlane(px, tl), ty = __builtin_amdgcn_readlane(py, tl);
             H3_T(C, 3, tph);
-            h3_line<HYBRID>(C, tx, ty, 255 - (int)(best & 0xFF));  // ends with a barrier
-            if (C.timing) tph = clock64();
+            h3_line<HYBRID, TM>(C, tx, ty, 255 - (int)(best & 0xFF));  // ends with a barrier
+            if (TM) tph = clock64();
             // the rest of the step against the updated mask
             am = __ballot(kk < N && lane > tl && h3_bit<HYBRID>(C, px, py));
         }
@@ -2397,7 +2583,7 @@ __device__ __forceinline__ int h3_cell_value(const Hough3& C, int r) {
     const int c = r + C.cbase;
     return (int)((C.cells[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
 }
-template <bool HYBRID>
+template <bool HYBRID, bool TM>
 __device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, int w_size) {
     const HoughParams& P = C.P;
     const int lane = C.lane, tid = C.tid;
@@ -2498,17 +2684,17 @@ __device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, 
             continue;
         }
         const unsigned q = list[seed];
-        h3_line<HYBRID, true>(C, q & 0xFFFF, q >> 16, bn);  // walks, clears, takes the votes back (marks touched maxima dirty)
+        h3_line<HYBRID, TM, true>(C, q & 0xFFFF, q >> 16, bn);  // walks, clears, takes the votes back (marks touched maxima dirty)
         if (HYBRID) __threadfence();
         __syncthreads();
     }
 }
 
-template <bool HYBRID>
+template <bool HYBRID, bool TM>
 __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = P.litcount[i];
-    const long long w0 = P.dbg ? wall_clock64() : 0;
+    const long long w0 = TM && P.dbg ? wall_clock64() : 0;
     unsigned* fix = lds;
     unsigned* list = lds + HOUGH3_FIXED_DWORDS;
     const int Np = (N + 3) & ~3;  // keeps the un-vote list and the mask 16-byte aligned
@@ -2620,8 +2806,8 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     for (int p = tid; p < cell_dw; p += HOUGH3_THREADS) cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
     cells[cell_dw + tid] = 0;
     __syncthreads();
-    Hough3 C{P, tc, ts, tid < NUM_ANGLE ? 1u : 0u, 0, true, nullptr, cells, mask_lds, lmask, by0, rows, 2 * wlo, 2 * wpr, gmask, P.WW,
-             (int)rint(P.out_gap[i]), i, 0, lane, wave, tid, fix, uv, false, P.dbg_phase != nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
+    Hough3 C{P, tc, ts, tid < NUM_ANGLE ? 1u : 0u, 0, true, false, nullptr, cells, mask_lds, lmask, by0, rows, 2 * wlo, 2 * wpr, gmask, P.WW,
+             (int)rint(P.out_gap[i]), i, 0, lane, wave, tid, fix, uv, false, {0, 0, 0, 0, 0, 0, 0, 0}};
     if (tid < NUM_ANGLE) {
         C.in_lds = placed > 0;
         C.cbase = off - w_lo;
@@ -2629,13 +2815,82 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     } else {
         C.cbase = 2 * (cell_dw + tid);  // r is 0 for the spare lanes (tc = ts = 0): their private cell
     }
-    const long long w1 = P.dbg ? wall_clock64() : 0;
-    if (P.acc_mode) h3_accumulate<HYBRID>(C, N, list, w_lo, w_size);
-    else h3_replay<HYBRID>(C, N, list);
+    if (HYBRID && !P.acc_mode && !P.no_lds_acc) {
+        // Angles whose window went to the pooled global accumulator (the LARGEST windows: the directions across which the streak
+        // spreads its points thinly).  Every vote of the replay would wait for their returning global atomics (round 2: 40 % of a
+        // hybrid frame's time at the sub-group barriers).  But a cell never holds more votes than the number of points that map to
+        // it -- votes come from points only, un-votes only lower a count -- so ONE order-free sweep (non-returning atomics, all
+        // points) gives every cell's upper bound, and an angle whose largest cell stays below the threshold can never trigger,
+        // never be the arg-max of a trigger (that one holds >= threshold), and is dropped from the replay altogether: the frame
+        // then runs at LDS speed.  An angle that could trigger keeps the global path (exactness first).
+        // The sweep is shared by the whole workgroup (a handful of angles, thousands of points): the angles publish themselves
+        // through the 180 private dummy words of the real angles (never used otherwise), 45 at a time.
+        const bool mine = tid < NUM_ANGLE && !C.in_lds;
+        int n_out;
+        const int rank = h3_scan(mine ? 1 : 0, n_out, fix + 32, lane, wave);
+        unsigned* pub = cells + cell_dw;  // [45][4]: angle, w_lo, w_size, max
+        int* const acc_base = P.accum + (size_t)slot * NUM_ANGLE * P.numrho + P.half;
+        for (int r0 = 0; r0 < n_out; r0 += 45) {
+            const int cnt = min(45, n_out - r0);
+            if (mine && rank >= r0 && rank < r0 + cnt) {
+                unsigned* e = pub + 4 * (rank - r0);
+                e[0] = (unsigned)tid; e[1] = (unsigned)w_lo; e[2] = (unsigned)w_size; e[3] = 0;
+            }
+            __syncthreads();
+            for (int k = 0; k < cnt; ++k) {
+                const int a = (int)pub[4 * k];
+                const float ca = P.trig[2 * a], sa = P.trig[2 * a + 1];
+                int* row = acc_base + (size_t)a * P.numrho;
+                for (int p = tid; p < N; p += HOUGH3_THREADS) {
+                    const unsigned pt = list[p];
+                    atomicAdd(&row[__float2int_rn(__fadd_rn(__fmul_rn((float)(pt & 0xFFFF), ca), __fmul_rn((float)(pt >> 16), sa)))], 1);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // every thread's atomics have been performed at the L2
+            for (int k = 0; k < cnt; ++k) {
+                const int a = (int)pub[4 * k], lo = (int)pub[4 * k + 1], size = (int)pub[4 * k + 2];
+                const int* row = acc_base + (size_t)a * P.numrho;
+                int m = 0;
+                for (int r = tid; r < size; r += HOUGH3_THREADS) m = max(m, (int)ld_l2((const unsigned*)&row[lo + r]));
+                m = (int)__builtin_amdgcn_wave_reduce_max_u32((unsigned)m, 0);
+                if (lane == 0 && m) atomicMax(&pub[4 * k + 3], (unsigned)m);
+            }
+            __syncthreads();
+            if (mine && rank >= r0 && rank < r0 + cnt) C.dead = (int)pub[4 * (rank - r0) + 3] < P.threshold;
+            for (int k = 0; k < cnt; ++k) {  // back to all-zero: the replay (or the next frame in this slot) starts from there
+                const int a = (int)pub[4 * k];
+                const float ca = P.trig[2 * a], sa = P.trig[2 * a + 1];
+                int* row = acc_base + (size_t)a * P.numrho;
+                for (int p = tid; p < N; p += HOUGH3_THREADS) {
+                    const unsigned pt = list[p];
+                    row[__float2int_rn(__fadd_rn(__fmul_rn((float)(pt & 0xFFFF), ca), __fmul_rn((float)(pt >> 16), sa)))] = 0;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (n_out > 0) {
+            for (int k = tid; k < 180; k += HOUGH3_THREADS) pub[k] = 0;  // (the dummy words of the spare lanes, 180..191, were never touched)
+            __threadfence();
+            __syncthreads();
+        }
+    }
+    long long dbg_alive = 0, dbg_global = 0;  // (MDH_HOUGH_DEBUG) angles on the pooled global accumulator: still in the replay / all
+    if (TM && HYBRID) {  // (fix[26], fix[27]: spare words of the fixed block, zeroed at the frame's start)
+        if (tid < NUM_ANGLE && !C.in_lds) atomicAdd(&fix[26], 1u);
+        if (tid < NUM_ANGLE && !C.in_lds && !C.dead) atomicAdd(&fix[27], 1u);
+        __syncthreads();
+        dbg_global = fix[26];
+        dbg_alive = fix[27];
+    }
+    const long long w1 = TM && P.dbg ? wall_clock64() : 0;
+    if (P.acc_mode) h3_accumulate<HYBRID, TM>(C, N, list, w_lo, w_size);
+    else h3_replay<HYBRID, TM>(C, N, list);
     if (tid == 0) P.out_nraw[i] = C.found;
-    if (P.dbg && tid == 0) {  // MDH_HOUGH_DEBUG=1: points, tier, 100 MHz ticks (set-up, PPHT), segments, LDS cells
+    if (TM && P.dbg && tid == 0) {  // MDH_HOUGH_DEBUG=1: points, tier, 100 MHz ticks (set-up, PPHT), segments, LDS cells
         long long* d = P.dbg + (size_t)i * 8;
-        d[0] = N; d[1] = HYBRID ? 2 : (P.lds_bytes == P.lds_small ? 0 : 1); d[2] = w1 - w0; d[3] = wall_clock64() - w1; d[4] = C.found;
+        d[0] = N; d[1] = (HYBRID ? 2 : (P.lds_bytes == P.lds_small ? 0 : 1)) | (dbg_alive << 8) | (dbg_global << 16); d[2] = w1 - w0; d[3] = wall_clock64() - w1; d[4] = C.found;
         d[5] = total; d[6] = wall_clock64(); d[7] = w0;
         if (P.dbg_phase)
             for (int k = 0; k < 8; ++k) P.dbg_phase[(size_t)i * 8 + k] = C.ph[k];
@@ -2643,7 +2898,7 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     if (HYBRID) {
         // leave the pooled buffers all-zero: every accumulator cell ever touched belongs to some point of the list
         __syncthreads();
-        if (tid < NUM_ANGLE && !C.in_lds) {
+        if (tid < NUM_ANGLE && !C.in_lds && !C.dead) {
             for (int p = 0; p < N; ++p) {
                 const unsigned pt = list[p];
                 C.acc_row[__float2int_rn(__fadd_rn(__fmul_rn((float)(pt & 0xFFFF), tc), __fmul_rn((float)(pt >> 16), ts)))] = 0;
@@ -2662,22 +2917,24 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
 
 // tiers 0 / 1: a machine-sized grid walks the tier's frame list (a pass has thousands of frames and most of them carry no
 // streak: one workgroup per frame would be thousands of workgroups that leave at once, each waiting for its LDS first)
+template <bool TM>
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3(HoughParams P) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int count = *P.fcount;
     for (int j = blockIdx.x; j < count; j += gridDim.x) {
-        hough3_frame<false>(P, P.flist[j], 0, lds_dyn);
+        hough3_frame<false, TM>(P, P.flist[j], 0, lds_dyn);
         __syncthreads();
     }
 }
 // tier 2: gridDim.x workgroups walk the list, each with its own slot of the pooled accumulator / mask
+template <bool TM>
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_hybrid(HoughParams P) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int count = *P.fcount;
     for (int j = blockIdx.x; j < count; j += gridDim.x) {
-        hough3_frame<true>(P, P.flist[j], blockIdx.x, lds_dyn);
+        hough3_frame<true, TM>(P, P.flist[j], blockIdx.x, lds_dyn);
         __syncthreads();
     }
 }
@@ -2699,6 +2956,7 @@ struct SingleResult {  // the pass's result block in (pinned, device-visible) HO
     unsigned* blockcnt;
     unsigned n_blockcnt;
 };
+template <bool TM>
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, SingleResult R) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
@@ -2710,8 +2968,8 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, 
     __syncthreads();
     const int tier = (int)lds_dyn[0] - 1;
     __syncthreads();
-    if (tier == 0 || tier == 1) hough3_frame<false>(P, 0, 0, lds_dyn);
-    else if (tier == 2) hough3_frame<true>(P, 0, 0, lds_dyn);
+    if (tier == 0 || tier == 1) hough3_frame<false, TM>(P, 0, 0, lds_dyn);
+    else if (tier == 2) hough3_frame<true, TM>(P, 0, 0, lds_dyn);
     else if (tier == 3 && tid < 64) ppht_one_wave_frame(P, 0, 0, lds_dyn);
     __threadfence();
     __syncthreads();

@@ -185,6 +185,135 @@ int ocv_hough_lines_p(const uint8_t* img, int H, int W, int threshold, double mi
     return found;
 }
 
+/* ------------------------------------------------------------------ hough_mode = accumulator
+ * C port of oracle/hough_accumulator.py (the specification of MDH_HOUGH_ACCUMULATOR; NOT cv2.HoughLinesP): all lit pixels vote,
+ * then repeatedly the largest cell (smaller angle, then smaller rho among equals) while it holds >= threshold votes; seed = the
+ * middle one (row-major) of the lit pixels voting for it; OpenCV's walk / ends / good test; every lit pixel on the walk is
+ * cleared and un-voted whether or not the segment is good.  More than 8192 lit pixels: the exact progressive transform.
+ * Per-angle maxima are cached and rescanned only when an un-vote hit the cached cell (an optimisation with the same result:
+ * other cells of the row only shrink). */
+#define OACC_MAX_LIST 8192
+int oacc_hough_lines(const uint8_t* img, int H, int W, int threshold, double min_len, double max_gap, int32_t* lines, int cap) {
+    const int line_length = (int)lrint(min_len);
+    const int line_gap = (int)lrint(max_gap);
+    const float theta = (float)(3.14159265358979323846 / 180.0);
+    const int numrho = (W + H) * 2 + 1;
+    const int half = (numrho - 1) / 2;
+    const int shift = 16;
+    int N = 0;
+    for (size_t p = 0; p < (size_t)H * W; ++p) N += img[p] != 0;
+    if (N < threshold) return 0;
+    if (N > OACC_MAX_LIST) return ocv_hough_lines_p(img, H, W, threshold, min_len, max_gap, lines, cap);
+    float tcos[NUM_ANGLE], tsin[NUM_ANGLE];
+    for (int n = 0; n < NUM_ANGLE; ++n) {
+        tcos[n] = (float)(cos((double)n * theta) * 1.0f);
+        tsin[n] = (float)(sin((double)n * theta) * 1.0f);
+    }
+    int32_t* accum = (int32_t*)calloc((size_t)NUM_ANGLE * numrho, sizeof(int32_t));
+    uint8_t* mask = (uint8_t*)malloc((size_t)H * W);
+    int32_t* nz = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)N);
+    {
+        int k = 0;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                mask[(size_t)y * W + x] = img[(size_t)y * W + x] != 0;
+                if (mask[(size_t)y * W + x]) { nz[2 * k] = x; nz[2 * k + 1] = y; ++k; }
+            }
+    }
+    int lo[NUM_ANGLE], hi[NUM_ANGLE], best[NUM_ANGLE], best_r[NUM_ANGLE], dirty[NUM_ANGLE];
+    for (int n = 0; n < NUM_ANGLE; ++n) { lo[n] = numrho; hi[n] = -1; dirty[n] = 1; best[n] = -1; best_r[n] = 0; }
+    for (int k = 0; k < N; ++k)
+        for (int n = 0; n < NUM_ANGLE; ++n) {
+            int r = (int)lrintf((float)nz[2 * k] * tcos[n] + (float)nz[2 * k + 1] * tsin[n]) + half;
+            accum[(size_t)n * numrho + r]++;
+            if (r < lo[n]) lo[n] = r;
+            if (r > hi[n]) hi[n] = r;
+        }
+    int found = 0;
+    for (int iter = 0; iter <= N; ++iter) {
+        int top = -1, bn = 0;
+        for (int n = 0; n < NUM_ANGLE; ++n) {
+            if (dirty[n]) {
+                best[n] = -1;
+                best_r[n] = lo[n];
+                for (int r = lo[n]; r <= hi[n]; ++r)
+                    if (accum[(size_t)n * numrho + r] > best[n]) { best[n] = accum[(size_t)n * numrho + r]; best_r[n] = r; }
+                dirty[n] = 0;
+            }
+            if (best[n] > top) { top = best[n]; bn = n; }
+        }
+        if (top < threshold) break;
+        const int rho = best_r[bn];
+        int voters = 0;
+        for (int k = 0; k < N; ++k) {
+            int x = nz[2 * k], y = nz[2 * k + 1];
+            if (mask[(size_t)y * W + x] && (int)lrintf((float)x * tcos[bn] + (float)y * tsin[bn]) + half == rho) ++voters;
+        }
+        int want = voters / 2, j = 0, i = 0;
+        for (int k = 0; k < N; ++k) {
+            int x = nz[2 * k], y = nz[2 * k + 1];
+            if (mask[(size_t)y * W + x] && (int)lrintf((float)x * tcos[bn] + (float)y * tsin[bn]) + half == rho && want-- == 0) { j = x; i = y; break; }
+        }
+        float a = -tsin[bn], b = tcos[bn];
+        int x0 = j, y0 = i, dx0, dy0, xflag;
+        if (fabsf(a) > fabsf(b)) {
+            xflag = 1;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = (int)lrintf(b * (float)(1 << shift) / fabsf(a));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = 0;
+            dy0 = b > 0 ? 1 : -1;
+            dx0 = (int)lrintf(a * (float)(1 << shift) / fabsf(b));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        int end_x[2] = {0, 0}, end_y[2] = {0, 0};
+        for (int k = 0; k < 2; ++k) {
+            int gap = 0, x = x0, y = y0, dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            for (;; x += dx, y += dy) {
+                int j1 = xflag ? x : x >> shift, i1 = xflag ? y >> shift : y;
+                if (j1 < 0 || j1 >= W || i1 < 0 || i1 >= H) break;
+                if (mask[(size_t)i1 * W + j1]) {
+                    gap = 0;
+                    end_x[k] = j1;
+                    end_y[k] = i1;
+                } else if (++gap > line_gap)
+                    break;
+            }
+        }
+        int good = abs(end_x[1] - end_x[0]) >= line_length || abs(end_y[1] - end_y[0]) >= line_length;
+        for (int k = 0; k < 2; ++k) {
+            int x = x0, y = y0, dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            for (;; x += dx, y += dy) {
+                int j1 = xflag ? x : x >> shift, i1 = xflag ? y >> shift : y;
+                uint8_t* m = &mask[(size_t)i1 * W + j1];
+                if (*m) {
+                    for (int n = 0; n < NUM_ANGLE; ++n) {
+                        int r = (int)lrintf((float)j1 * tcos[n] + (float)i1 * tsin[n]) + half;
+                        accum[(size_t)n * numrho + r]--;
+                        if (r == best_r[n]) dirty[n] = 1;
+                    }
+                    *m = 0;
+                }
+                if (i1 == end_y[k] && j1 == end_x[k]) break;
+            }
+        }
+        if (good) {
+            if (found < cap) {
+                lines[4 * found + 0] = end_x[0];
+                lines[4 * found + 1] = end_y[0];
+                lines[4 * found + 2] = end_x[1];
+                lines[4 * found + 3] = end_y[1];
+            }
+            ++found;
+        }
+    }
+    free(nz);
+    free(mask);
+    free(accum);
+    return found;
+}
+
 /* ------------------------------------------------------------------ lineset_nms (utils.py:780-839) */
 /* Stable ascending order on squared length, reversed (later index first among ties). */
 int o_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, double* nonline) {

@@ -57,6 +57,65 @@ def rho_theta(x0, y0, x1, y1):
     return x0 * math.cos(th) + y0 * math.sin(th), th
 
 
+@pytest.mark.parametrize("mask_share", [1.0, 0.02])
+def test_accumulator_segments_equal_the_oracle_bit_for_bit(mask_share):
+    """The mode's specification is oracle/hough_accumulator.py (a function of the binary image); the HIP path must return the same
+    segments in the same order on the image families of tests/test_gpu_hough_planes.py -- fans, borders, noise, dense noise,
+    short segments, dashes around the gap limit, blobs, grids (> 500 segments), single pixels, 1-pixel-wide images, > 8192 lit
+    pixels (both modes replay cv2.HoughLinesP there) -- at both ends of the adaptive gap."""
+    from oracle import hough_accumulator as ha
+    from tests.test_gpu_hough_planes import CASES, family
+    cfg = binary_cfg()
+    rng = np.random.default_rng(23)
+    seen = dict(lines=0, over_list=0, over500=0, multi=0)
+    for kind, H, W in CASES:
+        imgs = [family(kind, H, W, rng) for _ in range(3)]
+        K = len(imgs)
+        WW = (W + 63) // 64
+        mask_area = max(1.0, H * W * mask_share)
+        ctx = hough_context(H, W, K, _lib.MDH_HOUGH_ACCUMULATOR, cfg, mask_area)
+        planes = np.stack([pack_rows(im, WW) for im in imgs])[None]
+        info, raw = ctx.hough_planes(planes, K, 1, H)[:2]
+        ctx.close()
+        for j, im in enumerate(imgs):
+            gap = ha.adaptive_gap(im, mask_area, cfg.hough_line.max_gap)
+            want = ha.c_hough_lines_acc(im, cfg.hough_line.threshold, cfg.hough_line.min_len, gap)
+            assert info[j]["hough_gap"] == gap
+            assert int(info[j]["n_raw"]) == len(want), (kind, H, W, j, int(info[j]["n_raw"]), len(want))
+            k = min(len(want), _lib.MDH_MAX_LINES)
+            assert np.array_equal(raw[j, :k], want[:k]), (kind, H, W, j)
+            lit = int(np.count_nonzero(im))
+            seen["lines"] += len(want)
+            seen["over_list"] += lit > ha.MAX_LIST
+            seen["over500"] += len(want) > 500
+            seen["multi"] += len(want) > 3
+    assert seen["lines"] > 100 and seen["over_list"] > 0 and seen["multi"] > 5, seen
+
+
+def test_accumulator_stream_equals_the_oracle():
+    """Detector + accumulator mode on a sky stream: every frame's raw segments equal the oracle's on the frame's own binary image
+    (fetched from the GPU), i.e. the mode is pinned inside the whole path too, not only behind mdh_hough_planes."""
+    from oracle import hough_accumulator as ha
+    H, W, n = 270, 480, 8
+    mask = np.ones((H, W), np.uint8)
+    frames = SkyStream(H, W, 777, speed=9, streak_period=30, streak_life=12).take(96)
+    cfg = binary_cfg("normal")
+    det = M3Detector(1, n, mask, 10, cfg, None, hough_mode="accumulator")
+    total = 0
+    for t in range(len(frames)):
+        det.update(frames[t])
+        det.detect()
+        dst = det.dst
+        gap = ha.adaptive_gap(dst, float(mask.sum()), cfg.hough_line.max_gap)
+        want = ha.c_hough_lines_acc(dst, cfg.hough_line.threshold, cfg.hough_line.min_len, gap)
+        assert det.lines_num == len(want), t
+        if 0 < len(want) <= 500:
+            assert np.array_equal(np.asarray(det.linesp_ext).reshape(-1, 4), want), t
+        total += len(want)
+    det.close()
+    assert total > 10
+
+
 def test_isolated_lines_against_ground_truth():
     H, W = 240, 320
     cfg = binary_cfg()

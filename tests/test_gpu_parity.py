@@ -229,6 +229,64 @@ def test_m3_dense_binaries_direct_mapped_morphology(shape):
     run_pair(frames, n, mask, cfg, batch=13, max_batch=13)
 
 
+@pytest.mark.parametrize("shape,n", [((70, 192), 4), ((40, 64 * 62), 8), ((33, 64 * 63), 5), ((50, 64 * 125), 16), ((9, 64), 2)])
+def test_m3_dense_output_format_forced(shape, n, monkeypatch):
+    """MDH_DENSE=1: every batched pass runs in the dense format (the window kernel writes every word of b plainly, the 64-bit
+    direct-mapped morphology kernel k_morph_close_plain reads it: 62 word columns + 2 halo lanes per wave, edge bits through DPP
+    wave shifts at every stage) -- noise frames, flat frames, streak frames; widths of one word, below / at / across the 62-column
+    wave boundary and across two of them; every window length class of the wide-load kernels."""
+    monkeypatch.setenv("MDH_DENSE", "1")
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=3, hough=(10, 10, 2))
+    noise = frames_normal(sum(shape) + n, 12, shape, 30, 2.5)
+    flat = [np.full(shape, 30, np.uint8)]
+    run_pair(noise[:5] + flat * 4 + noise[5:9] + flat * 3 + noise[9:], n, mask, cfg, batch=11, max_batch=11)
+    s = SkyStream(*shape, 77 + n, speed=5, streak_period=9, streak_life=6)
+    total = run_pair([s.next() for _ in range(3 * n + 30)], n, mask, binary_cfg("high"), batch=16, max_batch=16)
+    assert total > 0 or shape[0] < 20
+    # the forced format really ran (and the per-frame protocol stays sparse)
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    det.detect_batch(np.stack(noise[:8]))
+    assert det._ctx.dense_passes == 1
+    det.update(noise[0])
+    det.detect()
+    assert det._ctx.dense_passes == 1
+    det.close()
+
+
+def test_m3_output_format_flips_mid_stream():
+    """The format is chosen per pass from the share of words with set bits the last collected pass reported (enter above 3 %, leave
+    below 1.5 %): a stream that is quiet, then noisy (the threshold EMA is slow, so a jump of the noise level goes straight into
+    the binaries), then quiet again must flip to the dense format and back, with the oracle's results on every frame -- slots
+    that held a dense pass are reused by sparse ones and the other way round."""
+    shape, n = (72, 256), 4
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg("normal")
+    quiet1 = frames_normal(1, 40, shape, 30, 2.0)
+    noisy = frames_normal(2, 56, shape, 30, 9.0)
+    s = SkyStream(*shape, 3, speed=5, streak_period=9, streak_life=6)
+    quiet2 = [s.next() for _ in range(80)]
+    frames = np.stack(quiet1 + noisy + quiet2)
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
+    dense_seen, modes = 0, []
+    for t0 in range(0, len(frames), 8):
+        before = det._ctx.dense_passes
+        res, info = det.detect_batch(frames[t0:t0 + 8])
+        modes.append(det._ctx.dense_passes - before)
+        for i in range(len(info)):
+            orc.update(frames[t0 + i])
+            o_lines, o_pred = orc.detect()
+            assert int(info[i]["bi_threshold"]) == orc.bi_threshold and int(info[i]["lit_count"]) == orc.lit_count, t0 + i
+            assert int(info[i]["n_raw"]) == orc.lines_num, t0 + i
+            assert np.array_equal(np.asarray(res[i][0]).reshape(-1, 4), np.asarray(o_lines).reshape(-1, 4)), t0 + i
+        assert np.array_equal(det.dst, orc.dst), t0
+    det.close()
+    # sparse at the start, dense somewhere in the noisy stretch, sparse again at the end
+    assert modes[0] == 0 and modes[-1] == 0 and max(modes) == 1, modes
+    assert 2 <= sum(modes) < len(modes) - 4, modes
+
+
 def test_m3_edge_inputs():
     shape, n = (48, 80), 4
     mask = np.ones(shape, np.uint8)

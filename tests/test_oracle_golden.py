@@ -189,6 +189,50 @@ def test_kat_hough_rejects_short_and_sparse():
     assert len(out) == 1 and sorted((out[0][1], out[0][3])) == [5, 34]
 
 
+def test_kat_hough_accumulator_mode():
+    """hough_mode = accumulator (oracle/hough_accumulator.py: the mode's specification).  Hand-computable cases:
+    * a vertical run of 46 px: at angle 0 (cos = 1, sin = 0) all 46 points share the cell rho = x = 7, no smaller angle exists, the
+      seed is the middle point, the walk is exactly vertical (dy0 = +1 first: the lower end is end 0);
+    * a horizontal run y = 20, x = 10..29: angle 89 is the SMALLEST angle at which all 20 points share one cell
+      (x * cos 89 + 20 * sin 89 = 20.17 .. 20.50 -> 20, half to even; at 88 degrees the run spreads over two cells), so it wins
+      over angle 90; |a| > |b| there: dx0 = -1 first, dy0 = round(cos 89 / sin 89 * 65536) = 1144, i.e. 0.017 rows per step: the
+      walk stays on row 20 and ends on the run's end points;
+    * 9 points < threshold: nothing; two collinear 10-px runs with a 10-px hole: bridged at gap 10, two peaks at gap 9 (each run
+      alone spans 9 px)."""
+    from oracle import hough_accumulator as ha
+    for impl in (ha.hough_lines_acc, ha.c_hough_lines_acc):
+        assert impl(_draw(60, 40, [(7, 5, 7, 50)]), 10, 10, 0).tolist() == [[7, 50, 7, 5]]
+        assert impl(_draw(40, 60, [(10, 20, 29, 20)]), 10, 10, 0).tolist() == [[10, 20, 29, 20]]
+        assert len(impl(_draw(30, 30, [(5, 5, 13, 5)]), 10, 10, 0)) == 0
+        img = _draw(80, 40, [(9, 5, 9, 14), (9, 25, 9, 34)])
+        assert impl(img, 10, 25, 10).tolist() == [[9, 34, 9, 5]]
+        assert len(impl(img, 10, 25, 9)) == 0  # both halves are found (10 votes each) but neither is 25 px long
+        assert len(impl(img, 10, 10, 9)) == 0  # (a 10-px run spans 9)
+        # min length 9: the cell holds 20 votes, the middle voter is the first pixel of the lower run -> that run first
+        assert impl(img, 10, 9, 9).tolist() == [[9, 34, 9, 25], [9, 14, 9, 5]]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_hough_accumulator_numpy_vs_c(seed):
+    """The two statements of the accumulator mode agree, its result does not depend on anything but the image (run twice), every
+    segment's end points are lit pixels of the image, and the segments are at least min_len long on one axis."""
+    from oracle import hough_accumulator as ha
+    rng = np.random.default_rng(100 + seed)
+    h, w = int(rng.integers(40, 140)), int(rng.integers(40, 200))
+    segs = []
+    for _ in range(int(rng.integers(1, 7))):
+        segs.append((int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, h))))
+    img = _draw(h, w, [s for s in segs if max(abs(s[2] - s[0]), abs(s[3] - s[1])) > 0])
+    img |= (rng.random((h, w)) < (0.01 if seed % 2 else 0.06)).astype(np.uint8) * 255
+    for gap in (0, 2.5, 10):
+        a = ha.hough_lines_acc(img, 10, 10, gap)
+        b = ha.c_hough_lines_acc(img, 10, 10, gap)
+        assert np.array_equal(a, b) and np.array_equal(b, ha.c_hough_lines_acc(img.copy(), 10, 10, gap))
+        for x1, y1, x2, y2 in a:
+            assert img[y1, x1] and img[y2, x2] and max(abs(x2 - x1), abs(y2 - y1)) >= 10
+    assert len(a) > 0
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_hough_numpy_vs_c(seed):
     rng = np.random.default_rng(seed)

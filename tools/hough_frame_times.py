@@ -24,6 +24,8 @@ dbg2 = np.zeros((2, B, 8), np.int64)
 rc = ctx.L.mdh_debug_hough(C.c_void_p(ctx.handle), dbg2.ctypes.data_as(C.POINTER(C.c_longlong)), B)
 assert rc == 0
 dbg, ph = dbg2[0], dbg2[1]
+glob_alive, glob_all = (dbg[:, 1] >> 8) & 0xFF, (dbg[:, 1] >> 16) & 0xFF  # hybrid tier: angles on the pooled global accumulator
+dbg[:, 1] &= 0xFF
 act = dbg[:, 0] > 0
 t = dbg[:, 3] / 100.0  # us
 print("frames with points", int(act.sum()), "of", B, " tiers:", {int(k): int((dbg[act, 1] == k).sum()) for k in np.unique(dbg[act, 1])})
@@ -53,6 +55,9 @@ if cyc > 0:
     print("phase share of PPHT cycles:", {n: round(float(v) / cyc, 3) for n, v in zip(names[:7], tot[:7])}, " line events per frame: %.1f" % (tot[7] / act.sum()),
           " cycles per frame: %.0f" % (cyc / act.sum()), " cycles per line event (walk+clear+un-vote): %.0f" % (tot[4:7].sum() / max(tot[7], 1)))
 # the same split per tier (0 small LDS, 1 large LDS, 2 hybrid)
+print("hybrid frames: angles outside LDS  mean %.1f  of them still in the replay (could reach the threshold)  mean %.1f  max %d" % (
+    (glob_all[act & (dbg[:, 1] == 2)].mean() if (act & (dbg[:, 1] == 2)).any() else 0), (glob_alive[act & (dbg[:, 1] == 2)].mean() if (act & (dbg[:, 1] == 2)).any() else 0),
+    glob_alive[act].max() if act.any() else 0))
 for tier in np.unique(dbg[act, 1]):
     m = act & (dbg[:, 1] == tier)
     tt = ph[m].sum(axis=0)
