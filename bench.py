@@ -83,6 +83,8 @@ def parse():
                     "(experiments: C5's frame size at m3det_normal thresholds)")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight in the timed region (0 = as many as the library "
                     "allows; 1 = one at a time: nothing overlaps, the kernel spans are the kernels' own durations)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic leg (roofline.traffic): two short re-executions of this "
+                    "command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes) when rocprofv3 is on PATH")
     ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive "
                     "rate; never the headline value, see DESIGN.md)")
     return ap.parse_args()
@@ -358,7 +360,58 @@ def make_stream_frames(wl, rank, mask, B, unique):
     return stream.take(uniq)
 
 
-def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_step, workload):
+def pmc_traffic_live(a, dense):
+    """roofline.traffic measured IN THIS RUN: the same command re-executed for 4 passes (one at a time) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md's HBM section
+    prescribes -- and the dominant kernel's counter summed per dispatch, averaged over its launches.  FETCH_SIZE (KB) is doubled:
+    gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes (same section); WRITE_SIZE is taken as reported.
+    Returns (bytes per launch or None, source text)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    kern = "k_classic_diff" if DETECTOR == "classic" else "k_stack_threshold"
+    base = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--batch", str(a.batch), "--unique", str(a.unique),
+            "--steps", "3", "--warmup", "1", "--depth", "1", "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0",
+            "--no-profile", "--no-pmc", "--detector", a.detector, "--hough-mode", a.hough_mode]
+    if a.sensitivity:
+        base += ["--sensitivity", a.sensitivity]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if dense:
+        env["MDH_DENSE"] = "1"  # the timed run ended in the dense output format: measure that one (4 passes would not get there)
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--output-format", "csv", "--"] + base
+            try:
+                subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+            except Exception as e:  # noqa: BLE001
+                return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter} wrote no counter_collection.csv"
+            total, launches = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == counter and kern in row.get("Kernel_Name", ""):
+                    total += float(row["Counter_Value"])
+                    launches.add(row["Dispatch_Id"])
+            if not launches:
+                return None, f"no {kern} dispatch in the {counter} pass"
+            got[counter] = (total / len(launches), len(launches))
+    traffic = int(got["FETCH_SIZE"][0] * 1024 * 2 + got["WRITE_SIZE"][0] * 1024)
+    return traffic, (f"live: this command re-executed under rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, "
+                     f"{got['FETCH_SIZE'][1]} launches of {kern}* each, {a.batch} frames per launch); FETCH_SIZE KB x 1024 x 2 (gfx950 "
+                     f"tallies 128-byte requests at 64) + WRITE_SIZE KB x 1024: read {int(got['FETCH_SIZE'][0] * 2048)} B + written "
+                     f"{int(got['WRITE_SIZE'][0] * 1024)} B per launch")
+
+
+def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_step, workload, dense=False, live_traffic=None):
     """Physical roofline of the dominant pixel kernel (the window kernel; Classic: the difference kernel).  Bytes one launch
     MUST move: every frame of the pass once plus the n-1 frames of history its window starts from, per time chunk (the
     kernel is blocked over the frames: grid.y chunks each re-read n-1 frames).  What it stores (tagged words of the sparse
@@ -387,12 +440,16 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_step, workload):
     tc = -(-B // nchunks)
     nchunks = -(-B // tc)
     compulsory = frame * (B + nchunks * (n - 1))
+    if dense:
+        compulsory += words * 8 * B  # the dense output format writes every word of the thresholded difference (1 bit per pixel)
     avg_ms = ms / launches
     frac_of = lambda t_ms: compulsory / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out.update({
         "bytes_per_launch": compulsory, "frames_per_launch": B,
         "bytes_model": f"H*W*(frames + chunks*(n-1)) = {frame}*({B}+{nchunks}*{n - 1}): each frame byte once per launch plus the "
-                       "window history per time chunk; stores (sparse tagged words) not counted",
+                       "window history per time chunk"
+                       + (f"; + {words}*8*{B} bytes written: the run was in the DENSE output format (every word of the bit image stored)"
+                          if dense else "; stores (sparse tagged words) not counted"),
         "launch_ms_in_pipeline": avg_ms, "launches_in_pipeline": launches,
         "frac_in_pipeline_per_launch": frac_of(avg_ms),
         "launches_overlapping_in_pipeline": avg_ms / ms_per_step,
@@ -415,14 +472,20 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_step, workload):
                     "launch_ms_note": "mean span of the kernel's launches in the timed region (no stand-alone leg in this run)",
                     "algorithmic_frac": (n + 1) * frame * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     traffic, src = None, None
-    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
-    if os.path.exists(tpath):  # rocprofv3 PMC passes of this workload (tools/profile_round.sh), scaled to this batch
-        t = json.load(open(tpath))
-        if t.get("stack_threshold_bytes_per_launch"):
-            traffic = int(t["stack_threshold_bytes_per_launch"] * B / t.get("frames_per_launch", B))
-            src = (f"profiles/pmc_traffic_{workload}.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
-                   f"passes of this command at {t.get('frames_per_launch', B)} frames per launch (tools/profile_round.sh), scaled to "
-                   "this batch -- NOT measured in this run")
+    if live_traffic is not None and live_traffic[0] is not None:
+        traffic, src = live_traffic
+    else:
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+        if os.path.exists(tpath):  # rocprofv3 PMC passes of this workload (tools/profile_round.sh), scaled to this batch
+            t = json.load(open(tpath))
+            if t.get("stack_threshold_bytes_per_launch"):
+                traffic = int(t["stack_threshold_bytes_per_launch"] * B / t.get("frames_per_launch", B))
+                src = (f"profiles/pmc_traffic_{workload}.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
+                       f"passes of this command at {t.get('frames_per_launch', B)} frames per launch (tools/profile_round.sh), scaled to "
+                       "this batch -- NOT measured in this run"
+                       + (f" ({live_traffic[1]})" if live_traffic is not None else ""))
+    if traffic is not None:
+        out["traffic_over_compulsory"] = traffic / compulsory
     out["traffic"] = traffic
     out["traffic_source"] = src
     return out
@@ -506,7 +569,7 @@ def run_streams(a, D, wl, mask):
         ctx.profile_enable(False)
     dt_all, tot = D.max_time_and_sum(dt, [segs, kept, lit])
     res = dict(frames=steps * B * D.world, dt=dt_all, steps=steps, tot=tot, prof=prof, prof_alone=prof_alone, frames_sample=frames,
-               B=B, uniq=uniq)
+               B=B, uniq=uniq, dense=bool(DETECTOR == "m3" and ctx.dense_now))
     (ctx.host_free if a.host_input else ctx.device_free)(pool)
     det.close()
     return res
@@ -615,7 +678,12 @@ def main():
     out.update(extra)
     if D.rank == 0:
         if r["prof"]:
-            rf = roofline(r["prof"], r["prof_alone"], H, W, n, B, out["ms_per_step"], a.workload)
+            live = None
+            if (not a.no_pmc and D.world == 1 and a.mode == "streams" and a.protocol == "batch" and a.workload != "C1e"
+                    and not a.host_input):
+                live = pmc_traffic_live(a, bool(r.get("dense")))
+            rf = roofline(r["prof"], r["prof_alone"], H, W, n, B, out["ms_per_step"], a.workload, dense=bool(r.get("dense")),
+                          live_traffic=live)
             if rf:
                 out["roofline"] = rf
             out["kernels_ms_per_step"] = {k: v[0] / v[1] for k, v in r["prof"].items() if v[1]}  # mean span per timed pass

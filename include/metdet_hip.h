@@ -137,6 +137,7 @@ int mdh_max_in_flight(const mdh_ctx* ctx);
  * noise, e.g. 8K at m3det_high: chosen per pass from what the last collected pass reported (half of its frames dense -> dense format; below 1.5 % of the words set -> back);
  * results are identical either way).  MDH_DENSE=0|1 in the environment pins the format. */
 int64_t mdh_dense_passes(const mdh_ctx* ctx);   /* batched passes queued in the dense format so far */
+int mdh_dense_now(const mdh_ctx* ctx);          /* 1: the next batched pass will be queued in the dense format */
 double mdh_last_density(const mdh_ctx* ctx);    /* last collected pass: share of frames with a dense binary (sparse pass) or of words with set bits (dense pass) */
 
 /* The binary image `dst` (H*W u8 of {0,255}) of frame `index` of the most recent pass (0 .. frames_in_pass-1;
@@ -229,6 +230,38 @@ int mdh_hough_planes(mdh_ctx* ctx, const uint64_t* pieces, int K, int on_device,
  * mdh_collect_batch hands out the results of the oldest queued pass.  Pieces in device memory must stay untouched until the
  * pass after the next one is submitted or this one is collected (two exchange buffers used alternately are enough). */
 int mdh_hough_planes_submit(mdh_ctx* ctx, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows);
+
+/* The same three steps WITHOUT host round trips (round 3).  Every call below only queues work; the sums never leave the device:
+ *
+ *   mdh_band_submit(band, frames, K, on_device, &n_jobs)          stage + this band's share of the noise sums (device memory)
+ *   all-reduce IN PLACE of mdh_band_sums_device(band) [2 * n_jobs int64] on stream mdh_stream_handle(band, MDH_STREAM_NOISE):
+ *       ncclAllReduce(p, p, 2 * n_jobs, ncclInt64, ncclSum, comm, stream)   (RCCL, one band per GPU; metdetpy_amd/rccl.py)
+ *       mdh_bands_allreduce_local(bands, n)                                 (all bands in one process on one GPU)
+ *   mdh_band_pixels_submit(band, NULL, roi_px_total, ..., send_buffer)     thresholds, pixel stages, owned rows -> send layout
+ *   all-to-all of the send buffer on stream mdh_stream_handle(band, MDH_STREAM_POST_LAST):
+ *       ncclGroupStart(); ncclSend / ncclRecv per peer; ncclGroupEnd()     (RCCL)
+ *       mdh_chain(band_b, MDH_STREAM_POST_LAST, hough_r, MDH_STREAM_POST_NEXT) + mdh_device_copy_on(hough_r, MDH_STREAM_POST_NEXT, ...)
+ *   mdh_chain(band, MDH_STREAM_POST_LAST, hough, MDH_STREAM_POST_NEXT); mdh_hough_planes_submit(hough, recv_buffer, ...)
+ *   ... next pass ...
+ *   mdh_band_collect(band, info)  (thresholds of the oldest band pass)   +   mdh_collect_batch(hough, ...)  (its Hough results)
+ *
+ * Buffers handed to a queued pass (send / receive) must stay untouched until that pass has been collected. */
+#define MDH_STREAM_NOISE 0       /* staging + noise / threshold chain */
+#define MDH_STREAM_POST_LAST 1   /* post-window stages of the pass queued last (a band context's exported rows come out of it) */
+#define MDH_STREAM_POST_NEXT 2   /* post-window stages of the pass queued next (a Hough context assembles its planes on it) */
+#define MDH_MAX_LOCAL_BANDS 16
+void* mdh_stream_handle(mdh_ctx* ctx, int which);   /* hipStream_t, for collectives enqueued by the host (RCCL) */
+int mdh_band_submit(mdh_ctx* ctx, const uint8_t* frames, int K, int on_device, int* n_jobs);
+void* mdh_band_sums_device(mdh_ctx* ctx);           /* device int64 [2 * n_jobs] of the pass staged by mdh_band_submit */
+/* sums_total_device: NULL (the sums were all-reduced in place) or a device pointer to 2 * n_jobs int64.  dst_rows_device: as
+ * mdh_band_pixels' dst_rows with out_on_device = 1. */
+int mdh_band_pixels_submit(mdh_ctx* ctx, const int64_t* sums_total_device, double roi_px_total, int own_row0, int own_rows,
+                           int rows_stride, int nsplit, uint64_t* dst_rows_device);
+int mdh_band_collect(mdh_ctx* ctx, mdh_frame_info* info);   /* waits for the oldest queued band pass; returns its frame count */
+/* everything queued on producer's stream so far precedes whatever is queued on consumer's stream from now on (same process) */
+int mdh_chain(mdh_ctx* producer, int producer_stream, mdh_ctx* consumer, int consumer_stream);
+int mdh_device_copy_on(mdh_ctx* ctx, int which_stream, void* dst_device, const void* src_device, uint64_t bytes);  /* queued */
+int mdh_bands_allreduce_local(mdh_ctx** bands, int n);      /* n band contexts of one process and device, passes staged */
 
 /* ---- One stream cut into time windows across GPUs (SURVEY 8e "time windows of one stream") --------------------------
  *

@@ -20,6 +20,8 @@ MDH_HOUGH_EXACT, MDH_HOUGH_ACCUMULATOR = 0, 1
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 MDH_ROLE_FULL, MDH_ROLE_BAND, MDH_ROLE_HOUGH = 0, 1, 2
 MDH_BAND_HALO = 4
+MDH_STREAM_NOISE, MDH_STREAM_POST_LAST, MDH_STREAM_POST_NEXT = 0, 1, 2
+MDH_MAX_LOCAL_BANDS = 16
 SENSITIVITY_ID = {"low": 0, "normal": 1, "high": 2}
 
 
@@ -74,7 +76,9 @@ EXPORTS = [
     "mdh_band_noise", "mdh_band_pixels", "mdh_hough_planes", "mdh_band_skip", "mdh_seek", "mdh_frame_sums",
     "mdh_inject_sums", "mdh_mute_hough_until", "mdh_hough_planes_submit",
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
-    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint", "mdh_dense_passes", "mdh_last_density"
+    "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint", "mdh_dense_passes", "mdh_last_density", "mdh_dense_now",
+    "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
+    "mdh_device_copy_on", "mdh_bands_allreduce_local"
 ]
 
 _lib = None
@@ -151,6 +155,17 @@ def load():
     L.mdh_mute_hough_until.argtypes = [vp, i64]
     L.mdh_dense_passes.argtypes = [vp]
     L.mdh_dense_passes.restype = i64
+    L.mdh_dense_now.argtypes = [vp]
+    L.mdh_stream_handle.argtypes = [vp, i32]
+    L.mdh_stream_handle.restype = vp
+    L.mdh_band_submit.argtypes = [vp, vp, i32, i32, C.POINTER(i32)]
+    L.mdh_band_sums_device.argtypes = [vp]
+    L.mdh_band_sums_device.restype = vp
+    L.mdh_band_pixels_submit.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp]
+    L.mdh_band_collect.argtypes = [vp, vp]
+    L.mdh_chain.argtypes = [vp, i32, vp, i32]
+    L.mdh_device_copy_on.argtypes = [vp, i32, vp, vp, u64]
+    L.mdh_bands_allreduce_local.argtypes = [C.POINTER(vp), i32]
     L.mdh_last_density.argtypes = [vp]
     L.mdh_last_density.restype = dbl
     if not hasattr(L, "mdh_abi_version") or L.mdh_abi_version() != MDH_ABI_VERSION:
@@ -158,6 +173,13 @@ def load():
                              "(`make -C metdetpy_amd/csrc -B`)")
     _lib = L
     return L
+
+
+def bands_allreduce_local(contexts):
+    """Sum of the staged passes' noise sums over band contexts of ONE process and device, on the device (no host wait)."""
+    L = load()
+    arr = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+    check(L.mdh_bands_allreduce_local(arr, len(contexts)), "mdh_bands_allreduce_local")
 
 
 def last_error() -> str:
@@ -363,6 +385,49 @@ class Context:
                                      int(host is None), info.ctypes.data), "mdh_band_pixels")
         return host, info
 
+    # ---- the same steps without host round trips (include/metdet_hip.h): everything is queued, the sums stay on the device ----
+    def band_submit(self, frames, K=None, on_device=False) -> int:
+        """Stage K sub-image frames and queue this band's share of the noise sums; returns the number of due frames."""
+        if on_device:
+            ptr = int(frames)
+            assert K is not None
+        else:
+            if frames.ndim != 3 or frames.shape[1:] != (self.H, self.W) or frames.dtype != np.uint8:
+                raise ValueError(f"frames must be uint8 (K,{self.H},{self.W})")
+            frames = np.ascontiguousarray(frames)
+            K, ptr = len(frames), frames.ctypes.data
+        nj = C.c_int(0)
+        check(self.L.mdh_band_submit(self.handle, ptr, int(K), int(bool(on_device)), C.byref(nj)), "mdh_band_submit")
+        self._band_K = int(K)
+        return nj.value
+
+    @property
+    def band_sums_device(self) -> int:
+        return int(self.L.mdh_band_sums_device(self.handle) or 0)
+
+    def stream_handle(self, which: int) -> int:
+        """hipStream_t (as an integer) of one of the context's streams: MDH_STREAM_*; for collectives the host enqueues (RCCL)."""
+        return int(self.L.mdh_stream_handle(self.handle, int(which)) or 0)
+
+    def band_pixels_submit(self, roi_px_total, own_row0, own_rows, rows_stride, nsplit, out: int, sums_total_device: int = 0):
+        check(self.L.mdh_band_pixels_submit(self.handle, int(sums_total_device) or None, float(roi_px_total), int(own_row0), int(own_rows),
+                                            int(rows_stride), int(nsplit), int(out)), "mdh_band_pixels_submit")
+
+    def band_collect(self):
+        """Thresholds (bi_threshold, bi_threshold_float, snr, sigma) of the oldest queued band pass."""
+        info = np.zeros(self.max_batch, FRAME_INFO_DTYPE)
+        K = self.L.mdh_band_collect(self.handle, info.ctypes.data)
+        if K < 0:
+            check(K, "mdh_band_collect")
+        return info[:K]
+
+    def chain_to(self, my_stream: int, consumer: "Context", consumer_stream: int):
+        """Everything queued on my stream so far precedes what is queued on the consumer's stream from now on."""
+        check(self.L.mdh_chain(self.handle, int(my_stream), consumer.handle, int(consumer_stream)), "mdh_chain")
+
+    def device_copy_on(self, which: int, dst: int, src: int, nbytes: int):
+        check(self.L.mdh_device_copy_on(self.handle, int(which), int(dst), int(src), int(nbytes)), "mdh_device_copy_on")
+
     def band_skip(self):
         """Drop the pass staged by band_noise (its frames stay in the window)."""
         check(self.L.mdh_band_skip(self.handle), "mdh_band_skip")
@@ -423,6 +488,10 @@ class Context:
     def dense_passes(self) -> int:
         """Batched passes queued in the dense output format of the window kernel so far (diagnostics; results do not depend on it)."""
         return self.L.mdh_dense_passes(self.handle)
+
+    @property
+    def dense_now(self) -> bool:
+        return self.L.mdh_dense_now(self.handle) == 1
 
     @property
     def last_density(self) -> float:

@@ -108,6 +108,18 @@ class HipBandEngine:
     def hough_collect(self, kp):
         return self.hough.hough_planes_collect(kp)
 
+    # ---- queued forms: nothing below waits for the GPU (include/metdet_hip.h, "WITHOUT host round trips") ----
+    def noise_submit(self, sub_frames, K=None, on_device=False) -> int:
+        return self.band.band_submit(sub_frames, K=K, on_device=on_device)
+
+    def pixels_submit(self, out: int):
+        d = self.plan.bands[self.b]
+        self.band.band_pixels_submit(self.plan.roi_px, d["own0"] - d["sub0"], d["own1"] - d["own0"], self.plan.band_rows,
+                                     self.plan.nbands, out)
+
+    def thresholds_collect(self):
+        return self.band.band_collect()
+
     def skip(self):
         self.band.band_skip()
 
@@ -199,28 +211,30 @@ class LocalBands:
 
     def collect(self):
         """Results of the oldest pass queued with submit_device."""
-        K, kp, thr = self._queued.pop(0)
+        K, kp = self._queued.pop(0)
         p = self.s.plan
         N = p.nbands
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
         results = [None] * K
-        staged = self._each(lambda r, e: e.hough_collect(kp) if len(range(r, K, N)) else None)
+        thr = [e.thresholds_collect() for e in self.engines][0]  # every band frees its slot; the scalars are the same everywhere
         for r, e in enumerate(self.engines):
             mine = len(range(r, K, N))
             if mine == 0:
                 continue
-            hi, raw, nms, prob = staged[r]
+            hi, raw, nms, prob = e.hough_collect(kp)
             for j in range(mine):
                 i = j * N + r
-                info[i] = _merge_info(thr[0][i], hi[j])
+                info[i] = _merge_info(thr[i], hi[j])
                 results[i] = _package(self.s.num_cls, hi[j], raw[j], nms[j], prob[j])
         return results, info
 
     def submit_device(self, sub_ptrs, K: int):
         """Queue a pass (at most two in flight: the exchange buffers alternate); collect() returns the oldest one's results, so
-        that the Hough replay of pass p runs under the band stages of pass p + 1.  Everything resident in HBM: sub_ptrs[b] = device pointer of band b's rows of the K frames
-        ((K, rows_b, W) u8, as `plan.crop` cuts them).  The bit planes go band -> exchange buffer -> Hough context through
-        device-to-device copies (what the all-to-all moves over xGMI when every band has a GPU of its own)."""
+        that the Hough replay of pass p runs under the band stages of pass p + 1.  Everything resident in HBM: sub_ptrs[b] = device
+        pointer of band b's rows of the K frames ((K, rows_b, W) u8, as `plan.crop` cuts them).  NOTHING here waits for the GPU
+        (round 3): the noise sums are added up on the device (mdh_bands_allreduce_local: what ncclAllReduce does across GPUs), the
+        bit planes go band -> send buffer -> receive buffer of the frame's Hough context through queued device-to-device copies
+        ordered by events (what the all-to-all moves over xGMI), and the Hough stage is queued behind them."""
         p = self.s.plan
         N = p.nbands
         kp = -(-K // N)
@@ -234,25 +248,28 @@ class LocalBands:
             self._free_xchg()
             piece = kp * p.band_rows * p.WW * 8
             ctx = self.engines[0].band
-            self._send = [ctx.device_alloc(N * piece) for _ in range(N)]
+            self._send = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
             self._recv = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
             self._xchg_kp = kp
-        recv = self._recv[self._seq % 2]
-        parts = self._each(lambda b, e: e.noise(sub_ptrs[b], K=K, on_device=True))
-        total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]
-        thr = self._each(lambda b, e: e.pixels(total, out=self._send[b])[1])
+        send, recv = self._send[self._seq % 2], self._recv[self._seq % 2]
+        for b, e in enumerate(self.engines):
+            e.noise_submit(sub_ptrs[b], K=K, on_device=True)
+        _lib.bands_allreduce_local([e.band for e in self.engines])
+        for b, e in enumerate(self.engines):
+            e.pixels_submit(send[b])
         live = kp * p.band_rows * p.WW * 8
-
-        def receive(r, e):  # "all-to-all": rank r pulls slice r of every band's send buffer
-            for b in range(N):
-                e.band.device_copy(recv[r] + b * live, self._send[b] + r * live, live)
-        self._each(receive)
-        self._each(lambda r, e: e.hough_submit(recv[r], kp, on_device=True) if len(range(r, K, N)) else None)
-        self._queued.append((K, kp, thr))
+        for r, e in enumerate(self.engines):  # "all-to-all": rank r pulls slice r of every band's send buffer
+            if not len(range(r, K, N)):
+                continue
+            for b, eb in enumerate(self.engines):
+                eb.band.chain_to(_lib.MDH_STREAM_POST_LAST, e.hough, _lib.MDH_STREAM_POST_NEXT)
+                e.hough.device_copy_on(_lib.MDH_STREAM_POST_NEXT, recv[r] + b * live, send[b] + r * live, live)
+            e.hough_submit(recv[r], kp, on_device=True)
+        self._queued.append((K, kp))
         self._seq += 1
 
     def _free_xchg(self):
-        for ptr in getattr(self, "_send", []) + [q for set_ in getattr(self, "_recv", []) for q in set_]:
+        for ptr in [q for set_ in getattr(self, "_send", []) + getattr(self, "_recv", []) for q in set_]:
             self.engines[0].band.device_free(ptr)
         self._send, self._recv, self._xchg_kp = [], [], 0
 
@@ -273,7 +290,11 @@ class BandedM3Detector:
     on rank 0 what `M3Detector.detect_batch` returns for the whole frames; other ranks get (None, info)."""
 
     def __init__(self, window_sec, fps, mask, num_cls, cfg, logger=None, *, rank: int, world: int, dist=None, device: int = 0,
-                 max_batch: int = 64, engine=HipBandEngine):
+                 max_batch: int = 64, engine=HipBandEngine, comm=None):
+        """comm: an `rccl.Communicator` of this rank (one rank per GPU).  With it -- or with an "nccl" process group, from which
+        one is made -- the data-path collectives are RCCL calls enqueued on the detector library's own streams and a pass is
+        queued without a host round trip; `dist` then only carries the unique id and the final gather of the results (control
+        plane).  Without it (gloo, the CPU tests) the blocking steps and host buffers of round 2 are used."""
         self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, world)
         self.rank, self.world, self.dist = int(rank), int(world), dist
         if world > 1 and dist is None:
@@ -282,8 +303,40 @@ class BandedM3Detector:
         self.engine = engine(self.plan, self.rank, self.s.n, cfg, self.s.mask_area, max_batch, device)
         self.max_batch = int(max_batch)
         self._on_gpu = dist is not None and dist.get_backend() == "nccl"
+        self.comm = comm
+        if self.comm is None and self._on_gpu and engine is HipBandEngine:
+            from . import rccl
+            self.comm = rccl.Communicator.from_torch_dist(dist, self.rank, self.world)  # after the engine: its device is current
         self._send = self._recv = None
+        self._xbuf = None
         self._pending, self._seq = [], 0
+
+    def _device_exchange_buffers(self):
+        """Two send and two receive buffers in HBM, (world, kp_max, band_rows, WW) u64 each, used alternately."""
+        if self._xbuf is None:
+            p = self.plan
+            nbytes = self.world * (-(-self.max_batch // self.world)) * p.band_rows * p.WW * 8
+            ctx = self.engine.band
+            self._xbuf = [[ctx.device_alloc(nbytes) for _ in range(2)] for _ in range(2)]
+        return self._xbuf[0][self._seq % 2], self._xbuf[1][self._seq % 2]
+
+    def _submit_queued(self, sub_frames, K, on_device):
+        """RCCL on the library's streams: noise sums all-reduced in place on the noise stream, bit planes exchanged on the post
+        stream, the Hough stage chained behind the exchange.  Nothing waits for the GPU."""
+        p, N, r = self.plan, self.world, self.rank
+        band, hough = self.engine.band, self.engine.hough
+        kp = -(-K // N)
+        nj = self.engine.noise_submit(sub_frames, K=K, on_device=on_device)
+        self.comm.all_reduce_sum_i64(band.band_sums_device, 2 * nj, band.stream_handle(_lib.MDH_STREAM_NOISE))
+        send, recv = self._device_exchange_buffers()
+        self.engine.pixels_submit(send)
+        self.comm.all_to_all_u64(send, recv, kp * p.band_rows * p.WW, band.stream_handle(_lib.MDH_STREAM_POST_LAST))
+        mine = len(range(r, K, N))
+        if mine:
+            band.chain_to(_lib.MDH_STREAM_POST_LAST, hough, _lib.MDH_STREAM_POST_NEXT)
+            self.engine.hough_submit(recv, kp, on_device=True)
+        self._pending.append((K, kp, mine, None, None, None))
+        self._seq += 1
 
     # ---- collectives ---------------------------------------------------------------------------
     def _allreduce_sums(self, sums: np.ndarray) -> np.ndarray:
@@ -321,6 +374,8 @@ class BandedM3Detector:
             raise ValueError("K exceeds max_batch")
         if len(self._pending) >= 2:
             raise RuntimeError("two passes are already queued: collect() one first")
+        if self.comm is not None:
+            return self._submit_queued(sub_frames, K, on_device)
         kp = -(-K // N)
         part = self.engine.noise(sub_frames, K=K, on_device=True) if on_device else self.engine.noise(sub_frames)
         total = self._allreduce_sums(part)
@@ -355,6 +410,8 @@ class BandedM3Detector:
         get (None, info)."""
         N, r = self.world, self.rank
         K, kp, mine, thr_info, done, _keep = self._pending.pop(0)
+        if thr_info is None:  # queued pass: its thresholds are fetched now (this also frees the band context's slot)
+            thr_info = self.engine.thresholds_collect()
         part = []
         if mine:
             hi, raw, nms, prob = done if done is not None else self.engine.hough_collect(kp)
@@ -382,4 +439,11 @@ class BandedM3Detector:
         return self.collect()
 
     def close(self):
+        if self._xbuf is not None:
+            for ptr in [q for pair in self._xbuf for q in pair]:
+                self.engine.band.device_free(ptr)
+            self._xbuf = None
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
         self.engine.close()

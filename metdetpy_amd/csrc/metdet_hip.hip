@@ -209,6 +209,8 @@ struct mdh_ctx {
     // A pass mutates host-side stream state (EMA schedule, history, ring positions) while it is being queued; if a HIP call
     // fails half-way the context no longer describes the stream, so it refuses further work instead of producing silently
     // wrong thresholds / windows.
+    std::vector<hipEvent_t> chain_ev;  // mdh_chain: a ring of events
+    size_t chain_next = 0;
     bool poisoned = false;
     // Format of b = (diff > T) between the window kernel and the morphology: sparse + tagged (a quiet sky: nothing is written for
     // 99 % of the wave-frames) or dense + plain (binaries with noise in them: 8K at m3det_high).  Chosen per pass from the share
@@ -255,6 +257,7 @@ extern "C" int mdh_in_flight(const mdh_ctx* c) { return c ? c->in_flight : -1; }
 extern "C" int mdh_max_in_flight(const mdh_ctx* c) { return c ? c->nslot : -1; }
 extern "C" int64_t mdh_dense_passes(const mdh_ctx* c) { return c ? c->dense_passes : -1; }
 extern "C" double mdh_last_density(const mdh_ctx* c) { return c ? c->last_density : -1; }
+extern "C" int mdh_dense_now(const mdh_ctx* c) { return c ? (c->dense_now ? 1 : 0) : -1; }
 
 template <typename T>
 static int dev_alloc(T*& p, size_t count, bool zero = true) {
@@ -316,6 +319,8 @@ static void free_all(mdh_ctx* c) {
         }
     }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : c->chain_ev)
+        if (e) hipEventDestroy(e);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
     for (HoughSet& h : c->hset) {
         void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work, h.d_tier_list, h.d_tier_count};
@@ -1701,6 +1706,168 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     c->last_slot = c->oldest;
     c->oldest = (c->oldest + 1) % c->nslot;
     c->in_flight -= 1;
+    return MDH_OK;
+}
+
+// ---- the same three steps without a host round trip (round 3): everything is QUEUED; the noise sums stay in device memory, the
+// all-reduce and the all-to-all are enqueued by the host on this context's own streams (RCCL through mdh_stream_handle, or the
+// single-process stand-ins below), and only mdh_band_collect / mdh_collect_batch wait.
+static hipStream_t pick_stream(mdh_ctx* c, int which) {
+    switch (which) {
+        case MDH_STREAM_NOISE: return c->nstream;
+        case MDH_STREAM_POST_LAST: return c->pstream[(c->pass_seq + 1) & 1];  // (pass_seq - 1) & 1
+        case MDH_STREAM_POST_NEXT: return c->pstream[c->pass_seq & 1];
+        default: return nullptr;
+    }
+}
+extern "C" void* mdh_stream_handle(mdh_ctx* c, int which) { return c ? (void*)pick_stream(c, which) : nullptr; }
+
+extern "C" int mdh_band_submit(mdh_ctx* c, const uint8_t* frames, int K, int on_device, int* n_jobs) {
+    if (!c || !frames || !n_jobs) { set_err("mdh_band_submit: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_submit: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (c->band_slot) { set_err("mdh_band_submit: the previous pass still waits for its pixel stages"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_band_submit");
+    HIPCHK(hipSetDevice(c->device));
+    Slot* sl = nullptr;
+    int rc, nj = 0;
+    if ((rc = slot_begin(c, K, sl)) != MDH_OK) return rc;
+    if ((rc = stage_frames(c, *sl, frames, K, on_device)) != MDH_OK) return poison(c, rc);
+    if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return poison(c, rc);
+    if ((rc = noise_prepare(c, *sl, K, &nj)) != MDH_OK) return poison(c, rc);
+    c->band_slot = sl;
+    c->band_nj = nj;
+    *n_jobs = nj;
+    return MDH_OK;
+}
+extern "C" void* mdh_band_sums_device(mdh_ctx* c) { return (c && c->band_slot) ? (void*)c->band_slot->d_sums : nullptr; }
+
+extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total, int own_row0, int own_rows,
+                                      int rows_stride, int nsplit, uint64_t* dst_rows_device) {
+    if (!c || !dst_rows_device) { set_err("mdh_band_pixels_submit: null argument"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_pixels_submit: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (!c->band_slot) { set_err("mdh_band_pixels_submit: call mdh_band_submit first"); return MDH_E_STATE; }
+    if (own_row0 < 0 || own_rows < 1 || own_row0 + own_rows > c->H || rows_stride < own_rows || nsplit < 1 || !(roi_px_total > 0)) {
+        set_err("mdh_band_pixels_submit: bad owned rows / stride / split / roi_px_total");
+        return MDH_E_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    Slot& sl = *c->band_slot;
+    const int K = sl.K, nj = c->band_nj;
+    int rc;
+    // the global sums: already in place (in-place all-reduce on the noise stream), or somewhere else in device memory
+    if (nj && d_sums_total && (const void*)d_sums_total != (const void*)c->d_sums)
+        HIPCHK(hipMemcpyAsync(c->d_sums, d_sums_total, sizeof(long long) * 2 * nj, hipMemcpyDeviceToDevice, c->nstream));
+    if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return poison(c, rc);
+    HoughSet& hs = c->hset[c->pass_seq % c->nhset];
+    hipStream_t post = c->pstream[c->pass_seq & 1];
+    if ((rc = run_pixels(c, sl, K)) != MDH_OK) return poison(c, rc);
+    const int Kp = (K + nsplit - 1) / nsplit;
+    const size_t out_words = (size_t)nsplit * Kp * rows_stride * c->WW;
+    u64* dev_out = (u64*)dst_rows_device;
+    HIPCHK(hipMemsetAsync(dev_out, 0, out_words * sizeof(u64), post));
+    hipLaunchKernelGGL(k_export_rows, dim3((own_rows * c->WW + 255) / 256, K), dim3(256), 0, post, sl.d_dst, dev_out, K, c->H, c->WW,
+                       own_row0, own_rows, rows_stride, nsplit, Kp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sl.h_fscal, sl.d_fscal, sizeof(FrameScalars) * K, hipMemcpyDeviceToHost, post));
+    HIPCHK(hipMemcpyAsync(sl.h_off + K + 1, sl.dense ? (const void*)(sl.d_nzcount + 2) : (const void*)sl.d_dense, 2 * sizeof(unsigned),
+                          hipMemcpyDeviceToHost, post));  // the format cue (see k_pack_lines)
+    HIPCHK(hipEventRecord(sl.ev_done, post));
+    const int si = (int)(&sl - c->slot);
+    hs.last_slot = si;
+    c->prev_slot = si;
+    c->pass_seq += 1;
+    slot_commit(c, sl);
+    c->band_slot = nullptr;
+    return MDH_OK;
+}
+
+extern "C" int mdh_band_collect(mdh_ctx* c, mdh_frame_info* info) {
+    if (!c) { set_err("mdh_band_collect: null context"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_collect: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (c->in_flight <= 0) { set_err("mdh_band_collect: no pass in flight"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    Slot& sl = c->slot[c->oldest];
+    const int K = sl.K;
+    HIPCHK(hipEventSynchronize(sl.ev_done));
+    spans_collect(c, sl);
+    format_cue(c, sl);
+    if (info) {
+        for (int i = 0; i < K; ++i) {
+            mdh_frame_info& o = info[i];
+            memset(&o, 0, sizeof(o));
+            o.bi_threshold = sl.h_fscal[i].thr;
+            o.bi_threshold_float = sl.h_fscal[i].thr_f;
+            o.snr = sl.h_fscal[i].snr;
+            o.sigma = sl.h_fscal[i].sigma;
+        }
+    }
+    sl.busy = false;
+    c->last_slot = c->oldest;
+    c->oldest = (c->oldest + 1) % c->nslot;
+    c->in_flight -= 1;
+    return K;
+}
+
+// Stream-to-stream ordering between two contexts of one process (a band context's exported rows -> the Hough context that
+// assembles them; an exchange enqueued on one stream -> its consumer on another): everything queued on `producer`'s stream so
+// far precedes whatever is queued on `consumer`'s stream from now on.  No host wait.
+extern "C" int mdh_chain(mdh_ctx* producer, int pwhich, mdh_ctx* consumer, int cwhich) {
+    if (!producer || !consumer) { set_err("mdh_chain: null context"); return MDH_E_ARG; }
+    hipStream_t ps = pick_stream(producer, pwhich), cs = pick_stream(consumer, cwhich);
+    if (!ps || !cs) { set_err("mdh_chain: unknown stream designator"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(consumer->device));
+    if (consumer->chain_ev.empty()) {
+        consumer->chain_ev.resize(64, nullptr);
+        for (auto& e : consumer->chain_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipEvent_t ev = consumer->chain_ev[consumer->chain_next++ % consumer->chain_ev.size()];
+    HIPCHK(hipEventRecord(ev, ps));
+    HIPCHK(hipStreamWaitEvent(cs, ev, 0));
+    return MDH_OK;
+}
+
+extern "C" int mdh_device_copy_on(mdh_ctx* c, int which, void* dst, const void* src, uint64_t bytes) {
+    if (!c || !dst || !src) { set_err("mdh_device_copy_on: null argument"); return MDH_E_ARG; }
+    hipStream_t st = pick_stream(c, which);
+    if (!st) { set_err("mdh_device_copy_on: unknown stream designator"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    return MDH_OK;
+}
+
+// Single-process stand-in of the noise all-reduce: the staged passes of `n` band contexts on ONE device get the sum of their
+// sums, on the device, ordered by events between the contexts' noise streams (what ncclAllReduce does across GPUs).
+struct SumPtrs { long long* p[MDH_MAX_LOCAL_BANDS]; };
+__global__ void k_sum_bands(SumPtrs ptrs, int n, int count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    long long t = 0;
+    for (int i = 0; i < n; ++i) t += ptrs.p[i][j];
+    for (int i = 0; i < n; ++i) ptrs.p[i][j] = t;
+}
+extern "C" int mdh_bands_allreduce_local(mdh_ctx** bands, int n) {
+    if (!bands || n < 1 || n > MDH_MAX_LOCAL_BANDS) { set_err("mdh_bands_allreduce_local: 1..MDH_MAX_LOCAL_BANDS contexts"); return MDH_E_ARG; }
+    SumPtrs ptrs{};
+    for (int i = 0; i < n; ++i) {
+        mdh_ctx* c = bands[i];
+        if (!c || c->role != MDH_ROLE_BAND || !c->band_slot || c->device != bands[0]->device || c->band_nj != bands[0]->band_nj) {
+            set_err("mdh_bands_allreduce_local: every context must be a band context of one device with a staged pass of the same frames");
+            return MDH_E_STATE;
+        }
+        ptrs.p[i] = c->band_slot->d_sums;
+    }
+    const int count = 2 * bands[0]->band_nj;
+    if (count == 0 || n == 1) return MDH_OK;
+    HIPCHK(hipSetDevice(bands[0]->device));
+    hipStream_t s0 = bands[0]->nstream;
+    for (int i = 1; i < n; ++i) {
+        HIPCHK(hipEventRecord(bands[i]->band_slot->ev_k1, bands[i]->nstream));
+        HIPCHK(hipStreamWaitEvent(s0, bands[i]->band_slot->ev_k1, 0));
+    }
+    hipLaunchKernelGGL(k_sum_bands, dim3((count + 255) / 256), dim3(256), 0, s0, ptrs, n, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(bands[0]->band_slot->ev_k1, s0));
+    for (int i = 1; i < n; ++i) HIPCHK(hipStreamWaitEvent(bands[i]->nstream, bands[0]->band_slot->ev_k1, 0));
     return MDH_OK;
 }
 

@@ -1067,16 +1067,17 @@ __global__ void __launch_bounds__(64) k_morph_close_plain(const u64* __restrict_
             }
             // dilate row yd: the OR of three median rows, then ONE horizontal OR-3 (OR commutes)
             const u64 v = mA | mB | mC;
-            if (__ballot(v != 0) == 0) {
+            if (yd >= 0 && yd < g.H && __ballot(v != 0) == 0) {
                 // (almost every row on a noisy sky: the median has removed what the threshold let through.)  No median pixel
-                // anywhere in the wave's three rows: the dilated row is zero in every lane, its horizontal erosion is a per-lane
-                // constant -- zero wherever a pixel exists -- so nothing can come out for row ya, and two of the three edge
-                // exchanges and all of the dilate / erode logic are skipped
+                // anywhere in the wave's three rows: the dilated row yd -- a row of the image -- is zero in every lane, its horizontal
+                // erosion zero wherever a pixel exists, so nothing can come out for row ya, and two of the three edge exchanges
+                // and all of the dilate / erode logic are skipped.  (A dilate row OUTSIDE the image never wins the erode: it
+                // counts as all ones, and row ya = H - 1 can still come out of the two rows above it: the general path.)
                 bA = bB; bB = brow;
                 eA = eB; eB = eC;
                 pA = pB; pB = pC;
                 mA = mB; mB = 0;
-                dA = dB; dB = (yd >= 0 && yd < g.H) ? ~vm : ~0ull;
+                dA = dB; dB = ~vm;
                 continue;
             }
             edge_bits(v, lb, rb);

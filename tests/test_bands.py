@@ -241,6 +241,44 @@ def test_hip_bands_resident_and_pipelined():
 
 
 @pytest.mark.gpu
+def test_rccl_collectives_on_the_library_streams_one_rank():
+    """The multi-GPU data path with its REAL collectives: an RCCL communicator (librccl through ctypes, metdetpy_amd/rccl.py) of
+    one rank -- RCCL refuses two ranks on one device, and the box has one -- with the noise all-reduce enqueued in place on the
+    band context's noise stream, the bit-plane all-to-all (a send to self) on its post stream, the Hough stage chained behind it by
+    events, two passes queued, and no host wait anywhere before collect().  Results against the oracle, pass by pass; the rows
+    come from HBM for the odd passes and from host memory for the even ones."""
+    from metdetpy_amd import rccl
+    from tests.helpers import binary_cfg
+    H, W, n, K = 272, 512, 8, 24
+    cfg = binary_cfg()
+    mask = np.ones((H, W), np.uint8)
+    frames = SkyStream(H, W, 20220417, speed=8, streak_period=16).take(4 * K)
+    want = whole_frame_oracle(frames, n, mask, cfg)
+    assert sum(w["n_raw"] for w in want) > 0
+    comm = rccl.Communicator(0, 1, rccl.new_unique_id())
+    det = BandedM3Detector(n / 10, 10, mask, 10, cfg, None, rank=0, world=1, max_batch=K, comm=comm)
+    band = det.engine.band
+    ptrs, queued = [], []
+    for k, p0 in enumerate(list(range(0, len(frames), K)) + [None]):
+        if p0 is not None:
+            sub = det.plan.crop(frames[p0:p0 + K], 0)
+            if k % 2:
+                ptr = band.device_alloc(sub.nbytes)
+                band.device_upload(ptr, sub)
+                ptrs.append(ptr)
+                det.submit(ptr, K=K, on_device=True)
+            else:
+                det.submit(sub)
+            queued.append(p0)
+        if len(queued) == 2 or (p0 is None and queued):
+            res, info = det.collect()
+            check_against(res, info, want, queued.pop(0))
+    for ptr in ptrs:
+        band.device_free(ptr)
+    det.close()
+
+
+@pytest.mark.gpu
 def test_two_process_gloo_hip_bands(tmp_path):
     """Two ranks, each with its own band + Hough contexts on GPU 0, host-staged gloo collectives."""
     compare_worker_output(run_two_ranks(tmp_path, "hip"), 270, 448, 8, 16)

@@ -255,18 +255,21 @@ def test_m3_dense_output_format_forced(shape, n, monkeypatch):
 
 
 def test_m3_output_format_flips_mid_stream():
-    """The format is chosen per pass from the share of words with set bits the last collected pass reported (enter above 3 %, leave
-    below 1.5 %): a stream that is quiet, then noisy (the threshold EMA is slow, so a jump of the noise level goes straight into
-    the binaries), then quiet again must flip to the dense format and back, with the oracle's results on every frame -- slots
-    that held a dense pass are reused by sparse ones and the other way round."""
+    """The format is chosen per pass from what the last collected pass reported (a sparse pass: half of its frames dense -> dense
+    format; a dense pass: fewer than 1.5 % of the words with a set bit -> back): a stream that is quiet, then noisy (the threshold
+    EMA is slow, so a jump of the noise level goes straight into the binaries), then a sky with streaks, then quiet again must
+    flip to the dense format and back, with the oracle's results on every frame -- image borders included (round 3: the first
+    version of the dense morphology kernel lost bottom-row pixels, found by this test) -- and slots that held a dense pass are
+    reused by sparse ones and the other way round."""
     shape, n = (72, 256), 4
     mask = np.ones(shape, np.uint8)
     cfg = binary_cfg("normal")
     quiet1 = frames_normal(1, 40, shape, 30, 2.0)
     noisy = frames_normal(2, 56, shape, 30, 9.0)
     s = SkyStream(*shape, 3, speed=5, streak_period=9, streak_life=6)
-    quiet2 = [s.next() for _ in range(80)]
-    frames = np.stack(quiet1 + noisy + quiet2)
+    sky = [s.next() for _ in range(40)]  # (on a frame this small a streak alone keeps 1.5 % of the words busy: still dense)
+    quiet2 = frames_normal(4, 40, shape, 30, 2.0)
+    frames = np.stack(quiet1 + noisy + sky + quiet2)
     det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
     orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
     dense_seen, modes = 0, []
@@ -284,7 +287,7 @@ def test_m3_output_format_flips_mid_stream():
     det.close()
     # sparse at the start, dense somewhere in the noisy stretch, sparse again at the end
     assert modes[0] == 0 and modes[-1] == 0 and max(modes) == 1, modes
-    assert 2 <= sum(modes) < len(modes) - 4, modes
+    assert 2 <= sum(modes) <= len(modes) - 6, modes
 
 
 def test_m3_edge_inputs():
