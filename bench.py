@@ -27,6 +27,7 @@ device when WORLD_SIZE is 1),  --host-input (frames cross PCIe every pass).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -629,6 +630,11 @@ def main():
         n = 4
     if a.batch is None:
         a.batch = wl["batch"]
+    if a.mode == "bands" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "MDH_BENCH_KEEP_QUEUES" not in os.environ:
+        # N band contexts + a Hough context in ONE process on one device: ~30 active streams.  The HIP runtime's hardware queues
+        # (read at its first call, which is still ahead) are few on purpose here: measured 54 k frames/s with 3-5 queues, 38-42 k with
+        # 6-12, 5 k with 32 (the command processor time-slices oversubscribed queues)
+        os.environ["GPU_MAX_HW_QUEUES"] = "4"
     mask = np.ones((H, W), np.uint8)
     if a.workload in ("C3", "C1e"):
         m = load_mask(H, W)

@@ -256,7 +256,13 @@ void* mdh_band_sums_device(mdh_ctx* ctx);           /* device int64 [2 * n_jobs]
 /* sums_total_device: NULL (the sums were all-reduced in place) or a device pointer to 2 * n_jobs int64.  dst_rows_device: as
  * mdh_band_pixels' dst_rows with out_on_device = 1. */
 int mdh_band_pixels_submit(mdh_ctx* ctx, const int64_t* sums_total_device, double roi_px_total, int own_row0, int own_rows,
-                           int rows_stride, int nsplit, uint64_t* dst_rows_device);
+                           int rows_stride, int nsplit, uint64_t* dst_rows_device, int flags);
+#define MDH_EXPORT_NOFILL 1     /* flags: do not zero-fill the slots first (the destination is a plane several bands write into) */
+/* All bands in ONE process: the dst planes ([K][H][WW] u64) the next pass queued on a MDH_ROLE_HOUGH context will read.  Every
+ * band exports its rows straight into them (dst_rows_device = planes + own_first_row * WW, rows_stride = H, nsplit = 1,
+ * MDH_EXPORT_NOFILL; together the bands cover every row) and mdh_hough_planes_submit(ctx, planes, K, 1, 1, H) assembles in
+ * place: the exchange costs nothing. */
+void* mdh_hough_input_planes(mdh_ctx* ctx);
 int mdh_band_collect(mdh_ctx* ctx, mdh_frame_info* info);   /* waits for the oldest queued band pass; returns its frame count */
 /* everything queued on producer's stream so far precedes whatever is queued on consumer's stream from now on (same process) */
 int mdh_chain(mdh_ctx* producer, int producer_stream, mdh_ctx* consumer, int consumer_stream);

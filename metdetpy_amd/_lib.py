@@ -78,7 +78,7 @@ EXPORTS = [
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
     "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint", "mdh_dense_passes", "mdh_last_density", "mdh_dense_now",
     "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
-    "mdh_device_copy_on", "mdh_bands_allreduce_local"
+    "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes"
 ]
 
 _lib = None
@@ -161,7 +161,9 @@ def load():
     L.mdh_band_submit.argtypes = [vp, vp, i32, i32, C.POINTER(i32)]
     L.mdh_band_sums_device.argtypes = [vp]
     L.mdh_band_sums_device.restype = vp
-    L.mdh_band_pixels_submit.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp]
+    L.mdh_band_pixels_submit.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32]
+    L.mdh_hough_input_planes.argtypes = [vp]
+    L.mdh_hough_input_planes.restype = vp
     L.mdh_band_collect.argtypes = [vp, vp]
     L.mdh_chain.argtypes = [vp, i32, vp, i32]
     L.mdh_device_copy_on.argtypes = [vp, i32, vp, vp, u64]
@@ -409,9 +411,15 @@ class Context:
         """hipStream_t (as an integer) of one of the context's streams: MDH_STREAM_*; for collectives the host enqueues (RCCL)."""
         return int(self.L.mdh_stream_handle(self.handle, int(which)) or 0)
 
-    def band_pixels_submit(self, roi_px_total, own_row0, own_rows, rows_stride, nsplit, out: int, sums_total_device: int = 0):
+    def band_pixels_submit(self, roi_px_total, own_row0, own_rows, rows_stride, nsplit, out: int, sums_total_device: int = 0,
+                           nofill: bool = False):
         check(self.L.mdh_band_pixels_submit(self.handle, int(sums_total_device) or None, float(roi_px_total), int(own_row0), int(own_rows),
-                                            int(rows_stride), int(nsplit), int(out)), "mdh_band_pixels_submit")
+                                            int(rows_stride), int(nsplit), int(out), 1 if nofill else 0), "mdh_band_pixels_submit")
+
+    @property
+    def hough_input_planes(self) -> int:
+        """Device pointer of the dst planes the next pass queued on this (Hough) context reads (bands export straight into it)."""
+        return int(self.L.mdh_hough_input_planes(self.handle) or 0)
 
     def band_collect(self):
         """Thresholds (bi_threshold, bi_threshold_float, snr, sigma) of the oldest queued band pass."""

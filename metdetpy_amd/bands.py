@@ -64,7 +64,8 @@ class HipBandEngine:
     frame, both on `device`.  (Tests may substitute an engine with the same three methods to exercise the exchange
     logic without a GPU.)"""
 
-    def __init__(self, plan: BandPlan, b: int, n: int, cfg: BinaryCfg, mask_area: float, max_batch: int, device: int):
+    def __init__(self, plan: BandPlan, b: int, n: int, cfg: BinaryCfg, mask_area: float, max_batch: int, device: int,
+                 with_hough: bool = True):
         d = plan.bands[b]
         self.plan, self.b = plan, b
 
@@ -88,15 +89,21 @@ class HipBandEngine:
 
         self.band = _lib.Context(d["sub1"] - d["sub0"], plan.W, n, base(_lib.MDH_ROLE_BAND, d["roi"], max_batch), device=device)
         self.kp_max = -(-int(max_batch) // plan.nbands)
-        self.hough = _lib.Context(plan.H, plan.W, 1, base(_lib.MDH_ROLE_HOUGH, (0, 0, 0, 0), self.kp_max), device=device)
+        self._hough_cfg = lambda kmax: base(_lib.MDH_ROLE_HOUGH, (0, 0, 0, 0), kmax)
+        self.hough = _lib.Context(plan.H, plan.W, 1, self._hough_cfg(self.kp_max), device=device) if with_hough else None
+        self.device = device
+
+    def shared_hough_context(self, max_batch):
+        """ONE Hough context for all frames of a pass (all bands in one process: LocalBands)."""
+        return _lib.Context(self.plan.H, self.plan.W, 1, self._hough_cfg(int(max_batch)), device=self.device)
 
     def noise(self, sub_frames, K=None, on_device=False):
         return self.band.band_noise(sub_frames, K=K, on_device=on_device)
 
-    def pixels(self, sums_total, out=None):
+    def pixels(self, sums_total, out=None, nsplit=None):
         d = self.plan.bands[self.b]
         return self.band.band_pixels(sums_total, self.plan.roi_px, d["own0"] - d["sub0"], d["own1"] - d["own0"],
-                                     self.plan.band_rows, self.plan.nbands, out=out)
+                                     self.plan.band_rows, nsplit or self.plan.nbands, out=out)
 
     def hough_stage(self, pieces, kp, on_device=False):
         return self.hough.hough_planes(pieces, kp, self.plan.nbands, self.plan.band_rows, on_device=on_device)
@@ -112,10 +119,16 @@ class HipBandEngine:
     def noise_submit(self, sub_frames, K=None, on_device=False) -> int:
         return self.band.band_submit(sub_frames, K=K, on_device=on_device)
 
-    def pixels_submit(self, out: int):
+    def pixels_submit(self, out: int, nsplit=None):
         d = self.plan.bands[self.b]
         self.band.band_pixels_submit(self.plan.roi_px, d["own0"] - d["sub0"], d["own1"] - d["own0"], self.plan.band_rows,
-                                     self.plan.nbands, out)
+                                     nsplit or self.plan.nbands, out)
+
+    def pixels_submit_into_planes(self, planes: int):
+        """Owned rows straight into whole-frame planes [K][H][WW] (the shared Hough context's input: mdh_hough_input_planes)."""
+        d = self.plan.bands[self.b]
+        self.band.band_pixels_submit(self.plan.roi_px, d["own0"] - d["sub0"], d["own1"] - d["own0"], self.plan.H, 1,
+                                     planes + d["own0"] * self.plan.WW * 8, nofill=True)
 
     def thresholds_collect(self):
         return self.band.band_collect()
@@ -128,7 +141,8 @@ class HipBandEngine:
 
     def close(self):
         self.band.close()
-        self.hough.close()
+        if self.hough is not None:
+            self.hough.close()
 
 
 def _package(num_cls, info, raw, nms, prob):
@@ -168,10 +182,21 @@ class LocalBands:
     """All bands of one stream in ONE process on ONE GPU: the same three steps per band, the exchanges done with array
     copies.  For single-GPU parity tests and for sizing the band path; production runs one BandedM3Detector per GPU."""
 
-    def __init__(self, window_sec, fps, mask, num_cls, cfg, nbands, *, device=0, max_batch=64, engine=HipBandEngine):
+    def __init__(self, window_sec, fps, mask, num_cls, cfg, nbands, *, device=0, max_batch=64, engine=HipBandEngine,
+                 shared_hough=None):
+        """shared_hough (default: yes with the HIP engine): the bands of one process hand their rows to ONE Hough context that
+        replays every frame of the pass -- each band's export kernel writes its piece of every plane straight into that context's
+        input buffer, so the exchange costs nothing -- instead of one Hough context per band with an all-to-all in between (the
+        multi-GPU structure, kept for the tests of the exchange logic: shared_hough=False)."""
         self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, nbands)
         p = self.s.plan
-        self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device) for b in range(p.nbands)]
+        self.shared = (engine is HipBandEngine) if shared_hough is None else bool(shared_hough)
+        if self.shared:
+            self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device, with_hough=False) for b in range(p.nbands)]
+            self.hough = self.engines[0].shared_hough_context(max_batch)
+        else:
+            self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device) for b in range(p.nbands)]
+            self.hough = None
         # one host thread per band: every band has a context of its own (a context is used by one thread at a time, and ctypes
         # releases the GIL inside a call), so the bands' blocking steps run side by side on the device the way they do on N GPUs
         from concurrent.futures import ThreadPoolExecutor
@@ -190,9 +215,16 @@ class LocalBands:
         kp = -(-K // N)
         parts = [e.noise(p.crop(frames, b)) for b, e in enumerate(self.engines)]
         total = np.sum(parts, axis=0) if len(parts[0]) else parts[0]           # "all-reduce"
-        sent = [e.pixels(total) for e in self.engines]                         # [(N, kp, band_rows, WW), info] per band
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
         results = [None] * K
+        if self.shared:
+            sent = [e.pixels(total, nsplit=1) for e in self.engines]           # [(1, K, band_rows, WW), info] per band: frame order
+            hi, raw, nms, prob = self.hough.hough_planes(np.stack([x[0][0] for x in sent]), K, N, p.band_rows)
+            for i in range(K):
+                info[i] = _merge_info(sent[0][1][i], hi[i])
+                results[i] = _package(self.s.num_cls, hi[i], raw[i], nms[i], prob[i])
+            return results, info
+        sent = [e.pixels(total) for e in self.engines]                         # [(N, kp, band_rows, WW), info] per band
         for r, e in enumerate(self.engines):                                   # "all-to-all": rank r receives slice r of every band
             mine = len(range(r, K, N))
             if mine == 0:
@@ -217,6 +249,12 @@ class LocalBands:
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
         results = [None] * K
         thr = [e.thresholds_collect() for e in self.engines][0]  # every band frees its slot; the scalars are the same everywhere
+        if self.shared:
+            hi, raw, nms, prob = self.hough.hough_planes_collect(K)
+            for i in range(K):
+                info[i] = _merge_info(thr[i], hi[i])
+                results[i] = _package(self.s.num_cls, hi[i], raw[i], nms[i], prob[i])
+            return results, info
         for r, e in enumerate(self.engines):
             mine = len(range(r, K, N))
             if mine == 0:
@@ -248,13 +286,43 @@ class LocalBands:
             self._free_xchg()
             piece = kp * p.band_rows * p.WW * 8
             ctx = self.engines[0].band
-            self._send = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
-            self._recv = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
+            if self.shared:  # (no exchange buffers: the bands write into the Hough context's planes)
+                self._send = [[], []]
+                self._recv = [[], []]
+            else:
+                self._send = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
+                self._recv = [[ctx.device_alloc(N * piece) for _ in range(N)] for _ in range(2)]
             self._xchg_kp = kp
         send, recv = self._send[self._seq % 2], self._recv[self._seq % 2]
         for b, e in enumerate(self.engines):
             e.noise_submit(sub_ptrs[b], K=K, on_device=True)
         _lib.bands_allreduce_local([e.band for e in self.engines])
+        if self.shared:
+            # band b writes its rows of every plane where the Hough context reads them: that context's own dst planes [K][H][WW]
+            import os
+            if os.environ.get("MDH_BANDS_INPLACE", "1") == "0":  # A/B: pieces into a buffer of their own, assembled by a copy
+                if not recv:
+                    piece_b = K * p.band_rows * p.WW * 8
+                    self._recv = [[self.engines[0].band.device_alloc(N * piece_b)] for _ in range(2)]
+                    recv = self._recv[self._seq % 2]
+                piece_b = K * p.band_rows * p.WW * 8
+                for b, e in enumerate(self.engines):
+                    e.pixels_submit(recv[0] + b * piece_b, nsplit=1)
+                    e.band.chain_to(_lib.MDH_STREAM_POST_LAST, self.hough, _lib.MDH_STREAM_POST_NEXT)
+                self.hough.hough_planes_submit(recv[0], K, N, p.band_rows, on_device=True)
+                self._queued.append((K, kp))
+                self._seq += 1
+                return
+            planes = self.hough.hough_input_planes
+            if not planes:
+                raise RuntimeError("the shared Hough context has no free pass slot")
+            for b, e in enumerate(self.engines):
+                e.pixels_submit_into_planes(planes)
+                e.band.chain_to(_lib.MDH_STREAM_POST_LAST, self.hough, _lib.MDH_STREAM_POST_NEXT)
+            self.hough.hough_planes_submit(planes, K, 1, p.H, on_device=True)
+            self._queued.append((K, kp))
+            self._seq += 1
+            return
         for b, e in enumerate(self.engines):
             e.pixels_submit(send[b])
         live = kp * p.band_rows * p.WW * 8
@@ -275,6 +343,9 @@ class LocalBands:
 
     def close(self):
         self._free_xchg()
+        if self.hough is not None:
+            self.hough.close()
+            self.hough = None
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None

@@ -675,6 +675,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
+    if (role != MDH_ROLE_FULL) c->nmain = 1;  // (see post_stream)
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
     if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_POLL")) c->lean_poll = atoi(v) != 0;
@@ -763,6 +764,12 @@ extern "C" int mdh_profile_read(mdh_ctx* c, double* ms, int64_t* launches, int r
 }
 
 // ------------------------------------------------------------------------------------------------ passes
+// Post stream of the pass with sequence number `seq`.  Full contexts alternate between two (the post stages of pass p + 1 do not
+// queue behind the Hough hand-over of pass p); band / Hough contexts of a tiled stream use ONE: a tiling runs 2 N contexts side by
+// side, and every extra active stream is one more client of the command processor's few hardware queues (8 bands + 8 Hough
+// contexts on one device: 104 active streams, 13 k frames/s).
+static inline hipStream_t post_stream(const mdh_ctx* c, int64_t seq) { return c->pstream[c->role == MDH_ROLE_FULL ? (seq & 1) : 0]; }
+
 static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
     PassGeom g;
     g.H = c->H; g.W = c->W; g.WW = c->WW; g.n = c->n; g.K = K; g.t_base = t_base; g.R = c->R;
@@ -871,11 +878,29 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     const int words = (int)c->words;
     const int waves = (words + PPL - 1) / PPL;
     static const int target_waves = getenv("MDH_WIN_WAVES") ? atoi(getenv("MDH_WIN_WAVES")) : 4096;  // experiment switch
+    static const int wpb = getenv("MDH_WIN_BLOCK") ? std::max(1, std::min(4, atoi(getenv("MDH_WIN_BLOCK")) / 64)) : 4;  // waves per workgroup
     int nchunks = (target_waves + waves - 1) / waves;
-    nchunks = std::max(1, std::min(nchunks, g.K / (2 * N)));
+    const int cap = std::max(1, g.K / (2 * N));
+    nchunks = std::max(1, std::min(nchunks, cap));
+    {   // Time chunks so that the grid is close to a whole number of ROUNDS of resident workgroups (256 CUs x 3 workgroups of four
+        // waves at <= 168 VGPRs, x 2 above): a band of an 8K frame (548 rows: 1028 workgroups) in one chunk is 1.34 rounds -- the
+        // launch lasts two, a third of the machine idle in the second -- in two chunks 2.68 of 3.  Whole frames at the bench's
+        // sizes are unchanged (1080p: 3 chunks = 1.98 rounds; 4K / n = 16: 3.95; 8K: 10.5).
+        static const bool balance = getenv("MDH_WIN_BALANCE") && atoi(getenv("MDH_WIN_BALANCE")) != 0;  // experiment switch, off: measured
+        // slower (960x540: 4.03 -> 3.76 M frames/s with 12 chunks instead of 9; 8 bands of 8K: 49.8 -> 48.3 k: every chunk re-reads n - 1
+        // frames and the launches of neighbouring passes / bands fill each other's tails anyway)
+        const double resident = 256.0 * (N <= 8 ? 3 : 2) * 4 / wpb;
+        const double wgs = (double)((waves + wpb - 1) / wpb);
+        auto eff = [&](int nc) { const double r = wgs * nc / resident; return r / std::ceil(r); };
+        if (balance) {
+            int best = nchunks;
+            for (int nc = nchunks + 1; nc <= std::min(cap, nchunks + 3); ++nc)
+                if (eff(nc) > eff(best) + 0.05) best = nc;
+            nchunks = best;
+        }
+    }
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
-    static const int wpb = getenv("MDH_WIN_BLOCK") ? std::max(1, std::min(4, atoi(getenv("MDH_WIN_BLOCK")) / 64)) : 4;  // waves per workgroup
     if (lean.copy_dst)  // per-frame protocol: its own instantiation, the batched one pays nothing for it
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
                            c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean, (unsigned long long*)nullptr);
@@ -1013,7 +1038,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // downstream of it -- morphology, dynamic mask, Hough, result packing -- is short or latency-bound and runs on the
     // pass's post streams, overlapping the window kernel of the following pass(es).
     // (the post streams are NOT the Hough streams: morphology of pass p must not queue behind the Hough stage of pass p-2)
-    hipStream_t post = c->lean ? c->nstream : c->pstream[c->pass_seq & 1];
+    hipStream_t post = c->lean ? c->nstream : post_stream(c, c->pass_seq);
     if (!c->lean_direct) EV_WAIT(c, c->stream, sl.ev_noise);  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
@@ -1664,7 +1689,7 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     if (nj) HIPCHK(hipMemcpyAsync(c->d_sums, sums_total, sizeof(long long) * 2 * nj, hipMemcpyHostToDevice, c->nstream));
     if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return rc;
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t post = c->pstream[c->pass_seq & 1];
+    hipStream_t post = post_stream(c, c->pass_seq);
     if ((rc = run_pixels(c, sl, K)) != MDH_OK) return rc;
     // owned rows -> exchange buffer in all-to-all send order
     const int Kp = (K + nsplit - 1) / nsplit;
@@ -1715,8 +1740,8 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
 static hipStream_t pick_stream(mdh_ctx* c, int which) {
     switch (which) {
         case MDH_STREAM_NOISE: return c->nstream;
-        case MDH_STREAM_POST_LAST: return c->pstream[(c->pass_seq + 1) & 1];  // (pass_seq - 1) & 1
-        case MDH_STREAM_POST_NEXT: return c->pstream[c->pass_seq & 1];
+        case MDH_STREAM_POST_LAST: return post_stream(c, c->pass_seq + 1);  // (pass_seq - 1) & 1
+        case MDH_STREAM_POST_NEXT: return post_stream(c, c->pass_seq);
         default: return nullptr;
     }
 }
@@ -1742,7 +1767,7 @@ extern "C" int mdh_band_submit(mdh_ctx* c, const uint8_t* frames, int K, int on_
 extern "C" void* mdh_band_sums_device(mdh_ctx* c) { return (c && c->band_slot) ? (void*)c->band_slot->d_sums : nullptr; }
 
 extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total, int own_row0, int own_rows,
-                                      int rows_stride, int nsplit, uint64_t* dst_rows_device) {
+                                      int rows_stride, int nsplit, uint64_t* dst_rows_device, int flags) {
     if (!c || !dst_rows_device) { set_err("mdh_band_pixels_submit: null argument"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_pixels_submit: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
     if (!c->band_slot) { set_err("mdh_band_pixels_submit: call mdh_band_submit first"); return MDH_E_STATE; }
@@ -1759,12 +1784,14 @@ extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, d
         HIPCHK(hipMemcpyAsync(c->d_sums, d_sums_total, sizeof(long long) * 2 * nj, hipMemcpyDeviceToDevice, c->nstream));
     if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return poison(c, rc);
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t post = c->pstream[c->pass_seq & 1];
+    hipStream_t post = post_stream(c, c->pass_seq);
     if ((rc = run_pixels(c, sl, K)) != MDH_OK) return poison(c, rc);
     const int Kp = (K + nsplit - 1) / nsplit;
     const size_t out_words = (size_t)nsplit * Kp * rows_stride * c->WW;
     u64* dev_out = (u64*)dst_rows_device;
-    HIPCHK(hipMemsetAsync(dev_out, 0, out_words * sizeof(u64), post));
+    // (zero fill only where the export leaves holes: slots of frames that do not exist, rows a short last band does not own)
+    if (!(flags & MDH_EXPORT_NOFILL) && ((size_t)nsplit * Kp != (size_t)K || own_rows != rows_stride))
+        HIPCHK(hipMemsetAsync(dev_out, 0, out_words * sizeof(u64), post));
     hipLaunchKernelGGL(k_export_rows, dim3((own_rows * c->WW + 255) / 256, K), dim3(256), 0, post, sl.d_dst, dev_out, K, c->H, c->WW,
                        own_row0, own_rows, rows_stride, nsplit, Kp);
     HIPCHK(hipGetLastError());
@@ -1826,17 +1853,30 @@ extern "C" int mdh_chain(mdh_ctx* producer, int pwhich, mdh_ctx* consumer, int c
     return MDH_OK;
 }
 
+__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16);
 extern "C" int mdh_device_copy_on(mdh_ctx* c, int which, void* dst, const void* src, uint64_t bytes) {
     if (!c || !dst || !src) { set_err("mdh_device_copy_on: null argument"); return MDH_E_ARG; }
     hipStream_t st = pick_stream(c, which);
     if (!st) { set_err("mdh_device_copy_on: unknown stream designator"); return MDH_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    // a copy KERNEL, not hipMemcpyAsync: same-device copies of tens of megabytes go through an SDMA engine at ~65 GB/s
+    // (8 bands x 8 pieces of 16.6 MB per pass: 16 ms), a grid of waves moves them at HBM speed
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    }
     return MDH_OK;
 }
 
 // Single-process stand-in of the noise all-reduce: the staged passes of `n` band contexts on ONE device get the sum of their
 // sums, on the device, ordered by events between the contexts' noise streams (what ncclAllReduce does across GPUs).
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x) dst[e] = src[e];
+}
 struct SumPtrs { long long* p[MDH_MAX_LOCAL_BANDS]; };
 __global__ void k_sum_bands(SumPtrs ptrs, int n, int count) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1971,7 +2011,7 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
     int rc;
     if ((rc = slot_begin(c, K, slp)) != MDH_OK) return rc;
     Slot& sl = *slp;
-    hipStream_t post = c->pstream[c->pass_seq & 1];
+    hipStream_t post = post_stream(c, c->pass_seq);
     const size_t in_words = (size_t)nbands * K * band_rows * c->WW;
     const u64* src = (const u64*)pieces;
     if (!on_device) {
@@ -1980,8 +2020,12 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
         src = c->d_xchg;
     }
     HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), post));
+    // pieces == the slot's own plane buffer (mdh_hough_input_planes: the bands exported straight into it, one "band" of H rows):
+    // nothing to copy, only the row / frame lit counts and the bounding boxes are taken
+    const int inplace = (on_device && (const void*)src == (const void*)sl.d_dst && nbands == 1 && band_rows == c->H) ? 1 : 0;
+    if ((const void*)src == (const void*)sl.d_dst && !inplace) { set_err(std::string(who) + ": the context's own plane buffer wants nbands = 1, band_rows = H"); return MDH_E_ARG; }
     hipLaunchKernelGGL(k_assemble_planes, dim3((unsigned)((c->words + 255) / 256), K), dim3(256), 0, post, src, sl.d_dst, sl.d_rowcount,
-                       sl.d_litcount, sl.d_bbox, K, c->H, c->W, c->WW, band_rows);
+                       sl.d_litcount, sl.d_bbox, K, c->H, c->W, c->WW, band_rows, inplace);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev_pix, post));
     // the staging buffer of host pieces is one per context: the next submit may refill it only after this pass has read it
@@ -1989,6 +2033,14 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
     if ((rc = run_hough(c, sl, K)) != MDH_OK) return rc;
     slot_commit(c, sl);
     return MDH_OK;
+}
+
+// The dst bit planes ([K][H][WW] u64, frame-major) the NEXT pass queued on a Hough context will read: band contexts of the same
+// process may export their rows straight into them (mdh_band_pixels_submit with rows_stride = H, MDH_EXPORT_NOFILL) and hand the
+// same pointer to mdh_hough_planes_submit (nbands = 1, band_rows = H), which then assembles in place.
+extern "C" void* mdh_hough_input_planes(mdh_ctx* c) {
+    if (!c || c->role != MDH_ROLE_HOUGH || c->in_flight >= c->nslot) return nullptr;
+    return (void*)c->slot[c->next_slot].d_dst;
 }
 
 extern "C" int mdh_hough_planes(mdh_ctx* c, const uint64_t* pieces, int K, int on_device, int nbands, int band_rows,

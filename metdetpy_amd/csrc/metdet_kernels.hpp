@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(256) k_export_rows(const u64* __restrict__ dst
 // counts and the bounding box of the lit pixels (as k_dy_sparse leaves them).
 __global__ void __launch_bounds__(256) k_assemble_planes(const u64* __restrict__ pieces, u64* __restrict__ dst_bits,
                                                          int* __restrict__ rowcount, int* __restrict__ litcount,
-                                                         int* __restrict__ bbox, int K, int H, int W, int WW, int band_rows) {
+                                                         int* __restrict__ bbox, int K, int H, int W, int WW, int band_rows, int inplace) {
     const int i = blockIdx.y;
     const int gw = blockIdx.x * blockDim.x + threadIdx.x;
     if (gw >= H * WW) return;
@@ -1334,7 +1334,7 @@ __global__ void __launch_bounds__(256) k_assemble_planes(const u64* __restrict__
     const int b = y / band_rows;
     u64 v = pieces[(((size_t)b * K + i) * band_rows + (y - b * band_rows)) * WW + w];
     if (w == WW - 1 && (W & 63)) v &= (1ull << (W & 63)) - 1;  // padding bits stay 0 whatever the sender left there
-    dst_bits[(size_t)i * H * WW + gw] = v;
+    if (!inplace) dst_bits[(size_t)i * H * WW + gw] = v;  // (inplace: the bands' export kernels wrote the planes where they are read)
     if (v) {
         const int c = __popcll(v);
         atomicAdd(&rowcount[i * H + y], c);
@@ -1625,6 +1625,19 @@ struct HoughParams {
 };
 
 
+// Maximum over the 64 lanes of a wave (all lanes active), returned wave-uniform: four row_shr steps leave every 16-lane row's
+// maximum in its lane 15, row_bcast:15 / row_bcast:31 carry it on to lane 63 -- seven DPP moves.  (__builtin_amdgcn_wave_reduce_max_u32
+// compiles to a scalar loop over the 64 lanes on gfx950, ~2000 cycles: the largest single item of a PPHT trigger, round 3.)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ u64 ld_l2(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1850,7 +1863,7 @@ __device__ void ppht_serial(Ppht& C, int N, unsigned* list) {
         vote_issue(C, x, y, old);
         const unsigned key = vote_key(C, old);
         if (!__any(key_value(key) >= C.P.threshold)) continue;
-        const unsigned best = __builtin_amdgcn_wave_reduce_max_u32(key, 0);
+        const unsigned best = wave_max_u32(key);
         ppht_line(C, x, y, 255 - (int)(best & 0xFF));
     }
 }
@@ -1964,7 +1977,7 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
                     unvote(C, pt & 0xFFFF, pt >> 16);
                 }
             }
-            const unsigned best = __builtin_amdgcn_wave_reduce_max_u32(trig_key, 0);
+            const unsigned best = wave_max_u32(trig_key);
             unsigned tp = 0;
 #pragma unroll
             for (int k = 0; k < PPHT_G; ++k)
@@ -2313,12 +2326,15 @@ __device__ __forceinline__ void h3_unvote(Hough3& C, int x, int y) {
 
 // exclusive scan over the workgroup (3 waves); `total` = sum over all threads.  Two barriers.
 __device__ __forceinline__ int h3_scan(int v, int& total, unsigned* scratch, int lane, int wave) {
+    // inclusive wave scan on DPP moves (Hillis-Steele inside a 16-lane row, then the row totals carried on with row_bcast:15 / :31)
+    // instead of six ds_bpermute round trips (__shfl_up)
     int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     if (lane == 63) scratch[wave] = (unsigned)incl;
     __syncthreads();
     const int s0 = (int)scratch[0], s1 = (int)scratch[1], s2 = (int)scratch[2];
@@ -2558,7 +2574,7 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
             // later ones are gone (= the `val` of hough.cpp's scan over n)
             const int kt1 = h3_cell_now<HYBRID>(C, tx, ty);
             const unsigned key = ((unsigned)(kt1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.tid < 256 ? C.tid : 255));
-            const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(C.vinc ? key : 0u, 0);
+            const unsigned wmax = wave_max_u32(C.vinc ? key : 0u);
             if (lane == 0) C.fix[8 + C.wave] = wmax;
             __syncthreads();
             const unsigned best = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(C.fix[8], C.fix[9]), C.fix[10]));
@@ -2631,7 +2647,7 @@ __device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, 
         }
         // ---- strongest cell of the accumulator: larger count first, then the smaller angle ("first maximum wins")
         const unsigned key = has_angle ? (((unsigned)(best + 1 + KEY_BIAS) << 8) | (unsigned)(255 - tid)) : 0u;
-        const unsigned wmax = __builtin_amdgcn_wave_reduce_max_u32(key, 0);
+        const unsigned wmax = wave_max_u32(key);
         if (lane == 0) C.fix[8 + C.wave] = wmax;
         __syncthreads();
         const unsigned top = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(C.fix[8], C.fix[9]), C.fix[10]));
@@ -2717,6 +2733,18 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     u64* gmask = P.work_bits + (size_t)slot * words;
     const int TW = rows * wpr;
     __syncthreads();
+    if (mask_lds) {
+        // the words of the bounding box into the LDS mask first, many loads in flight (round 3: the loop below used to fetch its
+        // word itself -- one dependent HBM round trip per 192 words between two barriers: 50 of a 2000-point frame's 60 us of set-up)
+#pragma unroll 4
+        for (int e = tid; e < TW; e += HOUGH3_THREADS) {
+            const int ry = e / wpr;
+            const u64 word = dst[(size_t)(by0 + ry) * P.WW + wlo + (e - ry * wpr)];
+            lmask[2 * e] = (unsigned)word;
+            lmask[2 * e + 1] = (unsigned)(word >> 32);
+        }
+        __syncthreads();
+    }
     int run = 0;
     for (int base = 0; base < TW; base += HOUGH3_THREADS) {
         const int e = base + tid;
@@ -2726,12 +2754,11 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
             const int ry = e / wpr;
             y = by0 + ry;
             w = wlo + (e - ry * wpr);
-            word = dst[(size_t)y * P.WW + w];
             if (mask_lds) {
-                lmask[2 * e] = (unsigned)word;
-                lmask[2 * e + 1] = (unsigned)(word >> 32);
-            } else if (word) {
-                gmask[(size_t)y * P.WW + w] = word;
+                word = (u64)lmask[2 * e] | ((u64)lmask[2 * e + 1] << 32);
+            } else {
+                word = dst[(size_t)y * P.WW + w];
+                if (word) gmask[(size_t)y * P.WW + w] = word;
             }
         }
         int tot;
@@ -2854,7 +2881,7 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
                 const int* row = acc_base + (size_t)a * P.numrho;
                 int m = 0;
                 for (int r = tid; r < size; r += HOUGH3_THREADS) m = max(m, (int)ld_l2((const unsigned*)&row[lo + r]));
-                m = (int)__builtin_amdgcn_wave_reduce_max_u32((unsigned)m, 0);
+                m = (int)wave_max_u32((unsigned)m);
                 if (lane == 0 && m) atomicMax(&pub[4 * k + 3], (unsigned)m);
             }
             __syncthreads();

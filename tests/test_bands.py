@@ -195,7 +195,7 @@ def test_hip_synthetic_sky_in_bands():
     frames = SkyStream(H, W, 20220415, speed=8, streak_period=16).take(3 * K)
     want = whole_frame_oracle(frames, n, mask, cfg)
     assert sum(w["n_raw"] for w in want) > 0
-    lb = LocalBands(n / 10, 10, mask, 10, cfg, 4, max_batch=K)
+    lb = LocalBands(n / 10, 10, mask, 10, cfg, 4, max_batch=K, shared_hough=False)  # (the host path of the all-to-all layout)
     for p0 in range(0, len(frames), K):
         res, info = lb.detect_batch(frames[p0:p0 + K])
         check_against(res, info, want, p0)
@@ -203,9 +203,12 @@ def test_hip_synthetic_sky_in_bands():
 
 
 @pytest.mark.gpu
-def test_hip_bands_resident_and_pipelined():
-    """Band rows resident in HBM, two passes in flight (the Hough stage of a pass is queued with mdh_hough_planes_submit and
-    collected one pass later, under the band stages of the next pass): same results as the oracle, pass by pass."""
+@pytest.mark.parametrize("shared_hough", [True, False])
+def test_hip_bands_resident_and_pipelined(shared_hough):
+    """Band rows resident in HBM, two passes in flight, nothing waits for the GPU between submit and collect (queued band steps,
+    device-side sum of the noise sums, event-chained hand-over to the Hough stage): same results as the oracle, pass by pass --
+    with ONE Hough context fed directly by the bands' export kernels (the single-process default) and with one Hough context
+    per band behind an all-to-all of device-to-device copies (the multi-GPU structure)."""
     from tests.helpers import binary_cfg
     H, W, n, K, nbands = 272, 512, 8, 24, 4
     cfg = binary_cfg()
@@ -213,7 +216,7 @@ def test_hip_bands_resident_and_pipelined():
     frames = SkyStream(H, W, 20220416, speed=8, streak_period=16).take(5 * K)
     want = whole_frame_oracle(frames, n, mask, cfg)
     assert sum(w["n_raw"] for w in want) > 0
-    lb = LocalBands(n / 10, 10, mask, 10, cfg, nbands, max_batch=K)
+    lb = LocalBands(n / 10, 10, mask, 10, cfg, nbands, max_batch=K, shared_hough=shared_hough)
     plan = lb.s.plan
     passes = []
     for p0 in range(0, len(frames), K):
