@@ -1093,6 +1093,12 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
             static const int plain_grid = getenv("MDH_PLAIN_GRID") ? std::max(64, atoi(getenv("MDH_PLAIN_GRID"))) : 8192;
             hipLaunchKernelGGL(k_morph_close_plain, dim3(plain_grid), dim3(64), 0, post, sl.d_bplain, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
         } else if (c->lean && K == 1) {
+            // one frame: fourteen rows of a block on fourteen lanes (MDH_MORPH_T=0: the one-lane row pipeline of round 2, A/B and parity testing)
+            static const bool transposed = !(getenv("MDH_MORPH_T") && atoi(getenv("MDH_MORPH_T")) == 0);
+            if (transposed)
+                hipLaunchKernelGGL(k_morph_close_frame_t, dim3((unsigned)((nb * c->WW + 63) / 64)), dim3(64), 0, post, sl.d_bbits, sl.d_bandflag,
+                                   c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+            else
             hipLaunchKernelGGL(k_morph_close_frame, dim3((unsigned)((nb * c->WW + 63) / 64)), dim3(64), 0, post, sl.d_bbits, sl.d_bandflag, c->d_act,
                                sl.d_nzlist, sl.d_nzcount, g);
         } else {

@@ -1144,6 +1144,74 @@ __global__ void __launch_bounds__(64) k_morph_close_frame(const ActWord* __restr
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (morph_block_keep(blockcnt, g, 0, tid)) morph_close_item(bbits, (unsigned)tid, act_ring, nzlist, nzcount, g);
 }
+// One frame, TRANSPOSED (round 3, the per-frame protocol): an item's fourteen input rows on fourteen LANES instead of fourteen steps of
+// a one-lane pipeline.  A group of 16 lanes owns one listed block (band of 8 rows x word column); lane j holds the 128-bit window
+// of row y0 - 3 + j and gets its vertical neighbours' intermediate rows with DPP row shifts (the 16 lanes of a group are one DPP
+// row): median on lanes 1..12, dilate on 2..11, erode + output on 3..10.  The whole 3-stage stencil of a block is then ~250
+// instructions deep instead of 14 x ~150: a streak frame's morphology (a few dozen blocks, one or two per wave: a serial chain of
+// 13-30 us in k_morph_close_frame) drops to the launch's floor.  Same borders as morph_close_band: rows replicated for the median
+// (clamped loads), a median row outside the image is zero, a dilate row outside the image never wins the erode.
+__device__ __forceinline__ u128 dpp_row_u128(u128 v, bool from_below) {
+    // lane j <- lane j - 1 (row_shr:1) of the same 16-lane row, or lane j + 1 (row_shl:1); lanes without a source get zero
+    unsigned w[4] = {(unsigned)v, (unsigned)(v >> 32), (unsigned)(v >> 64), (unsigned)(v >> 96)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        w[k] = from_below ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x101, 0xF, 0xF, false)   // row_shl:1
+                          : (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x111, 0xF, 0xF, false);  // row_shr:1
+    return (u128)w[0] | ((u128)w[1] << 32) | ((u128)w[2] << 64) | ((u128)w[3] << 96);
+}
+__global__ void __launch_bounds__(64) k_morph_close_frame_t(const ActWord* __restrict__ bbits, const unsigned* __restrict__ blockcnt,
+                                                            ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
+                                                            unsigned* __restrict__ nzcount, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15;
+    const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const long long t = g.t_base + 1;
+    ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
+    const u128 ones = ~(u128)0;
+    for (int b0 = blockIdx.x * 64; b0 < nb * g.WW; b0 += gridDim.x * 64) {
+        u64 todo = __ballot(morph_block_keep(blockcnt, g, 0, b0 + lane));
+        while (todo) {  // four listed blocks at a time, one per 16-lane group
+            u64 m = todo;
+            for (int k = 0; k < grp; ++k) m &= m - 1;
+            const bool have = m != 0;
+            const int blk = b0 + (have ? __builtin_ctzll(m) : 0);
+            for (int k = 0; k < 4 && todo; ++k) todo &= todo - 1;
+            const int band = blk / g.WW, w = blk - band * g.WW;
+            const int y0 = band * MORPH_RB;
+            const int yy = y0 - 3 + j;  // this lane's row (j = 14, 15: spare lanes, harmless)
+            const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
+            const Win q = make_win(w, g.W);
+            u128 b = 0;
+            if (have && j < 14) b = load_win_act(bbits + (size_t)yc * g.WW, w, g.WW, (u64)t);
+            // median of this lane's row from the rows above and below (lanes j - 1, j + 1)
+            u128 h0, h1;
+            hsum3_replicate(b, q, h0, h1);
+            const u128 a0 = dpp_row_u128(h0, false), a1 = dpp_row_u128(h1, false);
+            const u128 c0 = dpp_row_u128(h0, true), c1 = dpp_row_u128(h1, true);
+            u128 med = 0;
+            if (yy >= 0 && yy < g.H && j >= 1 && j <= 12) med = count_ge5(a0, a1, h0, h1, c0, c1) & q.valid;
+            // dilate
+            const u128 dil = hor_or3(dpp_row_u128(med, false) | med | dpp_row_u128(med, true)) & q.valid;
+            // erode: horizontal part per row (a dilate row outside the image never wins), then the three rows
+            const u128 e = (yy >= 0 && yy < g.H) ? hor_and3_open(dil, q) : ones;
+            const u128 ea = dpp_row_u128(e, false), ec = dpp_row_u128(e, true);
+            u64 a = 0;
+            if (have && j >= 3 && j <= 10 && yy < g.H) a = (u64)((ea & e & ec & q.valid) >> 3);
+            const u64 havem = __ballot(a != 0);
+            if (havem) {
+                const int leader = __builtin_ctzll(havem);
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(nzcount, (unsigned)__popcll(havem));
+                base = __shfl(base, leader);
+                if (a) {
+                    dst[(size_t)yy * g.WW + w] = ActWord{a, (u64)t};
+                    nzlist[base + __popcll(havem & ((1ull << lane) - 1))] = (unsigned)((size_t)yy * g.WW + w);
+                }
+            }
+        }
+    }
+}
 __global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                     const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
                                                     unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g,
