@@ -515,6 +515,15 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     unsigned sum[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) sum[r] = 0;
+    // the first burst of frames.  LEAN (one frame, read from the caller's buffer over PCIe): requested BEFORE the window history,
+    // so that the 45 us the bus needs start at once and the history's HBM reads (n - 1 frames) run under them
+    const int e_max = g.K + N - 2;
+    constexpr int NB = (N + U - 1) / U;  // bursts per window period
+    dvec buf2[2][U];
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
+    }
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
         unpack(fetch(i0 + k), win[k]);
@@ -546,7 +555,6 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
             }
         }
     }
-    const int e_max = g.K + N - 2;
 #ifndef WIDE_FOLD_TL
 #define WIDE_FOLD_TL (DENSE || N >= 12)  // (sparse, n = 8: +5 registers with it, one step over three-waves-plus-a-Hough-wave per SIMD; n = 9..11: 164 -> 181, three waves per SIMD -> two; from n = 12 on two waves either way: 4K / n = 16 +2.5 %)
 #endif
@@ -555,14 +563,14 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     const int len0 = window_len(g, i0);  // window_len(g, i0 + s) = min(n, len0 + s), in 32-bit scalar arithmetic
     // Bursts of U frames; the loads of burst b+1 are issued before burst b is consumed (double buffering), so a
     // wave always has loads in flight while it computes.
-    constexpr int NB = (N + U - 1) / U;  // bursts per window period
     // (an even number of bursts per period: the two buffers swap roles by the burst's parity, which is static after unrolling,
     // instead of being copied.  A single buffer refilled as soon as a frame is unpacked -- 16 registers less -- was measured and
     // lost 4 % stand-alone and 9 % in the pipeline at 1080p, 40 % at 4K: half the bytes in flight per wave.)
     constexpr bool PINGPONG = WIDE_MAX3 != 0 && !LEAN && (NB % 2 == 0);
-    dvec buf2[2][U];
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
+        for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
+    }
     for (int sb = 0; sb < steps; sb += N) {
         // thresholds of the whole window period up front (scalar loads, off the per-frame critical path)
         int Tp[N];
@@ -2239,8 +2247,8 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
 // A line clears at most one pixel per step along its major axis, and only inside the bounding box of the lit pixels.
 __device__ __forceinline__ int hough3_uv_cap(int N, int bw, int bh) { return (min(N, max(bw, bh) + 2) + 3) & ~3; }
 __device__ __forceinline__ int hough3_lds_need(int N, int uv_cap, int cells, int mask_dwords) {
-    // [fixed | point list N | un-vote list | mask | cells + one dummy dword per thread]
-    return 4 * (HOUGH3_FIXED_DWORDS + ((N + 3) & ~3) + uv_cap + mask_dwords + (cells + 1) / 2 + HOUGH3_THREADS);
+    // [fixed | point list N | un-vote list (two floats per entry) | mask | cells + one dummy dword per thread]
+    return 4 * (HOUGH3_FIXED_DWORDS + ((N + 3) & ~3) + 2 * uv_cap + mask_dwords + (cells + 1) / 2 + HOUGH3_THREADS);
 }
 
 // One wave per frame.  Returns the tier (-1: nothing to replay).
@@ -2360,8 +2368,10 @@ __device__ __forceinline__ bool h3_clear(const Hough3& C, int x, int y) {
 // sixteen independent rho chains interleave; an empty slot adds nothing to the cell of point (0, 0))
 // The vote is split in two so that the atomics of a sub-group are all in flight before the first returned count is looked at.
 template <bool HYBRID>
-__device__ __forceinline__ unsigned h3_vote_issue(Hough3& C, int x, int y, unsigned inc, int& sh) {
-    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+__device__ __forceinline__ unsigned h3_vote_issue(Hough3& C, float x, float y, unsigned inc, int& sh) {
+    // (x, y: the pixel's coordinates ALREADY as floats -- exact, they are below 2^15: converted once per point by the lane that
+    // holds it instead of once per vote by every one of the 192 threads, round 3)
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn(x, C.tc), __fmul_rn(y, C.ts)));
     if (!HYBRID || C.in_lds) {
         const int c = r + C.cbase;
         sh = (c & 1) * 16;
@@ -2380,8 +2390,8 @@ __device__ __forceinline__ u64 h3_uniform(u64 v) {  // the value is wave-uniform
     return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
 template <bool HYBRID, bool ACC = false>
-__device__ __forceinline__ void h3_unvote(Hough3& C, int x, int y) {
-    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+__device__ __forceinline__ void h3_unvote(Hough3& C, float x, float y) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn(x, C.tc), __fmul_rn(y, C.ts)));
     if (ACC && r == C.best_r) C.dirty = true;
     if (!HYBRID || C.in_lds) {
         const int c = r + C.cbase;
@@ -2503,7 +2513,11 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
                     unsigned base = 0;
                     if (lane == 0) base = atomicAdd(&C.fix[24], (unsigned)__popcll(ms));
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (was) C.uv[base + __popcll(ms & ((1ull << lane) - 1))] = pt;
+                    if (was) {  // (x, y) as floats: the sweep below is run by every thread for every entry
+                        const unsigned slot2 = 2 * (base + __popcll(ms & ((1ull << lane) - 1)));
+                        C.uv[slot2] = __float_as_uint((float)(pt & 0xFFFF));
+                        C.uv[slot2 + 1] = __float_as_uint((float)(pt >> 16));
+                    }
                 }
             }
         }
@@ -2514,17 +2528,12 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
     if (good || ACC) {
         const int M = __builtin_amdgcn_readfirstlane((int)C.fix[24]);
         int m = 0;
-        for (; m + 4 <= M; m += 4) {  // four points per LDS read (the list is 16-byte aligned)
-            const uint4 q = *(const uint4*)&C.uv[m];
-            h3_unvote<HYBRID, ACC>(C, q.x & 0xFFFF, q.x >> 16);
-            h3_unvote<HYBRID, ACC>(C, q.y & 0xFFFF, q.y >> 16);
-            h3_unvote<HYBRID, ACC>(C, q.z & 0xFFFF, q.z >> 16);
-            h3_unvote<HYBRID, ACC>(C, q.w & 0xFFFF, q.w >> 16);
+        for (; m + 2 <= M; m += 2) {  // two points per LDS read (the list is 16-byte aligned)
+            const uint4 q = *(const uint4*)&C.uv[2 * m];
+            h3_unvote<HYBRID, ACC>(C, __uint_as_float(q.x), __uint_as_float(q.y));
+            h3_unvote<HYBRID, ACC>(C, __uint_as_float(q.z), __uint_as_float(q.w));
         }
-        for (; m < M; ++m) {
-            const unsigned q = C.uv[m];
-            h3_unvote<HYBRID, ACC>(C, q & 0xFFFF, q >> 16);
-        }
+        for (; m < M; ++m) h3_unvote<HYBRID, ACC>(C, __uint_as_float(C.uv[2 * m]), __uint_as_float(C.uv[2 * m + 1]));
     }
     if (good) {
         if (C.found < MAX_LINES && C.tid == 0) {
@@ -2540,8 +2549,8 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
 // operations of a wave execute in order; a returning atomic on the thread's own row of the pooled accumulator is ordered
 // behind its earlier atomics on the same address).
 template <bool HYBRID>
-__device__ __forceinline__ int h3_cell_now(Hough3& C, int x, int y) {
-    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)x, C.tc), __fmul_rn((float)y, C.ts)));
+__device__ __forceinline__ int h3_cell_now(Hough3& C, float x, float y) {
+    const int r = __float2int_rn(__fadd_rn(__fmul_rn(x, C.tc), __fmul_rn(y, C.ts)));
     if (!HYBRID || C.in_lds) {
         const int c = r + C.cbase;
         return (int)((C.cells[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
@@ -2568,6 +2577,7 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
         nxt = kk + 64 < N ? perm[kk + 64] : 0;
         const unsigned pt = kk < N ? list[idx] : 0;
         const int px = pt & 0xFFFF, py = pt >> 16;
+        const int fxb = (int)__float_as_uint((float)px), fyb = (int)__float_as_uint((float)py);  // the same as float bit patterns
         u64 am = __ballot(kk < N && h3_bit<HYBRID>(C, px, py));
         H3_T(C, 0, tph);
         while (am) {
@@ -2596,20 +2606,29 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
                         rem &= rem - 1;
                         hasm |= (has ? 1u : 0u) << j;
                         int sh;
-                        raw[j] = h3_vote_issue<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l), has ? 1u : 0u, sh);
+                        raw[j] = h3_vote_issue<HYBRID>(C, __uint_as_float((unsigned)__builtin_amdgcn_readlane(fxb, l)),
+                                                      __uint_as_float((unsigned)__builtin_amdgcn_readlane(fyb, l)), has ? 1u : 0u, sh);
                         odd |= (sh > 0 ? 1u : 0u) << j;
                     }
                 }
                 if (TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 H3_T(C, 1, tph);
+                // most sub-groups are quiet: ONE test on the largest returned count says so; the per-slot tests only run on a hit
+                int val[H3_SUB];
+                int vmax = -KEY_BIAS;
 #pragma unroll
                 for (int j = 0; j < H3_SUB; ++j) {
+                    val[j] = -KEY_BIAS;
                     if (j < gused && ((hasm >> j) & 1)) {
-                        int v;
-                        if (!HYBRID || C.in_lds) v = (int)((raw[j] >> (((odd >> j) & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
-                        else v = (int)raw[j];
-                        if (__any(v + 1 >= P.threshold)) hits |= 1u << j;
+                        if (!HYBRID || C.in_lds) val[j] = (int)((raw[j] >> (((odd >> j) & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
+                        else val[j] = (int)raw[j];
+                        vmax = max(vmax, val[j]);
                     }
+                }
+                if (__any(vmax + 1 >= P.threshold)) {
+#pragma unroll
+                    for (int j = 0; j < H3_SUB; ++j)
+                        if (__any(val[j] + 1 >= P.threshold)) hits |= 1u << j;
                 }
             }
             if (lane == 0) C.fix[(round & 1) * 4 + C.wave] = hits;
@@ -2634,13 +2653,14 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
                     const int l = __builtin_ctzll(walk);
                     walk &= walk - 1;
                     if (j == trig) tl = l;
-                    else if (j > trig && j < gused) h3_unvote<HYBRID>(C, __builtin_amdgcn_readlane(px, l), __builtin_amdgcn_readlane(py, l));
+                    else if (j > trig && j < gused) h3_unvote<HYBRID>(C, __uint_as_float((unsigned)__builtin_amdgcn_readlane(fxb, l)),
+                                                                        __uint_as_float((unsigned)__builtin_amdgcn_readlane(fyb, l)));
                 }
             }
             const int tx = __builtin_amdgcn_readlane(px, tl), ty = __builtin_amdgcn_readlane(py, tl);
             // the count the trigger point's vote produced in this thread's cell: earlier points' votes + its own, now that the
             // later ones are gone (= the `val` of hough.cpp's scan over n)
-            const int kt1 = h3_cell_now<HYBRID>(C, tx, ty);
+            const int kt1 = h3_cell_now<HYBRID>(C, (float)tx, (float)ty);
             const unsigned key = ((unsigned)(kt1 + KEY_BIAS) << 8) | (unsigned)(255 - (C.tid < 256 ? C.tid : 255));
             const unsigned wmax = wave_max_u32(C.vinc ? key : 0u);
             if (lane == 0) C.fix[8 + C.wave] = wmax;
@@ -2679,15 +2699,15 @@ __device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, 
         for (; p + 4 <= N; p += 4) {
             const uint4 q = *(const uint4*)&list[p];
             int sh;
-            h3_vote_issue<HYBRID>(C, q.x & 0xFFFF, q.x >> 16, 1u, sh);
-            h3_vote_issue<HYBRID>(C, q.y & 0xFFFF, q.y >> 16, 1u, sh);
-            h3_vote_issue<HYBRID>(C, q.z & 0xFFFF, q.z >> 16, 1u, sh);
-            h3_vote_issue<HYBRID>(C, q.w & 0xFFFF, q.w >> 16, 1u, sh);
+            h3_vote_issue<HYBRID>(C, (float)(q.x & 0xFFFF), (float)(q.x >> 16), 1u, sh);
+            h3_vote_issue<HYBRID>(C, (float)(q.y & 0xFFFF), (float)(q.y >> 16), 1u, sh);
+            h3_vote_issue<HYBRID>(C, (float)(q.z & 0xFFFF), (float)(q.z >> 16), 1u, sh);
+            h3_vote_issue<HYBRID>(C, (float)(q.w & 0xFFFF), (float)(q.w >> 16), 1u, sh);
         }
         for (; p < N; ++p) {
             const unsigned q = list[p];
             int sh;
-            h3_vote_issue<HYBRID>(C, q & 0xFFFF, q >> 16, 1u, sh);
+            h3_vote_issue<HYBRID>(C, (float)(q & 0xFFFF), (float)(q >> 16), 1u, sh);
         }
     }
     if (HYBRID) __threadfence();
@@ -2786,10 +2806,10 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     unsigned* uv = list + Np;
     const int bx0 = P.W - 1 - P.bbox[4 * i], bx1 = P.bbox[4 * i + 1], by0 = P.H - 1 - P.bbox[4 * i + 2], by1 = P.bbox[4 * i + 3];
     const int uvc = hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1);
-    unsigned* lmask = uv + uvc;
+    unsigned* lmask = uv + 2 * uvc;
     const int wlo = bx0 >> 6, wpr = (bx1 >> 6) - wlo + 1, rows = by1 - by0 + 1;
     const int mask_dw = rows * wpr * 2;
-    const int budget_dw = P.lds_bytes / 4 - HOUGH3_FIXED_DWORDS - Np - uvc - HOUGH3_THREADS;  // mask + cells
+    const int budget_dw = P.lds_bytes / 4 - HOUGH3_FIXED_DWORDS - Np - 2 * uvc - HOUGH3_THREADS;  // mask + cells
     bool mask_lds = true;
     if (HYBRID) mask_lds = mask_dw <= budget_dw / 4;  // a huge bounding box: the mask stays in global memory, the LDS goes to the cells
     unsigned* cells = lmask + (mask_lds ? mask_dw : 0);
