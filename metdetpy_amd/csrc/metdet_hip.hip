@@ -197,6 +197,8 @@ struct mdh_ctx {
     // pointer table) from host memory itself and leaves the ring copy; the chain is window -> morphology -> mask -> Hough
     const uint8_t* lean_direct = nullptr;  // device-visible address of the caller's frame, or null
     bool lean_direct_on = true;            // MDH_LEAN_DIRECT=0 switches the path off (A/B)
+    bool lean_due = false;                 // the direct frame being queued is one whose noise sigma is due (a short noise chain in front)
+    bool lean_due_on = true;               // MDH_LEAN_DUE=0: due frames take the general path (DMA copy, prepare, noise chain) as in round 2
     bool lean_poll = true;                 // MDH_LEAN_POLL=0: wait on the event instead of polling the result block
     // time-window sharding on a full context: noise sums of due frames supplied by the caller (the frames of a window that
     // restarted empty cannot produce them: mdh_inject_sums), and frames whose Hough stage is skipped (mdh_mute_hough_until)
@@ -679,6 +681,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
     if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_POLL")) c->lean_poll = atoi(v) != 0;
+    if (const char* v = getenv("MDH_LEAN_DUE")) c->lean_due_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_DENSE")) c->dense_cfg = atoi(v) != 0;
     if (const char* v = getenv("MDH_DENSE_LEAVE")) c->dense_leave = atof(v);
     c->dense_now = c->dense_cfg == 1;
@@ -790,6 +793,22 @@ static bool wide_kernel_applies(const mdh_ctx* c, int K) {  // (the 16-pixels-pe
     return pass_alignment(c, K) >= 16 && c->n >= 2 && c->n <= std::min(16, wide16_max_n) && !c->force_ppl8;
 }
 
+// Momentum of the next EMA update (host mirror of utils.py:360-368; advances the schedule).
+static double ema_next_momentum(mdh_ctx* c) {
+    double m = c->ema_m0;
+    if (c->ema_warm != 0) {
+        const double ramp = (double)c->ema_t * (1 - c->ema_m0) * c->ema_warm;
+        if (ramp < 1) {
+            const double u = 1 - ramp;
+            m = c->ema_m0 * (1 - u * u);
+        } else {
+            c->ema_warm = 0;
+        }
+    }
+    c->ema_t += 1;
+    return m;
+}
+
 // Stage K frames (absolute timers t_base+1 .. t_base+K): build the pointer table [hist (n-1) | pass frames (K)].
 static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int on_device) {
     const int64_t t_base = sl.t_base;
@@ -807,6 +826,15 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
         c->h_ptrtab[c->n - 1] = c->lean_direct;
         c->d_ptrtab = sl.h_hdr_dev;
         sl.nj = 0;
+        if (c->lean_due) {  // the frame's sigma is due: its one noise job sits in the pinned header as well
+            NoiseJob& j = sl.h_jobs[0];
+            j.frame = 0;
+            j.k_used = c->n;
+            j.m_cur = ema_next_momentum(c);
+            j.one_minus = 1 - j.m_cur;
+            sl.nj = 1;
+            c->d_jobs = (NoiseJob*)((uint8_t*)sl.h_hdr_dev + sl.hdr_jobs_off);
+        }
         return MDH_OK;
     }
     if (!on_device) {
@@ -831,17 +859,7 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
         if (t > n && t % std_interval == 0) k_used = n;      // Detector.py:82
         else if (t > 1 && t <= n) k_used = (int)t;           // Detector.py:87
         if (!k_used) continue;
-        double m = c->ema_m0;
-        if (c->ema_warm != 0) {  // utils.py:360-368
-            const double ramp = (double)c->ema_t * (1 - c->ema_m0) * c->ema_warm;
-            if (ramp < 1) {
-                const double u = 1 - ramp;
-                m = c->ema_m0 * (1 - u * u);
-            } else {
-                c->ema_warm = 0;
-            }
-        }
-        c->ema_t += 1;
+        const double m = ema_next_momentum(c);
         NoiseJob& j = sl.h_jobs[nj++];
         j.frame = i;
         j.k_used = k_used;
@@ -1027,6 +1045,28 @@ static int run_noise(mdh_ctx* c, Slot& sl, int K) {
     return noise_finish(c, sl, K, nj, (double)(r[2] - r[0]) * (r[3] - r[1]));
 }
 
+// Per-frame protocol, a frame whose sigma is due, read straight from the caller's pinned buffer (round 3: such a frame -- one in
+// interval * n -- used to fall back to the general path: DMA copy with its 17 us hand-over, header copy, k_pass_prepare, noise chain).
+// Two launches in front of the window kernel: the ROI sums (the new frame's ROI crosses PCIe here, 0.2 MB) and the scalar chain.
+// The slot is clean (lean_direct_source checked it) and its sums are zero: k_hough_single's clean-up leaves them so.
+static int run_noise_direct(mdh_ctx* c, Slot& sl) {
+    const int* r = c->cfg.roi;
+    const int rh = r[2] - r[0], rw = r[3] - r[1];
+    PassGeom g = geom(c, 1, sl.t_base);
+    const int xa = r[1] & ~3;
+    const int nx4 = (r[1] + rw - xa + 3) >> 2;
+    span_begin(c, KK_NOISE_SUMS, c->nstream);
+    hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), 1), dim3(256), 0, c->nstream, c->d_ptrtab, c->d_jobs, c->d_sums, g,
+                       r[0], r[1], rh, rw);
+    span_end(c, c->nstream);
+    span_begin(c, KK_NOISE_FINAL, c->nstream);
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->nstream, c->d_jobs, 1, c->d_sums, c->d_state, c->d_jobres, sl.d_fscal, c->d_thr, 1,
+                       (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, (unsigned*)nullptr);
+    span_end(c, c->nstream);
+    HIPCHK(hipGetLastError());
+    return MDH_OK;
+}
+
 // {M3,Classic}Detector.detect for the K staged frames, pixel stages: window kernel on the main stream, morphology and
 // dynamic mask on the pass's post stream.  Leaves dst bit planes, row / frame lit counts and bounding boxes in the slot.
 static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
@@ -1048,8 +1088,8 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         c->win_dense_used = false;
         c->win_plain = sl.d_bplain;
         c->win_nzwords = c->lean ? nullptr : (unsigned long long*)(sl.d_nzcount + 2);
-        if (c->lean_direct) {  // the threshold is the detector's running one (no sigma due), the frame's ring copy is the kernel's job
-            c->d_thr = &c->d_state->thr;
+        if (c->lean_direct) {  // the threshold is the detector's running one (or, sigma due, what the short chain just made), the ring copy is the kernel's job
+            if (!c->lean_due) c->d_thr = &c->d_state->thr;
             c->read_seq += 1;
             if (c->read_seq == 0) c->read_seq = 1;
             copy_dst = LeanArgs{c->d_ring + (size_t)(t_base % c->R) * c->HW, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
@@ -1194,8 +1234,8 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         if (sl.seq_no == 0) sl.seq_no = 1;
         sl.seq_armed = c->lean_poll;
         SingleResult R{sl.h_off, sl.h_nraw, sl.h_litcount, sl.h_gap, sl.h_fscal, (int4*)sl.h_lines, sl.d_fscal,
-                       c->lean_direct ? c->d_state : nullptr, sl.seq_armed ? sl.h_seq : nullptr, sl.seq_no,
-                       1, sl.d_bandflag, (unsigned)(nb * c->WW)};
+                       (c->lean_direct && !c->lean_due) ? c->d_state : nullptr, sl.seq_armed ? sl.h_seq : nullptr, sl.seq_no,
+                       1, sl.d_bandflag, (unsigned)(nb * c->WW), sl.d_sums};
         sl.lean_clean = true;
         const size_t lds_single = std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned));
         if (P.dbg_phase) hipLaunchKernelGGL(k_hough_single<true>, dim3(1), dim3(HOUGH3_THREADS), lds_single, hstream[0], P, R);
@@ -1555,7 +1595,8 @@ static const uint8_t* lean_direct_source(mdh_ctx* c, const Slot& sl, const uint8
     if (c->cfg.detector != MDH_DET_M3 || c->W % 64 != 0 || c->force_generic || c->force_bytes || c->n < 2 || c->n > 16) return nullptr;
     const int64_t t = c->t + 1;
     const int64_t std_interval = (int64_t)c->cfg.interval * c->n;
-    if (t <= c->n || (std_interval > 0 && t % std_interval == 0)) return nullptr;
+    c->lean_due = t > c->n && std_interval > 0 && t % std_interval == 0;
+    if (t <= c->n || (c->lean_due && !c->lean_due_on)) { c->lean_due = false; return nullptr; }
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, frame) != hipSuccess) {
         (void)hipGetLastError();  // pageable memory: not an error, just not reachable from a kernel
@@ -1585,12 +1626,16 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
     c->lean = true;
     c->stream = c->nstream;
+    c->lean_due = false;
     c->lean_direct = lean_direct_source(c, *sl, frame);
+    if (!c->lean_direct) c->lean_due = false;
     rc = stage_frames(c, *sl, frame, 1, 0);
     if (rc == MDH_OK) rc = retire_frames(c, *sl, 1, 0);
     if (rc == MDH_OK && !c->lean_direct) rc = run_noise(c, *sl, 1);
+    if (rc == MDH_OK && c->lean_direct && c->lean_due) rc = run_noise_direct(c, *sl);
     if (rc == MDH_OK) rc = run_detect(c, *sl, 1);
     c->lean = false;
+    c->lean_due = false;
     const bool direct = c->lean_direct != nullptr;
     c->lean_direct = nullptr;
     if (rc != MDH_OK) return poison(c, rc);

@@ -3071,6 +3071,7 @@ struct SingleResult {  // the pass's result block in (pinned, device-visible) HO
     int clean;                    // (row / frame lit counts and the bounding box are reached through HoughParams)
     unsigned* blockcnt;
     unsigned n_blockcnt;
+    long long* sums;              // the slot's noise sums [0..1]: left at zero (a due frame on the direct path accumulates into them)
 };
 template <bool TM>
 __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, SingleResult R) {
@@ -3116,6 +3117,7 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, 
         for (int e = tid; e < P.H; e += HOUGH3_THREADS) ((int*)P.rowcount)[e] = 0;
         if (tid == 0) ((int*)P.litcount)[0] = 0;
         if (tid < 4) ((int*)P.bbox)[tid] = 0;
+        if (tid < 2 && R.sums) R.sums[tid] = 0;
         for (unsigned e = tid; e < R.n_blockcnt / 4; e += HOUGH3_THREADS) ((uint4*)R.blockcnt)[e] = z;
         for (unsigned e = (R.n_blockcnt & ~3u) + tid; e < R.n_blockcnt; e += HOUGH3_THREADS) R.blockcnt[e] = 0;
     }
