@@ -812,7 +812,10 @@ static double ema_next_momentum(mdh_ctx* c) {
 // Stage K frames (absolute timers t_base+1 .. t_base+K): build the pointer table [hist (n-1) | pass frames (K)].
 static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int on_device) {
     const int64_t t_base = sl.t_base;
-    if (!on_device && !c->d_ring) HIPCHK(hipMalloc((void**)&c->d_ring, (size_t)c->R * c->HW));  // first pass from host memory
+    // first pass from host memory: the frame ring is allocated here, once (25 GB for 1080p passes of 2000 frames: not paid by callers
+    // whose frames are resident in HBM).  Like every hipMalloc it synchronises the device -- a one-time stall of whatever other
+    // contexts have in flight (the other one-time cost, the visiting-order tables of mdh_create, is built on a private stream)
+    if (!on_device && !c->d_ring) HIPCHK(hipMalloc((void**)&c->d_ring, (size_t)c->R * c->HW));
     c->h_ptrtab = sl.h_ptrtab;
     for (int e = 0; e < c->n - 1; ++e) c->h_ptrtab[e] = c->hist[e];
     for (int i = 0; i < K; ++i) {

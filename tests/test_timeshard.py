@@ -200,6 +200,30 @@ def test_seek_errors_and_restart():
 
 
 @pytest.mark.gpu
+def test_inject_sums_only_for_due_frames():
+    """mdh_inject_sums: only a frame whose sigma is due (Detector.py:82,87: t > n and t % (interval * n) == 0, or 1 < t <= n) ever
+    looks its entry up, so anything else is refused instead of sitting in the 64-entry table for good; a second entry for the same
+    frame replaces the first; frames already submitted are refused."""
+    from metdetpy_amd import M3Detector, _lib
+    H, W, n = 64, 128, 4
+    mask = np.ones((H, W), np.uint8)
+    frames, cfg = make_case("sky", H, W, n, 8, 3)   # interval 2: due at t = 2, 3, 4 (warm-up) and 8, 16, 24, ...
+    det = M3Detector(n / 10, 10, mask, 10, cfg, None, max_batch=8)
+    ctx = det._ctx
+    for t in (5, 6, 7, 9, 15, 17):
+        with pytest.raises(_lib.MetDetHipError, match="no noise sigma is due"):
+            ctx.inject_sums(t, 1, 2)
+    for _ in range(70):              # far more calls than the table holds: the same frame again replaces its entry
+        ctx.inject_sums(8, 10, 20)
+    ctx.inject_sums(16, 1, 2)
+    ctx.inject_sums(3, 1, 2)
+    det.detect_batch(frames)         # frames 1..8 consumed: their entries are used up
+    with pytest.raises(_lib.MetDetHipError, match="already been submitted"):
+        ctx.inject_sums(8, 1, 2)
+    det.close()
+
+
+@pytest.mark.gpu
 def test_seek_then_resident_frames_at_once():
     """mdh_seek wipes the tagged binaries with device-side fills; the passes submitted right behind it -- frames resident in HBM,
     so nothing delays the first kernels -- must not race those fills (they did: streak frames lost their lit pixels)."""

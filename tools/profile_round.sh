@@ -9,7 +9,9 @@ WL=${2:-C2}
 OUT=gpurun_out/profile_${TAG}_$WL
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --steps 8 --warmup 2 --cpu-seconds 0 --parity-frames 0 --standalone-passes 0"
+ARGS="bench.py --workload $WL --steps 8 --warmup 3 --cpu-seconds 0 --parity-frames 0 --standalone-passes 0 --no-pmc ${EXTRA:-}"
+# (C5 flips to the dense output format after its first collected pass: pinned for the profile so that every launch is the same kernel)
+if [ "$WL" = "C5" ]; then export MDH_DENSE=1; fi
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r --output-format csv -- python $ARGS > "$OUT/stats.log" 2>&1
 # the same passes one at a time (nothing overlaps): the average duration of the window kernel here is what roofline.launch_ms / frac use
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_d1" -o r --output-format csv -- python $ARGS --depth 1 > "$OUT/stats_d1.log" 2>&1
