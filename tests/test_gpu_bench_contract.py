@@ -34,8 +34,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "ONE pass in flight" in r["launch_ms_note"]  # frac is priced on the non-overlapped launch
     assert r["algorithmic_bytes_per_launch"] == 9 * 128 * 1080 * 1920 and r["algorithmic_frac"] > r["frac"]
     assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"] or r["traffic_source"].startswith("live")
-        if r["traffic"] is not None and r["traffic_source"].startswith("live"):  # measured in this run: the kernel moves what it must, not more
-            assert 0.9 < r["traffic_over_compulsory"] < 1.6, r["traffic_over_compulsory"]
+    if r["traffic"] is not None and r["traffic_source"].startswith("live"):  # measured in this run: the kernel moves what it must, not more
+        assert 0.9 < r["traffic_over_compulsory"] < 1.6, r["traffic_over_compulsory"]
     assert set(d["kernels_ms_standalone"]) >= {"stack_threshold", "hough_ppht"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
