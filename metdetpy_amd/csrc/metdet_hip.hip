@@ -200,6 +200,21 @@ struct mdh_ctx {
     bool lean_due = false;                 // the direct frame being queued is one whose noise sigma is due (a short noise chain in front)
     bool lean_due_on = true;               // MDH_LEAN_DUE=0: due frames take the general path (DMA copy, prepare, noise chain) as in round 2
     bool lean_poll = true;                 // MDH_LEAN_POLL=0: wait on the event instead of polling the result block
+    // Window kernel launched ahead of its frame (k_stack_threshold_mail): queued at the end of mdh_update behind the frame's
+    // last launch, resident and waiting on the mailbox when the next frame arrives; the next mdh_update writes the arguments
+    // and the sequence number instead of launching.  Anything else that is about to use the GPU cancels it first.
+    MailBox* h_mail = nullptr;             // pinned
+    unsigned mail_seq = 0;                 // sequence number of the kernel waiting on the mailbox (mail_armed)
+    bool mail_armed = false;
+    bool mail_on = true;                   // MDH_LEAN_MAIL=0: every frame's window kernel is launched by its own mdh_update (A/B)
+    int mail_n = 0;                        // window length the waiting kernel was instantiated for
+    unsigned mail_grid = 0;                // its grid (workgroups)
+    bool mail_used = false;                // the frame being queued went through the mailbox
+    bool lean_entry = false;               // slot_begin is being called by mdh_update
+    int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
+    double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
+    double mail_gap_us = 40;               //   caller is in a tight loop (MDH_LEAN_MAIL_GAP: a waiting kernel spins, so only then)
+    bool tight_loop = false;
     // time-window sharding on a full context: noise sums of due frames supplied by the caller (the frames of a window that
     // restarted empty cannot produce them: mdh_inject_sums), and frames whose Hough stage is skipped (mdh_mute_hough_until)
     std::vector<std::pair<int64_t, std::pair<int64_t, int64_t>>> injected;  // (frame number, (S1, S2)), any order
@@ -297,11 +312,16 @@ static void free_all(mdh_ctx* c) {
                 (long long)c->host_n, c->host_us[0] / c->host_n, c->host_us[1] / c->host_n, c->host_us[2] / c->host_n,
                 c->host_us[3] / c->host_n);
     hipSetDevice(c->device);
+    if (c->mail_armed && c->h_mail) __atomic_store_n(&c->h_mail->line[0][15], ~c->mail_seq, __ATOMIC_RELEASE);  // (mail_cancel is declared further down)
+    if (getenv("MDH_HOST_TRACE") && (c->mail_hits || c->mail_misses))
+        fprintf(stderr, "[mdh host] window kernels launched ahead of their frame: %lld took their frame, %lld cancelled / expired\n",
+                (long long)c->mail_hits, (long long)c->mail_misses);
     hipDeviceSynchronize();
     void* dev[] = {c->d_ring, c->d_hist, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg, c->d_read_count};
     for (void* p : dev)
         if (p) hipFree(p);
     if (c->h_read_flag) hipHostFree(c->h_read_flag);
+    if (c->h_mail) hipHostFree(c->h_mail);
     if (c->h_inject) hipHostFree(c->h_inject);
     for (Slot& s : c->slot) {
         void* sdev[] = {s.d_bbits, s.d_bplain, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr};
@@ -466,7 +486,8 @@ static int create_impl(mdh_ctx* c) {
         if (c->cfg.detector == MDH_DET_M3) TRY(dev_alloc(c->d_act, (size_t)c->R * words));
     }
     TRY(dev_alloc(c->d_state, 1));
-    TRY(dev_alloc(c->d_read_count, 4));
+    TRY(dev_alloc(c->d_read_count, 64 + MAIL_PAYLOAD + 8));  // [0] finished waves of the direct window kernel, [32] the mailbox kernel's go word, [64..] its payload
+    TRY(host_alloc(c->h_mail, 1));
     TRY(host_alloc(c->h_read_flag, 16));
     c->h_read_flag[0] = 0;
     if (pix) TRY(host_alloc(c->h_inject, (size_t)2 * 64 * NSLOT_MAX));  // staging of mdh_inject_sums entries (at most 64 pending)
@@ -682,6 +703,8 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_POLL")) c->lean_poll = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_DUE")) c->lean_due_on = atoi(v) != 0;
+    if (const char* v = getenv("MDH_LEAN_MAIL")) c->mail_on = atoi(v) != 0;
+    if (const char* v = getenv("MDH_LEAN_MAIL_GAP")) c->mail_gap_us = atof(v);
     if (const char* v = getenv("MDH_DENSE")) c->dense_cfg = atoi(v) != 0;
     if (const char* v = getenv("MDH_DENSE_LEAVE")) c->dense_leave = atof(v);
     c->dense_now = c->dense_cfg == 1;
@@ -894,6 +917,33 @@ static void launch_tb(mdh_ctx* c, const PassGeom& g) {
                        c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc);
 }
 
+// The window kernel waiting on the mailbox (if any) is told to leave; it is gone within a poll period, whatever is queued next on
+// the staging stream follows it in order.
+static void mail_cancel(mdh_ctx* c) {
+    if (!c->mail_armed) return;
+    __atomic_store_n(&c->h_mail->line[0][15], ~c->mail_seq, __ATOMIC_RELEASE);
+    c->mail_armed = false;
+    c->mail_misses += 1;
+}
+// Queue the NEXT frame's window kernel (end of mdh_update): n = 2..16, 16 pixels per lane, one chunk -- what launch_wide<N, 16>
+// launches for a direct frame.
+static void mail_prelaunch(mdh_ctx* c) {
+    const int words = (int)c->words;
+    const unsigned grid = (unsigned)(((words + 15) / 16 + 3) / 4);
+    c->mail_seq += 1;
+    if (c->mail_seq == 0 || c->mail_seq == ~0u) c->mail_seq = 1;
+    unsigned* go = c->d_read_count + 32;
+    switch (c->n) {
+#define MAIL_CASE(N) case N: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_mail<N>), dim3(grid, 1), dim3(256), 0, c->nstream, c->h_mail, c->mail_seq, go); break;
+        MAIL_CASE(2) MAIL_CASE(3) MAIL_CASE(4) MAIL_CASE(5) MAIL_CASE(6) MAIL_CASE(7) MAIL_CASE(8) MAIL_CASE(9)
+        MAIL_CASE(10) MAIL_CASE(11) MAIL_CASE(12) MAIL_CASE(13) MAIL_CASE(14) MAIL_CASE(15) MAIL_CASE(16)
+#undef MAIL_CASE
+        default: return;
+    }
+    c->mail_armed = true;
+    c->mail_n = c->n;
+    c->mail_grid = grid;
+}
 template <int N, int PPL>
 static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     const int words = (int)c->words;
@@ -922,9 +972,37 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     }
     const int Tc = (g.K + nchunks - 1) / nchunks;
     nchunks = (g.K + Tc - 1) / Tc;
-    if (lean.copy_dst)  // per-frame protocol: its own instantiation, the batched one pays nothing for it
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
-                           c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean, (unsigned long long*)nullptr);
+    if (lean.copy_dst) {  // per-frame protocol: its own instantiation, the batched one pays nothing for it
+        if (c->mail_armed && PPL == 16 && c->mail_n == N && nchunks == 1 && c->mail_grid == (unsigned)((waves + 3) / 4) && wpb == 4 &&
+            c->stream == c->nstream && __atomic_load_n(&c->h_mail->state, __ATOMIC_ACQUIRE) != ~c->mail_seq) {
+            // the kernel is waiting (or about to be resident): hand it the frame
+            unsigned pay[MAIL_PAYLOAD] = {0};
+            MailArgs a{};
+            // the kernel reads the pass's pointer table from the payload's copy in device memory, not across the bus
+            a.ptrtab = (const uint8_t* const*)(c->d_read_count + 64 + MAIL_ARG_DW);
+            a.thr_tab = c->d_thr; a.bbits = c->d_bbits; a.blockcnt = c->d_bandflag; a.g = g; a.Tc = Tc; a.lean = lean;
+            memcpy(pay, &a, sizeof(a));
+            memcpy(pay + MAIL_ARG_DW, c->h_ptrtab, sizeof(uint8_t*) * (size_t)(N - 1 + 1));
+            constexpr int nch = (MAIL_ARG_DW + 2 * N + 14) / 15;
+            for (int ch = 0; ch < nch; ++ch) memcpy((void*)&c->h_mail->line[ch][0], pay + 15 * ch, 60);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            for (int ch = nch - 1; ch >= 0; --ch) __atomic_store_n(&c->h_mail->line[ch][15], c->mail_seq, __ATOMIC_RELEASE);
+            c->mail_armed = false;
+            // Taken or given up?  The kernel decides once (one lane) and says so: the frame's other launches are only queued
+            // behind a window kernel that IS working on the frame.  (The wait is a bus round trip while the frame's 2 MB start
+            // to cross it; a kernel that has not become resident yet answers when it has; one that expired a moment ago has
+            // answered already.)
+            unsigned st;
+            while ((st = __atomic_load_n(&c->h_mail->state, __ATOMIC_ACQUIRE)) != c->mail_seq && st != ~c->mail_seq) __builtin_ia32_pause();
+            c->mail_used = st == c->mail_seq;
+            if (c->mail_used) c->mail_hits += 1; else c->mail_misses += 1;
+        } else {
+            mail_cancel(c);
+        }
+        if (!c->mail_used)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
+                               c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean, (unsigned long long*)nullptr);
+    }
     else if (PPL == 16 && c->win_dense)  // dense output format: 16-pixels-per-lane variants only (its own instantiation as well)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, 16, false, true>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
                            c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
@@ -1416,6 +1494,7 @@ extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, 
 // Take the next slot for a pass of K frames.  The slot's previous pass must have been collected.
 static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     if (K < 1 || K > c->Kmax) { set_err("pass size must be 1..max_batch"); return MDH_E_ARG; }
+    if (!c->lean_entry) mail_cancel(c);  // (mdh_update decides for itself whether the waiting window kernel gets its frame)
     if (c->in_flight >= c->nslot) { set_err("the maximum number of passes is already in flight: collect one first"); return MDH_E_STATE; }
     Slot& sl = c->slot[c->next_slot];
     if (sl.busy) { set_err("internal: slot still busy"); return MDH_E_STATE; }
@@ -1623,15 +1702,23 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     if (c->pending) { set_err("mdh_update: previous frame not yet consumed by mdh_detect"); return MDH_E_STATE; }
     if (c->in_flight) { set_err("mdh_update: collect the submitted passes first"); return MDH_E_STATE; }
     CHECK_POISON(c, "mdh_update");
+    // a caller that comes back within a few dozen microseconds of the last results is in a tight loop (the reference's, fed from
+    // memory); one that decodes video between frames is not, and gets no kernel spinning on its behalf
+    c->tight_loop = c->t_detect_ret > 0 && now_us() - c->t_detect_ret < c->mail_gap_us;
     HIPCHK(hipSetDevice(c->device));
     Slot* sl = nullptr;
     int rc;
-    if ((rc = slot_begin(c, 1, sl)) != MDH_OK) return rc;
+    c->lean_entry = true;
+    rc = slot_begin(c, 1, sl);
+    c->lean_entry = false;
+    if (rc != MDH_OK) return rc;
     c->lean = true;
     c->stream = c->nstream;
     c->lean_due = false;
+    c->mail_used = false;
     c->lean_direct = lean_direct_source(c, *sl, frame);
     if (!c->lean_direct) c->lean_due = false;
+    if (!c->lean_direct || c->lean_due || c->prof) mail_cancel(c);  // copies / noise launches / timing events come first on the staging stream
     rc = stage_frames(c, *sl, frame, 1, 0);
     if (rc == MDH_OK) rc = retire_frames(c, *sl, 1, 0);
     if (rc == MDH_OK && !c->lean_direct) rc = run_noise(c, *sl, 1);
@@ -1643,6 +1730,13 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     c->lean_direct = nullptr;
     if (rc != MDH_OK) return poison(c, rc);
     slot_commit(c, *sl);
+    // The next frame's window kernel goes behind this frame's last launch (k_stack_threshold_mail) when the next frame can be
+    // expected to take the same path: this one did, and no sigma is due for the next (a due frame's noise chain runs in front of
+    // its window kernel).  Queued here, its launch costs the host 3 us of the 45 the frame needs to cross the bus.
+    if (direct && c->mail_on && c->tight_loop && c->lean_poll && c->prof_every == 0 && c->cfg.detector == MDH_DET_M3) {
+        const int64_t t_next = c->t + 1, std_interval = (int64_t)c->cfg.interval * c->n;
+        if (!(std_interval > 0 && t_next % std_interval == 0)) mail_prelaunch(c);
+    }
     // the caller may reuse `frame` after return
     bool read_seen = false;
     if (direct && c->lean_poll) {
@@ -1665,7 +1759,9 @@ extern "C" int mdh_detect(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, 
     CHECK_POISON(c, "mdh_detect");
     HIPCHK(hipSetDevice(c->device));
     c->pending = false;
-    return collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
+    const int rc = collect_pass(c, info, raw_lines, nms_lines, nonline, nullptr);
+    c->t_detect_ret = now_us();
+    return rc;
 }
 
 extern "C" int mdh_process_batch(mdh_ctx* c, const uint8_t* frames, int K, int on_device, mdh_frame_info* info,
@@ -2016,6 +2112,7 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
     if (c->in_flight || c->pending || c->band_slot) { set_err("mdh_seek: collect / finish the passes in flight first"); return MDH_E_STATE; }
     if (t0 < 0 || ema_updates < 0) { set_err("mdh_seek: negative position"); return MDH_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
+    mail_cancel(c);
     HIPCHK(hipDeviceSynchronize());
     c->t = t0;
     c->injected.clear();
@@ -2119,6 +2216,7 @@ extern "C" int mdh_get_binary(mdh_ctx* c, int index, int stage, uint8_t* out) {
     if (index < 0) index = sl.K - 1;
     if (index >= sl.K) { set_err("mdh_get_binary: index beyond the last pass"); return MDH_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
+    mail_cancel(c);
     const int total = (int)c->HW;
     if (stage == 0) {
         hipLaunchKernelGGL(k_expand_bits, dim3((total + 255) / 256), dim3(256), 0, c->stream, sl.d_dst + (size_t)index * c->words,

@@ -420,11 +420,11 @@ __device__ __forceinline__ void lean_wave_done(const LeanArgs& lean, unsigned to
         }
     }
 }
-template <int N, int PPL, bool LEAN, bool DENSE = false>
-__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
+template <int N, int PPL, bool LEAN, bool DENSE>
+__device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
-                                                              unsigned* __restrict__ blockcnt, PassGeom g, int Tc,
-                                                              LeanArgs lean, unsigned long long* __restrict__ nzwords) {
+                                                              unsigned* __restrict__ blockcnt, const PassGeom& g, int Tc,
+                                                              const LeanArgs& lean, unsigned long long* __restrict__ nzwords) {
     // DENSE (its own instantiation: the sparse one must not pay a register for it; batched passes on streams whose binaries are dense: 8K at m3det_high, where the lowered threshold lets noise
     // through and 9 % of the words carry a bit): EVERY word of b is written, plainly -- u64 [K][H][WW] in the same buffer, no
     // tags, no block counters, 128 contiguous bytes per wave and frame -- and k_morph_close_plain reads it.  The sparse-tagged
@@ -759,6 +759,112 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uin
     if constexpr (DENSE) {
         if (nzwords != nullptr && lane == 0 && nz_mine) atomicAdd(nzwords, (unsigned long long)nz_mine);
     }
+}
+template <int N, int PPL, bool LEAN, bool DENSE = false>
+__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
+                                                              const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
+                                                              unsigned* __restrict__ blockcnt, PassGeom g, int Tc,
+                                                              LeanArgs lean, unsigned long long* __restrict__ nzwords) {
+    stack_threshold_wide_body<N, PPL, LEAN, DENSE>(ptrtab, thr_tab, bbits, blockcnt, g, Tc, lean, nzwords);
+}
+
+// The per-frame protocol's window kernel, launched AHEAD of its frame (round 3).  A frame's chain used to start with the host's
+// launch call and the command processor's dispatch -- 3 us of host time plus 3-5 us until the first wave runs, with the GPU
+// idle: in the reference's loop nothing else is in flight.  mdh_update now queues the NEXT frame's window kernel behind the
+// current frame's last launch; it becomes resident when that launch ends (while the host still unpacks the results) and waits
+// for a MAILBOX in pinned host memory.  The next mdh_update does its bookkeeping as before and then, instead of launching,
+// writes the kernel's arguments and a sequence number into the mailbox: the first loads of the frame are a PCIe poll period
+// away.  One lane of workgroup (0, 0) polls the host word (2000 waves polling across the bus would saturate it) and republishes
+// it in a device word the other workgroups poll.  The kernel gives up -- cancelled by the host (anything that is not the
+// expected direct frame: a batched pass, a frame in pageable memory, get_binary, destroy ...) or after MAIL_EXPIRE_US without a
+// frame -- and says so in the mailbox; the decision is taken by that one lane, so a frame is never processed twice.
+struct MailArgs {
+    const uint8_t* const* ptrtab;
+    const int* thr_tab;
+    ActWord* bbits;
+    unsigned* blockcnt;
+    PassGeom g;
+    int Tc;
+    LeanArgs lean;
+};
+// Mailbox layout: MAIL_CHUNKS lines of 64 bytes, each [15 payload dwords | tag].  The host writes the payload -- the kernel's
+// arguments, then the pass's pointer table (n entries) -- and then every used line's tag = sequence number; the device reads a
+// line with one 64-byte bus read, so a line whose tag is right carries its payload (x86 stores become visible in order): seeing
+// the frame costs the kernel ONE bus round trip, arguments and table included.  `~s` in line 0's tag cancels kernel s.
+#define MAIL_CHUNKS 8
+#define MAIL_PAYLOAD (15 * MAIL_CHUNKS)
+struct __attribute__((aligned(64))) MailBox {
+    unsigned line[MAIL_CHUNKS][16];  // host -> kernel
+    unsigned state;                  // kernel -> host: `s` = taken, `~s` = given up (expired or cancelled)
+    unsigned pad1[15];
+};
+#define MAIL_ARG_DW ((int)((sizeof(MailArgs) + 7) / 8) * 2)  // dwords of the arguments in the payload (the table follows, 8-byte aligned)
+#define MAIL_EXPIRE_TICKS 15000  // 150 us of the 100 MHz wall clock
+template <int N>
+__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* __restrict__ mail, unsigned seq, unsigned* __restrict__ go) {
+    // go[0]: the sequence number republished in device memory; go[32 ..]: the payload, copied across the bus ONCE by the polling
+    // wave (2000 waves fetching their arguments from host memory themselves made the kernel 70 us slower than the launch it
+    // replaces; an agent-scope acquire per wave behind the poll, 13 us: 2000 L2 invalidations)
+    __shared__ unsigned s_go;
+    constexpr int NCH = (MAIL_ARG_DW + 2 * N + 14) / 15;  // lines in use
+    static_assert(NCH <= MAIL_CHUNKS, "mailbox too small");
+    unsigned* const dpay = go + 32;
+    if (threadIdx.x < 64) {
+        unsigned v = 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            const int lane = threadIdx.x;
+            const unsigned* src = &mail->line[0][0];
+            unsigned w0 = 0, w1 = 0;  // dwords lane and 64 + lane of the mailbox
+            const long long t0 = wall_clock64();
+            // two reads of the mailbox in flight, half a bus round trip apart: a frame is seen on average a quarter of a round
+            // trip after it was written instead of a half
+            unsigned n0 = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned n1 = __hip_atomic_load(src + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_s_sleep(12);
+            for (;;) {
+                const unsigned m0 = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned m1 = __hip_atomic_load(src + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w0 = n0; w1 = n1;  // (the older pair: the compiler waits for it with the younger pair still in flight)
+                n0 = m0; n1 = m1;
+                const bool tag_lane = (lane & 15) == 15;
+                const u64 ok0 = __ballot(tag_lane && w0 == seq), ok1 = __ballot(tag_lane && w1 == seq);
+                const unsigned tag0 = __builtin_amdgcn_readlane(w0, 15);
+                // tags of lines 0 .. NCH-1: lanes 15, 31, 47, 63 of w0, then of w1
+                int good = 0;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) good += (int)(((ch < 4 ? ok0 : ok1) >> (16 * (ch & 3) + 15)) & 1);
+                if (good == NCH) { v = seq; break; }
+                if (tag0 == ~seq) { v = ~seq; break; }
+                if (wall_clock64() - t0 > MAIL_EXPIRE_TICKS) { v = ~seq; break; }
+            }
+            if (v == seq) {  // payload dword p of line ch sits at mailbox dword 16 ch + p -> device dword 15 ch + p
+                if ((lane & 15) != 15) __hip_atomic_store(dpay + 15 * (lane >> 4) + (lane & 15), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((lane & 15) != 15) __hip_atomic_store(dpay + 15 * (4 + (lane >> 4)) + (lane & 15), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_store(go, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&mail->state, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else if (threadIdx.x == 0) {
+            for (;;) {
+                v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == seq || v == ~seq) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        if (threadIdx.x == 0) s_go = v;
+    }
+    __syncthreads();
+    if (s_go != seq) return;
+    // (no cache maintenance: nothing of this kernel has read the payload's lines before the poll ended, the poller wrote them
+    // through, and the lines a previous frame's kernel may have left in this XCD's L2 went at this kernel's dispatch)
+    asm volatile("" ::: "memory");
+    const MailArgs* a = (const MailArgs*)dpay;
+    const PassGeom g = a->g;
+    const LeanArgs lean = a->lean;
+    // (a->ptrtab is the host's to set: the table's copy behind the arguments, dpay + MAIL_ARG_DW)
+    stack_threshold_wide_body<N, 16, true, false>(a->ptrtab, a->thr_tab, a->bbits, a->blockcnt, g, a->Tc, lean, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -96,6 +96,52 @@ def test_m3_per_frame_from_pinned_memory(shape, n):
     run_pair([s.next() for _ in range(30)], 4, np.ones(shape2, np.uint8), binary_cfg("normal"), pinned=True)
 
 
+@pytest.mark.parametrize("n", [4, 8, 16])
+def test_m3_per_frame_window_kernel_launched_ahead(n, monkeypatch):
+    """The window kernel of the NEXT frame is queued by mdh_update behind the current frame's launches and waits on a mailbox in
+    pinned host memory (k_stack_threshold_mail); the next mdh_update hands it its arguments instead of launching.  Forced on for
+    every frame here (the library only does it for callers in a tight loop): results as on every other path, with get_binary
+    between the frames (cancels the waiting kernel: run_pair asks for the pre-mask binary), with a pause longer than the
+    kernel's patience (it expires, the frame is launched the usual way), and straight through (the hand-over itself)."""
+    import ctypes
+    import time
+    monkeypatch.setenv("MDH_LEAN_MAIL_GAP", "1e12")
+    shape = (72, 192)
+    mask = np.ones(shape, np.uint8)
+    s = SkyStream(*shape, 77 + n, speed=5, streak_period=11, streak_life=7)
+    run_pair([s.next() for _ in range(3 * n + 30)], n, mask, binary_cfg("normal"), pinned=True)
+    # no get_binary in between: the waiting kernel takes its frame; every 7th frame comes late
+    cfg = binary_cfg("normal")
+    s = SkyStream(*shape, 177 + n, speed=5, streak_period=11, streak_life=7)
+    frames = np.stack([s.next() for _ in range(3 * n + 40)])
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
+    pool = det._ctx.host_alloc(frames.nbytes)
+    ctypes.memmove(pool, frames.ctypes.data, frames.nbytes)
+    pinned = np.ctypeslib.as_array((ctypes.c_uint8 * frames.nbytes).from_address(pool)).reshape(frames.shape)
+    got = []
+    for t, f in enumerate(pinned):
+        if t % 7 == 6:
+            time.sleep(0.002)
+        det.update(f)
+        lines, pred = det.detect()
+        got.append((int(det._ctx._info1[0]["bi_threshold"]), int(det._ctx._info1[0]["lit_count"]), det.linesp_ext.reshape(-1, 4).copy(),
+                    np.asarray(lines).reshape(-1, 4).copy()))
+    total = 0
+    for t, f in enumerate(frames):
+        orc.update(f)
+        o_lines, _ = orc.detect()
+        thr, lit, raw, nms = got[t]
+        assert thr == orc.bi_threshold and lit == orc.lit_count, f"frame {t}"
+        assert np.array_equal(raw, (orc.raw_lines if orc.lines_num <= 500 else orc.raw_lines[:0]).reshape(-1, 4)), f"frame {t}: raw"
+        assert np.array_equal(nms, np.asarray(o_lines).reshape(-1, 4)), f"frame {t}: NMS lines"
+        total += len(o_lines)
+    assert total > 0
+    del pinned
+    det._ctx.host_free(pool)
+    det.close()
+
+
 def test_m3_per_frame_pinned_interleaved_with_batches():
     """Batched passes leave the slots in the state k_pass_prepare expects, per-frame passes in the clean-after-use state:
     a detector that alternates between the two protocols must keep producing the oracle's results."""
