@@ -2985,19 +2985,44 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
         h3_scan(w_size, total, fix + 32, lane, wave);
         if (total > cell_cap && cell_cap > 0) {
             // The corner windows do not fit.  A streak is thin and usually oblique, so the rho range its points really span is
-            // up to a third smaller than what the corners of its bounding box span: one sweep over the point list (the cost
-            // of voting every point once) gives the exact window of every angle.
-            int rmin = 0x7FFFFFFF, rmax = -0x7FFFFFFF;
-            if (tid < NUM_ANGLE) {
-                int p = 0;
-                for (; p + 4 <= N; p += 4) {
-                    const uint4 q = *(const uint4*)&list[p];
-                    const int r0 = rho_bin(q.x & 0xFFFF, q.x >> 16, tc, ts, 0), r1 = rho_bin(q.y & 0xFFFF, q.y >> 16, tc, ts, 0);
-                    const int r2 = rho_bin(q.z & 0xFFFF, q.z >> 16, tc, ts, 0), r3 = rho_bin(q.w & 0xFFFF, q.w >> 16, tc, ts, 0);
-                    rmin = min(min(rmin, min(r0, r1)), min(r2, r3));
-                    rmax = max(max(rmax, max(r0, r1)), max(r2, r3));
+            // up to a third smaller than what the corners of its bounding box span.  Round 2 swept the point list for the exact
+            // window of every angle (the cost of voting every point once: 40 of a 2100-point frame's 69 us of set-up); round 3
+            // takes the x-extent of the points per band of HB_ROWS rows (one LDS min / max per point, all threads) and lets every
+            // angle walk the bands' boxes instead of the points: rho is monotone in x and in y -- also in float32, rounding is
+            // monotone -- so a box's extremes are at two of its corners.  The windows come out at most HB_ROWS - 1 rows' worth
+            // of rho wider than the exact ones (a superset is all the replay needs); the cells region is free until it is
+            // initialised below and serves as scratch.
+            constexpr int HB_ROWS = 8;
+            const int nhb = (rows + HB_ROWS - 1) / HB_ROWS;
+            unsigned* const bmin = cells;
+            unsigned* const bmax = cells + nhb;
+            if (2 * nhb + HOUGH3_THREADS <= cell_cap / 2) {
+                for (int b = tid; b < nhb; b += HOUGH3_THREADS) { bmin[b] = 0xFFFFu; bmax[b] = 0u; }
+                __syncthreads();
+                for (int p = tid; p < N; p += HOUGH3_THREADS) {
+                    const unsigned q = list[p];
+                    const int b = ((int)(q >> 16) - by0) / HB_ROWS;
+                    atomicMin(&bmin[b], q & 0xFFFFu);
+                    atomicMax(&bmax[b], q & 0xFFFFu);
                 }
-                for (; p < N; ++p) {
+                __syncthreads();
+                if (tid < NUM_ANGLE) {
+                    int rmin = 0x7FFFFFFF, rmax = -0x7FFFFFFF;
+                    const bool cpos = tc >= 0.f, spos = ts >= 0.f;
+                    for (int b = 0; b < nhb; ++b) {
+                        const int x_lo = (int)bmin[b], x_hi = (int)bmax[b];
+                        if (x_lo > x_hi) continue;  // (no point in this band: the same test for every thread)
+                        const int y_lo = by0 + b * HB_ROWS, y_hi = min(y_lo + HB_ROWS - 1, by1);
+                        rmin = min(rmin, rho_bin(cpos ? x_lo : x_hi, spos ? y_lo : y_hi, tc, ts, 0));
+                        rmax = max(rmax, rho_bin(cpos ? x_hi : x_lo, spos ? y_hi : y_lo, tc, ts, 0));
+                    }
+                    w_lo = rmin;
+                    w_size = rmax - rmin + 1;
+                }
+                __syncthreads();  // (the scratch is read for the last time above; the size search below reuses it)
+            } else if (tid < NUM_ANGLE) {  // (no room for the boxes: the exact sweep)
+                int rmin = 0x7FFFFFFF, rmax = -0x7FFFFFFF;
+                for (int p = 0; p < N; ++p) {
                     const unsigned q = list[p];
                     const int r = rho_bin(q & 0xFFFF, q >> 16, tc, ts, 0);
                     rmin = min(rmin, r);
@@ -3011,15 +3036,33 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
         }
         if (total > cell_cap) {
             // still too many: the smallest windows first (the angles across the streak, where the votes pile up) -- the largest
-            // size limit that fits; the other angles use the pooled global accumulator
-            int lo = 0, hi = P.numrho;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                int sum;
-                h3_scan(w_size <= mid ? w_size : 0, sum, fix + 32, lane, wave);
-                if (sum <= cell_cap) lo = mid; else hi = mid - 1;
+            // size limit that fits; the other angles use the pooled global accumulator.  Every thread adds up the windows not
+            // larger than its own (180 LDS reads, one barrier) instead of a bisection with a workgroup-wide scan per step.
+            unsigned* const wsz = cells;
+            if (HOUGH3_THREADS + 1 <= cell_cap / 2) {
+                wsz[tid] = (unsigned)w_size;
+                if (tid == 0) wsz[HOUGH3_THREADS] = 0;
+                __syncthreads();
+                int mine = 0;
+                for (int j = 0; j < NUM_ANGLE; ++j) {
+                    const int wj = (int)wsz[j];
+                    mine += wj <= w_size ? wj : 0;
+                }
+                if (tid < NUM_ANGLE && mine <= cell_cap) atomicMax(&wsz[HOUGH3_THREADS], (unsigned)w_size);
+                __syncthreads();
+                const int lo = (int)wsz[HOUGH3_THREADS];
+                placed = w_size <= lo ? w_size : 0;
+                __syncthreads();
+            } else {
+                int lo = 0, hi = P.numrho;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    int sum;
+                    h3_scan(w_size <= mid ? w_size : 0, sum, fix + 32, lane, wave);
+                    if (sum <= cell_cap) lo = mid; else hi = mid - 1;
+                }
+                placed = w_size <= lo ? w_size : 0;
             }
-            placed = w_size <= lo ? w_size : 0;
         }
     }
     const int off = h3_scan(placed, total, fix + 32, lane, wave);
@@ -3059,8 +3102,40 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
                 e[0] = (unsigned)tid; e[1] = (unsigned)w_lo; e[2] = (unsigned)w_size; e[3] = 0;
             }
             __syncthreads();
+            // Round 3: the bound of an angle is a HISTOGRAM of its window, and the LDS behind the placed windows has room for one
+            // (16-bit counters, two per dword: what did not fit the windows of ALL angles fits one at a time): LDS atomics
+            // instead of a sweep of global atomics, a wait for them, a read-back through the L2 and a sweep of stores to leave
+            // the pooled accumulator all-zero (17-20 of a 4K streak frame's 44 us of set-up).  An angle whose window does not
+            // fit even alone keeps the global sweep.
+            unsigned* const hist = pub + HOUGH3_THREADS;
+            const int hist_dw = (int)(P.lds_bytes / 4) - (int)(hist - lds);
+            bool any_global = false;
+            for (int k = 0; k < cnt; ++k) {
+                const int a = (int)pub[4 * k], lo = (int)pub[4 * k + 1], size = (int)pub[4 * k + 2];
+                const int need = (size + 1) >> 1;
+                if (need > hist_dw) { any_global = true; continue; }  // (the same decision in every thread)
+                const float ca = P.trig[2 * a], sa = P.trig[2 * a + 1];
+                for (int d = tid; d < need; d += HOUGH3_THREADS) hist[d] = 0;
+                __syncthreads();
+                for (int p = tid; p < N; p += HOUGH3_THREADS) {
+                    const unsigned pt = list[p];
+                    const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)(pt & 0xFFFF), ca), __fmul_rn((float)(pt >> 16), sa))) - lo;
+                    atomicAdd(&hist[r >> 1], 1u << (16 * (r & 1)));
+                }
+                __syncthreads();
+                unsigned m = 0;
+                for (int d = tid; d < need; d += HOUGH3_THREADS) {
+                    const unsigned v = hist[d];
+                    m = max(m, max(v & 0xFFFFu, v >> 16));
+                }
+                m = wave_max_u32(m);
+                if (lane == 0 && m) atomicMax(&pub[4 * k + 3], m);
+                __syncthreads();
+            }
+            if (any_global) {
             for (int k = 0; k < cnt; ++k) {
                 const int a = (int)pub[4 * k];
+                if ((((int)pub[4 * k + 2] + 1) >> 1) <= hist_dw) continue;
                 const float ca = P.trig[2 * a], sa = P.trig[2 * a + 1];
                 int* row = acc_base + (size_t)a * P.numrho;
                 for (int p = tid; p < N; p += HOUGH3_THREADS) {
@@ -3072,16 +3147,20 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
             __syncthreads();  // every thread's atomics have been performed at the L2
             for (int k = 0; k < cnt; ++k) {
                 const int a = (int)pub[4 * k], lo = (int)pub[4 * k + 1], size = (int)pub[4 * k + 2];
+                if (((size + 1) >> 1) <= hist_dw) continue;
                 const int* row = acc_base + (size_t)a * P.numrho;
                 int m = 0;
                 for (int r = tid; r < size; r += HOUGH3_THREADS) m = max(m, (int)ld_l2((const unsigned*)&row[lo + r]));
                 m = (int)wave_max_u32((unsigned)m);
                 if (lane == 0 && m) atomicMax(&pub[4 * k + 3], (unsigned)m);
             }
+            }
             __syncthreads();
             if (mine && rank >= r0 && rank < r0 + cnt) C.dead = (int)pub[4 * (rank - r0) + 3] < P.threshold;
+            if (any_global) {
             for (int k = 0; k < cnt; ++k) {  // back to all-zero: the replay (or the next frame in this slot) starts from there
                 const int a = (int)pub[4 * k];
+                if ((((int)pub[4 * k + 2] + 1) >> 1) <= hist_dw) continue;
                 const float ca = P.trig[2 * a], sa = P.trig[2 * a + 1];
                 int* row = acc_base + (size_t)a * P.numrho;
                 for (int p = tid; p < N; p += HOUGH3_THREADS) {
@@ -3090,6 +3169,7 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();
         }
         if (n_out > 0) {
