@@ -500,7 +500,7 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(h.d_nz_orig, (size_t)h.pool_list * HW, false));
         TRY(dev_alloc(h.d_nz_work, (size_t)h.pool_list * HW, false));
         TRY(dev_alloc(h.d_tier_list, (size_t)HOUGH_TIERS * K));
-        TRY(dev_alloc(h.d_tier_count, HOUGH_TIERS));
+        TRY(dev_alloc(h.d_tier_count, HOUGH_TIERS + 4));  // (+ the work queue's head of k_hough3_big)
     }
     if (hough) TRY(perm_table(c->device, &c->d_perm));
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
@@ -1360,13 +1360,21 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         // frame that lives in LDS), so their launch goes first and the large-LDS launch runs BESIDE it on a stream of its own
         // instead of in front of it: the stage then lasts as long as its longest frame, not as the sum of the tiers' tails.
         // (MDH_HOUGH_SPLIT=0: round-2a order, large -> hybrid -> one-wave on one stream.)
-        static const bool split = !(getenv("MDH_HOUGH_SPLIT") && atoi(getenv("MDH_HOUGH_SPLIT")) == 0);
+        static const bool split_env = !(getenv("MDH_HOUGH_SPLIT") && atoi(getenv("MDH_HOUGH_SPLIT")) == 0);
+        // MDH_HOUGH_BIG=0: hybrid and large-LDS frames as two launches side by side (round 2 / early round 3) instead of one launch
+        // with a work queue (k_hough3_big)
+        static const bool big = !(getenv("MDH_HOUGH_BIG") && atoi(getenv("MDH_HOUGH_BIG")) == 0);
+        const bool split = split_env && !(big && !c->lean);
         hipStream_t lstream = split ? hs.stream[2] : hstream[1];
-        if (!c->lean && !split) {
+        if (!c->lean && !split && !big) {
             tier(1);
             launch_h3(false, std::min(K, grid_l), hstream[1]);
         }
         tier(2);
+        if (big && !c->lean) {
+            if (P.dbg_phase) hipLaunchKernelGGL(k_hough3_big<true>, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+            else hipLaunchKernelGGL(k_hough3_big<false>, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+        } else
         launch_h3(true, std::min(K, hs.pool), hstream[1]);
         tier(3);
         hipLaunchKernelGGL(k_hough_ppht, dim3(std::min(K, hs.pool_list)), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned),

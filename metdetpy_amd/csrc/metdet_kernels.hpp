@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(1024) k_pack_lines(const int4* __restrict__ li
     if (threadIdx.x < 2) off[K + 1 + threadIdx.x] = nzwords ? (int)nzwords[threadIdx.x] : 0;  // words of b with set bits (u64)
     // the routing counters of the Hough set: every launch that read them is done (this kernel runs behind them), so they are
     // left at zero for the set's next pass -- one memset command per pass less on the Hough stream
-    if (tier_count && threadIdx.x < HOUGH_TIERS) tier_count[threadIdx.x] = 0;
+    if (tier_count && threadIdx.x < HOUGH_TIERS + 1) tier_count[threadIdx.x] = 0;  // (+ the work queue's head of k_hough3_big)
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3237,6 +3237,28 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_hybrid(HoughParams P)
     const int count = *P.fcount;
     for (int j = blockIdx.x; j < count; j += gridDim.x) {
         hough3_frame<true, TM>(P, P.flist[j], blockIdx.x, lds_dyn);
+        __syncthreads();
+    }
+}
+
+// Tiers 2 and 1 in ONE launch with a work queue (round 3).  Both want a whole CU's LDS, and a 4K pass has more such frames than
+// the machine has CUs (164 hybrid + 188 large-LDS frames in a 1000-frame pass of the bench stream).  As two launches side by side
+// they shared the CUs as the dispatcher saw fit: the large-LDS launch usually got there first, most hybrid frames -- the longest,
+// 330 us against 150 -- started a round late, and the stage lasted 0.63 ms for 0.34 ms' worth of CU time.  Here every workgroup
+// takes the next frame from one queue, hybrid frames first (longest first), so the short frames fill in behind the long ones.
+template <bool TM>
+__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3_big(HoughParams P) {
+    __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int c2 = P.tier_count[2], c1 = P.tier_count[1];
+    for (;;) {  // (the queue index travels through the first dynamic LDS word: the launch takes the whole 160 KB, a static word more would not fit)
+        if (threadIdx.x == 0) lds_dyn[0] = (unsigned)atomicAdd(&P.tier_count[HOUGH_TIERS], 1);
+        __syncthreads();
+        const int q = (int)lds_dyn[0];
+        __syncthreads();
+        if (q < c2) hough3_frame<true, TM>(P, P.tier_list[2 * P.K + q], blockIdx.x, lds_dyn);
+        else if (q - c2 < c1) hough3_frame<false, TM>(P, P.tier_list[1 * P.K + (q - c2)], 0, lds_dyn);
+        else break;
         __syncthreads();
     }
 }
