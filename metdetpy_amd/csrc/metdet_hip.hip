@@ -210,6 +210,7 @@ struct mdh_ctx {
     int mail_n = 0;                        // window length the waiting kernel was instantiated for
     unsigned mail_grid = 0;                // its grid (workgroups)
     bool mail_used = false;                // the frame being queued went through the mailbox
+    bool mail_next = false;                // the next frame's window kernel will be queued behind the frame being queued
     bool lean_entry = false;               // slot_begin is being called by mdh_update
     int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
     double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
@@ -917,6 +918,11 @@ static void launch_tb(mdh_ctx* c, const PassGeom& g) {
                        c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc);
 }
 
+// MDH_LEAN_MAIL_CLEAN=0: k_hough_single keeps cleaning up behind its own results (A/B)
+static bool mail_clean_on() {
+    static const bool on = !(getenv("MDH_LEAN_MAIL_CLEAN") && atoi(getenv("MDH_LEAN_MAIL_CLEAN")) == 0);
+    return on;
+}
 // The window kernel waiting on the mailbox (if any) is told to leave; it is gone within a poll period, whatever is queued next on
 // the staging stream follows it in order.
 static void mail_cancel(mdh_ctx* c) {
@@ -927,19 +933,20 @@ static void mail_cancel(mdh_ctx* c) {
 }
 // Queue the NEXT frame's window kernel (end of mdh_update): n = 2..16, 16 pixels per lane, one chunk -- what launch_wide<N, 16>
 // launches for a direct frame.
-static void mail_prelaunch(mdh_ctx* c) {
+static void mail_prelaunch(mdh_ctx* c, const MailClean& cl) {
     const int words = (int)c->words;
     const unsigned grid = (unsigned)(((words + 15) / 16 + 3) / 4);
     c->mail_seq += 1;
     if (c->mail_seq == 0 || c->mail_seq == ~0u) c->mail_seq = 1;
     unsigned* go = c->d_read_count + 32;
     switch (c->n) {
-#define MAIL_CASE(N) case N: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_mail<N>), dim3(grid, 1), dim3(256), 0, c->nstream, c->h_mail, c->mail_seq, go); break;
+#define MAIL_CASE(N) case N: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_mail<N>), dim3(grid, 1), dim3(256), 0, c->nstream, c->h_mail, c->mail_seq, go, cl); break;
         MAIL_CASE(2) MAIL_CASE(3) MAIL_CASE(4) MAIL_CASE(5) MAIL_CASE(6) MAIL_CASE(7) MAIL_CASE(8) MAIL_CASE(9)
         MAIL_CASE(10) MAIL_CASE(11) MAIL_CASE(12) MAIL_CASE(13) MAIL_CASE(14) MAIL_CASE(15) MAIL_CASE(16)
 #undef MAIL_CASE
         default: return;
     }
+    if (hipGetLastError() != hipSuccess) return;  // (not queued: the next frame is launched the usual way)
     c->mail_armed = true;
     c->mail_n = c->n;
     c->mail_grid = grid;
@@ -993,7 +1000,18 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
             // to cross it; a kernel that has not become resident yet answers when it has; one that expired a moment ago has
             // answered already.)
             unsigned st;
-            while ((st = __atomic_load_n(&c->h_mail->state, __ATOMIC_ACQUIRE)) != c->mail_seq && st != ~c->mail_seq) __builtin_ia32_pause();
+            const double t_spin = now_us();
+            for (int spin = 0;; ++spin) {
+                st = __atomic_load_n(&c->h_mail->state, __ATOMIC_ACQUIRE);
+                if (st == c->mail_seq || st == ~c->mail_seq) break;
+                __builtin_ia32_pause();
+                if ((spin & 4095) == 4095 && now_us() - t_spin > 2e6) {  // (a kernel that neither takes its frame nor expires: the device is gone)
+                    set_err("the window kernel waiting for this frame does not answer");
+                    c->poisoned = true;
+                    st = ~c->mail_seq;
+                    break;
+                }
+            }
             c->mail_used = st == c->mail_seq;
             if (c->mail_used) c->mail_hits += 1; else c->mail_misses += 1;
         } else {
@@ -1316,7 +1334,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         sl.seq_armed = c->lean_poll;
         SingleResult R{sl.h_off, sl.h_nraw, sl.h_litcount, sl.h_gap, sl.h_fscal, (int4*)sl.h_lines, sl.d_fscal,
                        (c->lean_direct && !c->lean_due) ? c->d_state : nullptr, sl.seq_armed ? sl.h_seq : nullptr, sl.seq_no,
-                       1, sl.d_bandflag, (unsigned)(nb * c->WW), sl.d_sums};
+                       c->mail_next && mail_clean_on() ? 0 : 1, sl.d_bandflag, (unsigned)(nb * c->WW), sl.d_sums};  // (mail_next: the waiting window kernel cleans up)
         sl.lean_clean = true;
         const size_t lds_single = std::max<size_t>(P.lds_bytes, (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned));
         if (P.dbg_phase) hipLaunchKernelGGL(k_hough_single<true>, dim3(1), dim3(HOUGH3_THREADS), lds_single, hstream[0], P, R);
@@ -1727,6 +1745,14 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     c->lean_direct = lean_direct_source(c, *sl, frame);
     if (!c->lean_direct) c->lean_due = false;
     if (!c->lean_direct || c->lean_due || c->prof) mail_cancel(c);  // copies / noise launches / timing events come first on the staging stream
+    // Will the next frame's window kernel be queued behind this frame (decided here: k_hough_single then leaves the slot's
+    // clean-up to it)?  This frame takes the direct path, the caller is in a tight loop, and no sigma is due for the next frame
+    // (a due frame's noise chain runs in front of its window kernel).
+    c->mail_next = false;
+    if (c->lean_direct && c->mail_on && c->tight_loop && c->lean_poll && c->prof_every == 0 && !c->prof && c->cfg.detector == MDH_DET_M3) {
+        const int64_t t_next = c->t + 2, std_interval = (int64_t)c->cfg.interval * c->n;  // (c->t counts the frames before this one)
+        c->mail_next = !(std_interval > 0 && t_next % std_interval == 0);
+    }
     rc = stage_frames(c, *sl, frame, 1, 0);
     if (rc == MDH_OK) rc = retire_frames(c, *sl, 1, 0);
     if (rc == MDH_OK && !c->lean_direct) rc = run_noise(c, *sl, 1);
@@ -1741,9 +1767,19 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     // The next frame's window kernel goes behind this frame's last launch (k_stack_threshold_mail) when the next frame can be
     // expected to take the same path: this one did, and no sigma is due for the next (a due frame's noise chain runs in front of
     // its window kernel).  Queued here, its launch costs the host 3 us of the 45 the frame needs to cross the bus.
-    if (direct && c->mail_on && c->tight_loop && c->lean_poll && c->prof_every == 0 && c->cfg.detector == MDH_DET_M3) {
-        const int64_t t_next = c->t + 1, std_interval = (int64_t)c->cfg.interval * c->n;
-        if (!(std_interval > 0 && t_next % std_interval == 0)) mail_prelaunch(c);
+    if (c->mail_next) {
+        const size_t nbk = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
+        MailClean cl{sl->d_rowcount, sl->d_litcount, sl->d_bbox, sl->d_sums, sl->d_bandflag, (unsigned)(nbk * c->WW), c->H};
+        if (!mail_clean_on()) cl.blockcnt = nullptr;
+        mail_prelaunch(c, cl);
+        if (!c->mail_armed && mail_clean_on()) {  // (could not be queued: the clean-up k_hough_single skipped, as plain fills)
+            HIPCHK(hipMemsetAsync(sl->d_bandflag, 0, sizeof(unsigned) * nbk * c->WW, c->nstream));
+            HIPCHK(hipMemsetAsync(sl->d_rowcount, 0, sizeof(int) * c->H, c->nstream));
+            HIPCHK(hipMemsetAsync(sl->d_litcount, 0, sizeof(int), c->nstream));
+            HIPCHK(hipMemsetAsync(sl->d_bbox, 0, sizeof(int) * 4, c->nstream));
+            if (sl->d_sums) HIPCHK(hipMemsetAsync(sl->d_sums, 0, sizeof(long long) * 2, c->nstream));
+        }
+        c->mail_next = false;
     }
     // the caller may reuse `frame` after return
     bool read_seen = false;

@@ -799,9 +799,28 @@ struct __attribute__((aligned(64))) MailBox {
     unsigned pad1[15];
 };
 #define MAIL_ARG_DW ((int)((sizeof(MailArgs) + 7) / 8) * 2)  // dwords of the arguments in the payload (the table follows, 8-byte aligned)
+// What k_hough_single zeroes behind its results (clean-after-use) the waiting kernel can zero instead, in front of its poll and
+// with every workgroup: the previous frame's last launch then ends with its results, and this kernel is resident that much earlier.
+struct MailClean {
+    int* rowcount;   // [H]
+    int* litcount;   // [1]
+    int* bbox;       // [4]
+    long long* sums; // [2] (may be null)
+    unsigned* blockcnt;
+    unsigned n_blockcnt;
+    int H;
+};
 #define MAIL_EXPIRE_TICKS 15000  // 150 us of the 100 MHz wall clock
 template <int N>
-__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* __restrict__ mail, unsigned seq, unsigned* __restrict__ go) {
+__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* __restrict__ mail, unsigned seq, unsigned* __restrict__ go, MailClean cl) {
+    if (cl.blockcnt != nullptr) {  // the previous frame's slot, left as a fresh one's (that frame's launches are done: same stream)
+        const unsigned gt = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, gn = gridDim.x * gridDim.y * blockDim.x;
+        for (unsigned e = gt; e < cl.n_blockcnt; e += gn) cl.blockcnt[e] = 0;
+        for (unsigned e = gt; e < (unsigned)cl.H; e += gn) cl.rowcount[e] = 0;
+        if (gt == 0) cl.litcount[0] = 0;
+        if (gt < 4) cl.bbox[gt] = 0;
+        if (gt < 2 && cl.sums) cl.sums[gt] = 0;
+    }
     // go[0]: the sequence number republished in device memory; go[32 ..]: the payload, copied across the bus ONCE by the polling
     // wave (2000 waves fetching their arguments from host memory themselves made the kernel 70 us slower than the launch it
     // replaces; an agent-scope acquire per wave behind the poll, 13 us: 2000 L2 invalidations)
