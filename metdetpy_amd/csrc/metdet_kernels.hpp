@@ -384,6 +384,9 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_U16_BIGN
 #define WIDE_U16_BIGN WIDE_U16  // the same for windows of more than 8 frames (A/B builds: -DWIDE_U16_BIGN=2: 16 registers less at n = 16)
 #endif
+#ifndef LEAN_AUX
+#define LEAN_AUX 0  // cache policy bits of the per-frame window kernel's loads (A/B builds: 1 = sc0, 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#endif
 #ifndef WIDE_MAX3
 #define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
 #endif
@@ -478,9 +481,9 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     auto fetch = [&](int e) -> dvec {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
         if constexpr (PPL == 16) {
-            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : 0));
         } else {
-            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : 0));
         }
     };
     auto unpack = [&](const dvec& d, PK (&p)[RW]) {
