@@ -1641,6 +1641,13 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
     std::vector<int32_t> tmp_l(4 * MAX_LINES);
     std::vector<double> tmp_p(MAX_LINES);
     for (int i = 0; i < K; ++i) {
+        // (the caller's arrays are [K][MAX_LINES] strided: a frame with segments touches three cold lines 8-16 KB apart; asked for a
+        // few frames ahead they arrive side by side -- the unpacking of a 4000-frame pass is otherwise a chain of 4000 cache misses)
+        if (i + 6 < K && sl.h_nraw[i + 6] > 0) {
+            if (raw_lines) __builtin_prefetch(raw_lines + (size_t)(i + 6) * MAX_LINES * 4, 1);
+            if (nms_lines) __builtin_prefetch(nms_lines + (size_t)(i + 6) * MAX_LINES * 4, 1);
+            if (nonline) __builtin_prefetch(nonline + (size_t)(i + 6) * MAX_LINES, 1);
+        }
         const int n_raw = sl.h_nraw[i];
         const int stored = std::min(n_raw, MAX_LINES);
         const int32_t* L = sl.h_lines + (size_t)sl.h_off[i] * 4;
