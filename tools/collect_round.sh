@@ -20,6 +20,8 @@ python bench.py --batch 250 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch250.json 2
 python bench.py --host-input --cpu-seconds 0 --steps 200 > $O/${TAG}_bench_C2_host_input.json 2> $O/err_host
 python bench.py --protocol per-frame --cpu-seconds 0 > $O/${TAG}_bench_per_frame_protocol.json 2> $O/err_pf
 python tools/bench_per_frame.py > $O/${TAG}_per_frame_protocol.json 2>> $O/err_pf
+# kernel trace of the per-frame loop (the window kernel launched ahead of its frame shows up as k_stack_threshold_mail)
+(export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $O/pf_stats -o r --output-format csv -- python bench.py --protocol per-frame --steps 3000 --cpu-seconds 0 --parity-frames 0 > $O/pf_stats.log 2>&1; cp $(find $O/pf_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_rocprofv3_kernel_stats_per_frame.csv 2>/dev/null)
 timeout 600 python bench.py --mode bands --workload C5 --unique 50 --batch 500 --cpu-seconds 0 > $O/${TAG}_bench_mode_bands_C5_8bands_one_gpu.json 2> $O/err_bands
 python bench.py --mode timeshard --cpu-seconds 0 > $O/${TAG}_bench_mode_timeshard_C2_8windows_one_gpu.json 2> $O/err_ts
 python bench.py --mode timeshard --host-input --steps 16 --cpu-seconds 0 > $O/${TAG}_bench_mode_timeshard_C2_host_input.json 2>> $O/err_ts
