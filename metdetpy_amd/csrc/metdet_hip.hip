@@ -108,6 +108,7 @@ struct Slot {
     // (lean_clean: the slot is in that state now; was_clean: it was when the pass being queued took it), and announces its
     // results through a word in the pinned result block that the host polls
     bool lean_clean = true, was_clean = false;
+    bool was_lean = false;  // the slot's previous pass was a per-frame one (everything on the staging stream)
     unsigned* h_seq = nullptr;
     unsigned seq_no = 0;
     bool seq_armed = false;
@@ -212,6 +213,7 @@ struct mdh_ctx {
     bool mail_used = false;                // the frame being queued went through the mailbox
     bool mail_next = false;                // the next frame's window kernel will be queued behind the frame being queued
     bool lean_entry = false;               // slot_begin is being called by mdh_update
+    bool lean_commit = false;              // slot_commit is being called by mdh_update
     int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
     double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
     double mail_gap_us = 40;               //   caller is in a tight loop (MDH_LEAN_MAIL_GAP: a waiting kernel spins, so only then)
@@ -1528,7 +1530,10 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     // Consecutive passes alternate between two main streams, so the next window kernel fills the machine while the last
     // workgroups of the previous one drain (+4 % once the post stages had streams of their own; MDH_MAIN_STREAMS=1 for A/B).
     c->stream = c->mstream[c->pass_seq % c->nmain];
-    if (sl.used) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    // (a per-frame pass runs on the staging stream alone, behind the slot's previous pass if that was a per-frame one too; the
+    // event of a previous BATCHED pass -- recorded on a Hough stream -- is waited for by the staging stream instead: mdh_update)
+    if (sl.used && !c->lean_entry) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    if (sl.used && c->lean_entry && !sl.was_lean) HIPCHK(hipStreamWaitEvent(c->nstream, sl.ev_done, 0));
     c->prof = c->prof_every > 0 && c->pass_seq % c->prof_every == 0;
     sl.K = K;
     sl.t_base = c->t;
@@ -1547,7 +1552,8 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     sl.was_clean = sl.lean_clean;
     sl.lean_clean = false;
     sl.seq_armed = false;
-    if (getenv("MDH_TAG_PASS")) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
+    static const bool tag_pass = getenv("MDH_TAG_PASS") != nullptr;
+    if (tag_pass) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
     c->cur_spans = &sl.spans;
     c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr;
     c->d_bandflag = sl.d_bandflag; c->d_bbits = sl.d_bbits;
@@ -1555,6 +1561,7 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     return MDH_OK;
 }
 static void slot_commit(mdh_ctx* c, Slot& sl) {
+    sl.was_lean = c->lean_commit;
     sl.busy = true;
     sl.used = true;
     c->t += sl.K;
@@ -1638,8 +1645,8 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
         HIPCHK(hipStreamSynchronize(c->cstream));
     }
     const double t2 = now_us();
-    std::vector<int32_t> tmp_l(4 * MAX_LINES);
-    std::vector<double> tmp_p(MAX_LINES);
+    std::vector<int32_t> tmp_l(nms_lines ? 0 : 4 * MAX_LINES);  // (only a caller that does not want the NMS output needs somewhere to put it)
+    std::vector<double> tmp_p(nonline ? 0 : MAX_LINES);
     for (int i = 0; i < K; ++i) {
         // (the caller's arrays are [K][MAX_LINES] strided: a frame with segments touches three cold lines 8-16 KB apart; asked for a
         // few frames ahead they arrive side by side -- the unpacking of a 4000-frame pass is otherwise a chain of 4000 cache misses)
@@ -1770,7 +1777,9 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     const bool direct = c->lean_direct != nullptr;
     c->lean_direct = nullptr;
     if (rc != MDH_OK) return poison(c, rc);
+    c->lean_commit = true;
     slot_commit(c, *sl);
+    c->lean_commit = false;
     // The next frame's window kernel goes behind this frame's last launch (k_stack_threshold_mail) when the next frame can be
     // expected to take the same path: this one did, and no sigma is due for the next (a due frame's noise chain runs in front of
     // its window kernel).  Queued here, its launch costs the host 3 us of the 45 the frame needs to cross the bus.
