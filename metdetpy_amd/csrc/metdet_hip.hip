@@ -133,6 +133,7 @@ struct HoughSet {
     int last_slot = -1;  // slot of the pass that used the set last
 };
 
+struct HostPool { uintptr_t base, bytes, dev; };
 struct mdh_ctx {
     int device = 0;
     int role = MDH_ROLE_FULL;
@@ -214,6 +215,7 @@ struct mdh_ctx {
     bool mail_next = false;                // the next frame's window kernel will be queued behind the frame being queued
     bool lean_entry = false;               // slot_begin is being called by mdh_update
     bool lean_commit = false;              // slot_commit is being called by mdh_update
+    std::vector<HostPool> host_pools;      // pinned pools handed out by mdh_host_alloc: [base, base + bytes) and the device-visible base
     int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
     double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
     double mail_gap_us = 40;               //   caller is in a tight loop (MDH_LEAN_MAIL_GAP: a waiting kernel spins, so only then)
@@ -1719,6 +1721,14 @@ static const uint8_t* lean_direct_source(mdh_ctx* c, const Slot& sl, const uint8
     const int64_t std_interval = (int64_t)c->cfg.interval * c->n;
     c->lean_due = t > c->n && std_interval > 0 && t % std_interval == 0;
     if (t <= c->n || (c->lean_due && !c->lean_due_on)) { c->lean_due = false; return nullptr; }
+    for (const HostPool& hp : c->host_pools)
+        if ((uintptr_t)frame >= hp.base && (uintptr_t)frame + c->HW <= hp.base + hp.bytes) {
+            const uintptr_t dp = hp.dev + ((uintptr_t)frame - hp.base);
+            if (dp & 15) return nullptr;
+            for (int e = 0; e < c->n - 1; ++e)
+                if ((uintptr_t)c->hist[e] & 15) return nullptr;
+            return (const uint8_t*)dp;
+        }
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, frame) != hipSuccess) {
         (void)hipGetLastError();  // pageable memory: not an error, just not reachable from a kernel
@@ -2333,12 +2343,20 @@ extern "C" void* mdh_host_alloc(mdh_ctx* c, uint64_t bytes) {
         set_err("mdh_host_alloc: hipHostMalloc failed");
         return nullptr;
     }
+    // (the per-frame protocol asks for a frame's device-visible address at every mdh_update: a pool the library handed out is
+    // answered from this list instead of by the runtime)
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess && dp) c->host_pools.push_back({(uintptr_t)p, (uintptr_t)bytes, (uintptr_t)dp});
+    else (void)hipGetLastError();
     return p;
 }
 extern "C" int mdh_host_free(mdh_ctx* c, void* p) {
     if (!c) return MDH_E_ARG;
     HIPCHK(hipSetDevice(c->device));
+    mail_cancel(c);
     HIPCHK(hipDeviceSynchronize());
+    for (size_t k = 0; k < c->host_pools.size(); ++k)
+        if (c->host_pools[k].base == (uintptr_t)p) { c->host_pools.erase(c->host_pools.begin() + k); break; }
     HIPCHK(hipHostFree(p));
     return MDH_OK;
 }
