@@ -202,3 +202,20 @@ def test_two_process_gloo_gather(tmp_path):
     assert sorted(int(k) for k in res["merged"]) == [0, 1, 2, 3, 4]
     for k, v in res["merged"].items():
         assert len(v) == int(k) % 3 and all(r["stream"] == int(k) and r["rank"] == int(k) % 2 for r in v)
+
+
+def test_every_environment_switch_is_documented():
+    """The library and the bench read MDH_* switches from the environment (A/B builds of one path, experiments, instrumentation);
+    INTEGRATION.md's table is where a maintainer finds out what each does: none may be missing from it."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for path in glob.glob(os.path.join(root, "metdetpy_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "metdetpy_amd", "*.py")) + [
+            os.path.join(root, "bench.py"), os.path.join(root, "bench_modes.py")]:
+        text = open(path).read()
+        names |= set(re.findall(r'getenv\("(MDH_[A-Z0-9_]+)"', text))
+        names |= set(re.findall(r'environ(?:\.get\(|\[)"(MDH_[A-Z0-9_]+)"', text))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
