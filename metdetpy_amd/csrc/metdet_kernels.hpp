@@ -856,7 +856,8 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* 
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) good += (int)(((ch < 4 ? ok0 : ok1) >> (16 * (ch & 3) + 15)) & 1);
                 if (good == NCH) { v = seq; break; }
-                if (tag0 == ~seq) { v = ~seq; break; }
+                // (cancelled -- or the mailbox already speaks to this kernel's successor: cancelled before it became resident)
+                if (tag0 == ~seq || tag0 == seq + 1 || tag0 == ~(seq + 1)) { v = ~seq; break; }
                 if (wall_clock64() - t0 > MAIL_EXPIRE_TICKS) { v = ~seq; break; }
             }
             if (v == seq) {  // payload dword p of line ch sits at mailbox dword 16 ch + p -> device dword 15 ch + p
