@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s is wha
 WORKLOADS = {
     "C2": dict(H=1080, W=1920, n=8, seed=20220413, batch=4000, desc="synthetic 1920x1080 u8 stream, 8-frame window"),
     "C3": dict(H=2160, W=3840, n=16, seed=20220414, batch=1000, desc="synthetic 3840x2160 u8 stream, 16-frame window + mask"),
-    "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=2000, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
+    "C1s": dict(H=540, W=960, n=8, seed=20220412, batch=16000, desc="synthetic 960x540 u8 stream (runtime size of config 1)"),
     "C5": dict(H=4320, W=7680, n=8, seed=20220415, batch=500, sensitivity="high",
                desc="synthetic 7680x4320 u8 stream, m3det_high thresholds, whole frame on one GPU (no row-band tiling)"),
     "C1e": dict(H=540, W=960, n=8, seed=20220412, batch=500, src=(2160, 3840),
