@@ -32,6 +32,7 @@ extern "C" {
 #define MDH_E_HIP (-2)           /* a HIP runtime call failed */
 #define MDH_E_STATE (-3)         /* call sequence error (detect without update, ...) */
 #define MDH_E_NOMEM (-4)
+#define MDH_E_TIMEOUT (-5)       /* a collect gave up waiting (mdh_set_wait_timeout_ms); the context is poisoned */
 
 #define MDH_DET_M3 0             /* M3Detector.detect       (Detector.py:324-392) */
 #define MDH_DET_CLASSIC 1        /* ClassicDetector.detect  (Detector.py:257-296) */
@@ -50,13 +51,16 @@ extern "C" {
 /* ABI guard.  Both configuration structs start with `struct_size` = sizeof(the struct) as the CALLER's header declares it;
  * mdh_create / mdh_collector_create refuse (NULL, text in mdh_last_error) a struct whose size differs from the library's, so a
  * host compiled against an older header -- or a stale hand-written binding -- fails loudly instead of having fields read from
- * beyond its struct.  mdh_abi_version() is bumped whenever a struct or a prototype changes (2: struct_size fields, round 3). */
-#define MDH_ABI_VERSION 2
+ * beyond its struct.  mdh_abi_version() is bumped whenever a struct or a prototype changes (2: struct_size fields, round 3;
+ * 3: mdh_host_register / mdh_host_unregister / mdh_set_auto_register / mdh_update_stats, round 4). */
+#define MDH_ABI_VERSION 3
 int mdh_abi_version(void);
 /* The library runs a pass on up to ten HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
  * read once when the runtime initialises.  The library never modifies the process environment: export GPU_MAX_HW_QUEUES=12
  * before the first HIP call for full overlap.  Returns the value the environment holds (0 = unset).  Results never depend on it. */
 int mdh_hw_queues_hint(void);
+/* hipSetDevice(device) for hosts without a HIP binding of their own (the RCCL communicator binds to the current device). */
+int mdh_set_device(int device);
 
 typedef struct mdh_cfg {
     uint32_t struct_size;        /* sizeof(mdh_cfg): checked first by mdh_create */
@@ -157,7 +161,22 @@ int mdh_device_copy(mdh_ctx* ctx, void* dst_device, const void* src_device, uint
 /* Pinned host memory for frames handed over with on_device = 0: the H2D copies of a pass then run asynchronously at PCIe
  * speed (from pageable memory they are staged by the runtime). */
 void* mdh_host_alloc(mdh_ctx* ctx, uint64_t bytes);
-int mdh_host_free(mdh_ctx* ctx, void* ptr);
+int mdh_host_free(mdh_ctx* ctx, void* ptr);   /* a pool may be freed through any context of the process, never by hipHostFree directly */
+/* The per-frame protocol reads a frame IN PLACE (no copy in front of the window kernel) when the caller's buffer is memory a
+ * kernel can reach: a pool of mdh_host_alloc, memory the caller pinned itself (hipHostMalloc / hipHostRegister), or ordinary
+ * memory registered here.  The reference's loaders hand over plain NumPy arrays (MetDetPy.py:192; videoloader.py:569-593), and
+ * ProcessVideoLoader recycles a fixed ring of them (a shared RawArray, videoloader.py:696-701, 746-772):
+ *   mdh_host_register(ctx, ring_base, ring_bytes)   once, by a loader that knows its ring;  mdh_host_unregister before freeing it
+ *   mdh_set_auto_register(ctx, 1)  (the default; MDH_AUTO_REGISTER=0 in the environment switches it off): the third time
+ *       mdh_update is handed the same pageable address the library registers that frame buffer itself (at most 64 buffers per
+ *       context, unregistered by mdh_destroy).  A caller that frees such a buffer while the context lives should call
+ *       mdh_host_unregister on it first.
+ * Frames at addresses seen for the first time are copied (H2D from pageable memory) as before; results are identical. */
+int mdh_host_register(mdh_ctx* ctx, void* ptr, uint64_t bytes);
+int mdh_host_unregister(mdh_ctx* ctx, void* ptr);
+int mdh_set_auto_register(mdh_ctx* ctx, int on);
+/* mdh_update so far: frames the window kernel read in place / frames copied first / buffers registered by the library */
+int mdh_update_stats(const mdh_ctx* ctx, int64_t* direct_frames, int64_t* copied_frames, int* auto_registered);
 
 /* Per-kernel timing with HIP events on the context's own stream (off by default).
  * names: MDH_NUM_KERNELS strings; ms / launches: accumulated since the last reset. */
@@ -268,6 +287,10 @@ int mdh_band_collect(mdh_ctx* ctx, mdh_frame_info* info);   /* waits for the old
 int mdh_chain(mdh_ctx* producer, int producer_stream, mdh_ctx* consumer, int consumer_stream);
 int mdh_device_copy_on(mdh_ctx* ctx, int which_stream, void* dst_device, const void* src_device, uint64_t bytes);  /* queued */
 int mdh_bands_allreduce_local(mdh_ctx** bands, int n);      /* n band contexts of one process and device, passes staged */
+/* How long mdh_collect_batch / mdh_band_collect / mdh_detect wait for their pass (0, the default: for ever).  A queued pass that
+ * contains a collective never completes when a peer rank has died; with a timeout the wait returns MDH_E_TIMEOUT and poisons the
+ * context -- the host then aborts its communicator (ncclCommAbort releases the stuck kernels) and destroys the context. */
+int mdh_set_wait_timeout_ms(mdh_ctx* ctx, double ms);
 
 /* ---- One stream cut into time windows across GPUs (SURVEY 8e "time windows of one stream") --------------------------
  *

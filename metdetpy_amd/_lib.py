@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MDH_LIB") or os.path.join(_HERE, "libmetdet_hip.so") 
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
-MDH_ABI_VERSION = 2
+MDH_ABI_VERSION = 3
 MDH_HOUGH_EXACT, MDH_HOUGH_ACCUMULATOR = 0, 1
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 MDH_ROLE_FULL, MDH_ROLE_BAND, MDH_ROLE_HOUGH = 0, 1, 2
@@ -78,7 +78,9 @@ EXPORTS = [
     "mdh_collector_create", "mdh_collector_destroy", "mdh_collector_update", "mdh_collector_update_batch", "mdh_collector_events",
     "mdh_collector_active", "mdh_pre_run_batch", "mdh_host_alloc", "mdh_host_free", "mdh_device_copy", "mdh_abi_version", "mdh_hw_queues_hint", "mdh_dense_passes", "mdh_last_density", "mdh_dense_now",
     "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
-    "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes"
+    "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes",
+    "mdh_host_register", "mdh_host_unregister", "mdh_set_auto_register", "mdh_update_stats", "mdh_set_device",
+    "mdh_set_wait_timeout_ms"
 ]
 
 _lib = None
@@ -86,6 +88,31 @@ _lib = None
 
 class MetDetHipError(RuntimeError):
     pass
+
+
+class _HostOnlyLibrary:
+    """MDH_LIB pointing at the host-only sanitizer build (`make -C metdetpy_amd/csrc san`): lineset_nms and the native collector are
+    there, every entry point that needs a GPU is not -- and says so when called (it never computes anything instead)."""
+
+    class _Absent:
+        def __init__(self, name):
+            self.name = name
+
+        def __call__(self, *a, **k):
+            raise MetDetHipError(f"{self.name}: {LIB_PATH} is the host-only (sanitizer) build; it has no GPU entry points")
+
+    def __init__(self, L):
+        self.__dict__["_L"] = L
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self.__dict__["_L"], name)
+        except AttributeError:
+            if not name.startswith("mdh_"):
+                raise
+            stub = self._Absent(name)
+            self.__dict__[name] = stub
+            return stub
 
 
 def load():
@@ -100,6 +127,8 @@ def load():
     # runtime initialises, i.e. at the process's first HIP call).  The library itself never touches the environment.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     L = C.CDLL(LIB_PATH)
+    if not hasattr(L, "mdh_create") and hasattr(L, "mdh_collector_create"):
+        L = _HostOnlyLibrary(L)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
     L.mdh_create.argtypes = [i32, i32, i32, i32, C.POINTER(MdhCfg)]
     L.mdh_create.restype = vp
@@ -121,6 +150,12 @@ def load():
     L.mdh_host_alloc.argtypes = [vp, u64]
     L.mdh_host_alloc.restype = vp
     L.mdh_host_free.argtypes = [vp, vp]
+    L.mdh_set_device.argtypes = [i32]
+    L.mdh_set_wait_timeout_ms.argtypes = [vp, dbl]
+    L.mdh_host_register.argtypes = [vp, vp, u64]
+    L.mdh_host_unregister.argtypes = [vp, vp]
+    L.mdh_set_auto_register.argtypes = [vp, i32]
+    L.mdh_update_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
     L.mdh_device_upload.argtypes = [vp, vp, vp, u64]
     L.mdh_device_copy.argtypes = [vp, vp, vp, u64]
     L.mdh_profile_enable.argtypes = [vp, i32]
@@ -191,6 +226,11 @@ def last_error() -> str:
 def check(rc: int, what: str):
     if rc != 0:
         raise MetDetHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def set_device(device: int):
+    """hipSetDevice for this thread (the RCCL communicator of rccl.py binds to the current device)."""
+    check(load().mdh_set_device(int(device)), "mdh_set_device")
 
 
 def lineset_nms(lines: np.ndarray):
@@ -332,6 +372,27 @@ class Context:
 
     def host_free(self, ptr: int):
         check(self.L.mdh_host_free(self.handle, ptr), "mdh_host_free")
+
+    def host_register(self, arr) -> None:
+        """Register a loader's frame buffers (a NumPy array or (address, nbytes)) so that update() reads frames lying in them in place."""
+        ptr, nbytes = arr if isinstance(arr, tuple) else (arr.__array_interface__["data"][0], arr.nbytes)
+        check(self.L.mdh_host_register(self.handle, ptr, int(nbytes)), "mdh_host_register")
+
+    def host_unregister(self, arr) -> None:
+        ptr = arr[0] if isinstance(arr, tuple) else arr.__array_interface__["data"][0]
+        check(self.L.mdh_host_unregister(self.handle, ptr), "mdh_host_unregister")
+
+    def set_wait_timeout(self, seconds: float) -> None:
+        """Collects give up (MetDetHipError, the context is poisoned) when their pass has not completed after `seconds` (0: never)."""
+        check(self.L.mdh_set_wait_timeout_ms(self.handle, float(seconds) * 1e3), "mdh_set_wait_timeout_ms")
+
+    def set_auto_register(self, on: bool) -> None:
+        check(self.L.mdh_set_auto_register(self.handle, 1 if on else 0), "mdh_set_auto_register")
+
+    def update_stats(self) -> dict:
+        d, c, a = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(self.L.mdh_update_stats(self.handle, C.byref(d), C.byref(c), C.byref(a)), "mdh_update_stats")
+        return {"direct_frames": d.value, "copied_frames": c.value, "auto_registered": a.value}
 
     def device_free(self, ptr: int):
         check(self.L.mdh_device_free(self.handle, ptr), "mdh_device_free")

@@ -21,6 +21,8 @@ frame in one process on one GPU (same code path minus the collectives) for singl
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -377,7 +379,15 @@ class BandedM3Detector:
         self.comm = comm
         if self.comm is None and self._on_gpu and engine is HipBandEngine:
             from . import rccl
-            self.comm = rccl.Communicator.from_torch_dist(dist, self.rank, self.world)  # after the engine: its device is current
+            # (MDH_RCCL_TIMEOUT seconds, default 120: a rank whose peers never arrive raises instead of hanging in ncclCommInitRank)
+            self.comm = rccl.Communicator.from_torch_dist(dist, self.rank, self.world, device=device,
+                                                          timeout_s=float(os.environ.get("MDH_RCCL_TIMEOUT", "120")))
+        if self.comm is not None and engine is HipBandEngine:
+            # a pass that waits on a dead peer's send must not hang collect(): the library gives up after the same time,
+            # collect() then aborts the communicator (which releases the stuck kernels) and raises
+            t = float(os.environ.get("MDH_RCCL_TIMEOUT", "120"))
+            self.engine.band.set_wait_timeout(t)
+            self.engine.hough.set_wait_timeout(t)
         self._send = self._recv = None
         self._xbuf = None
         self._pending, self._seq = [], 0
@@ -481,11 +491,18 @@ class BandedM3Detector:
         get (None, info)."""
         N, r = self.world, self.rank
         K, kp, mine, thr_info, done, _keep = self._pending.pop(0)
-        if thr_info is None:  # queued pass: its thresholds are fetched now (this also frees the band context's slot)
-            thr_info = self.engine.thresholds_collect()
+        try:
+            if thr_info is None:  # queued pass: its thresholds are fetched now (this also frees the band context's slot)
+                thr_info = self.engine.thresholds_collect()
+            if mine and done is None:
+                done = self.engine.hough_collect(kp)
+        except _lib.MetDetHipError:
+            if self.comm is not None:  # timed out (or failed) with collectives queued: release them, then report
+                self.comm.abort()
+            raise
         part = []
         if mine:
-            hi, raw, nms, prob = done if done is not None else self.engine.hough_collect(kp)
+            hi, raw, nms, prob = done
             for j in range(mine):
                 part.append((j * N + r, hi[j].copy(), raw[j, :min(int(hi[j]["n_raw"]), _lib.MDH_MAX_LINES)].copy(),
                              nms[j, :int(hi[j]["n_nms"])].copy(), prob[j, :int(hi[j]["n_nms"])].copy()))

@@ -15,7 +15,7 @@
 // to frame (frame ring, ring of binaries, running scalars) is only touched on the main stream, in stream order.
 #include "metdet_kernels.hpp"
 #include "metdet_pre.hpp"
-#include "metdet_collector.hpp"
+#include "metdet_host.hpp"  // error text, lineset_nms, the native collector: host-only code, also built alone under ASan / UBSan
 
 #include "../../include/metdet_hip.h"
 
@@ -29,8 +29,6 @@
 #include <string>
 #include <vector>
 
-static thread_local std::string g_err;
-static void set_err(const std::string& s) { g_err = s; }
 
 #define HIPCHK(call)                                                                                   \
     do {                                                                                               \
@@ -133,7 +131,22 @@ struct HoughSet {
     int last_slot = -1;  // slot of the pass that used the set last
 };
 
-struct HostPool { uintptr_t base, bytes, dev; };
+// Host memory a kernel can read (the per-frame protocol's direct path): pools handed out by mdh_host_alloc, buffers registered with
+// mdh_host_register, and buffers the library registered itself because a caller kept handing over the same addresses (a loader
+// that recycles a fixed ring of frame buffers: ProcessVideoLoader's shared RawArray, videoloader.py:696-701, 746-772).  One list
+// per PROCESS under a mutex: a pool freed through any context disappears for all of them.
+struct mdh_ctx;
+struct HostPool {
+    uintptr_t base, bytes, dev;
+    int device;
+    int kind;        // 0: mdh_host_alloc, 1: mdh_host_register, 2: registered by the library (auto)
+    mdh_ctx* owner;  // the context that unregisters an auto entry when it is destroyed
+};
+static std::mutex g_pool_mutex;
+static std::vector<HostPool> g_pools;
+#define AUTO_REG_SEEN 32           // addresses remembered while deciding
+#define AUTO_REG_HITS 3            // the third hand-over of an address registers it
+#define AUTO_REG_MAX_BUFFERS 64    // cap per context
 struct mdh_ctx {
     int device = 0;
     int role = MDH_ROLE_FULL;
@@ -215,7 +228,12 @@ struct mdh_ctx {
     bool mail_next = false;                // the next frame's window kernel will be queued behind the frame being queued
     bool lean_entry = false;               // slot_begin is being called by mdh_update
     bool lean_commit = false;              // slot_commit is being called by mdh_update
-    std::vector<HostPool> host_pools;      // pinned pools handed out by mdh_host_alloc: [base, base + bytes) and the device-visible base
+    // buffers in pageable memory seen lately (address, hand-overs): a repeated address is a recycled buffer and gets registered
+    struct { uintptr_t addr; int hits; } reg_seen[AUTO_REG_SEEN] = {};
+    int reg_seen_next = 0;
+    int auto_registered = 0;               // buffers this context registered itself (unregistered by mdh_destroy)
+    bool auto_register_on = true;          // MDH_AUTO_REGISTER=0 / mdh_set_auto_register(ctx, 0)
+    int64_t direct_frames = 0, copied_frames = 0;  // mdh_update: frames read in place by the window kernel / copied first
     int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
     double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
     double mail_gap_us = 40;               //   caller is in a tight loop (MDH_LEAN_MAIL_GAP: a waiting kernel spins, so only then)
@@ -234,6 +252,7 @@ struct mdh_ctx {
     std::vector<hipEvent_t> chain_ev;  // mdh_chain: a ring of events
     size_t chain_next = 0;
     bool poisoned = false;
+    double wait_timeout_ms = 0;  // mdh_set_wait_timeout_ms: how long a collect waits for its pass (0 = for ever)
     // Format of b = (diff > T) between the window kernel and the morphology: sparse + tagged (a quiet sky: nothing is written for
     // 99 % of the wave-frames) or dense + plain (binaries with noise in them: 8K at m3det_high).  Chosen per pass from the share
     // of words with set bits the last collected pass reported (both formats report it); identical results either way.
@@ -266,12 +285,15 @@ struct mdh_ctx {
     int64_t prof_n[MDH_NUM_KERNELS] = {0};
 };
 
-extern "C" const char* mdh_last_error(void) { return g_err.c_str(); }
-extern "C" int mdh_abi_version(void) { return MDH_ABI_VERSION; }
 // GPU_MAX_HW_QUEUES as the process environment has it (0: unset, the runtime's default of 4 applies); the library wants >= 12
 extern "C" int mdh_hw_queues_hint(void) {
     const char* v = getenv("GPU_MAX_HW_QUEUES");
     return v ? atoi(v) : 0;
+}
+// hipSetDevice for host code that has no HIP binding of its own (metdetpy_amd/rccl.py selects the device before ncclCommInitRank)
+extern "C" int mdh_set_device(int device) {
+    HIPCHK(hipSetDevice(device));
+    return MDH_OK;
 }
 extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KERNELS) ? kKernelNames[k] : ""; }
 extern "C" int64_t mdh_frames_seen(const mdh_ctx* c) { return c ? c->t : -1; }
@@ -322,6 +344,18 @@ static void free_all(mdh_ctx* c) {
         fprintf(stderr, "[mdh host] window kernels launched ahead of their frame: %lld took their frame, %lld cancelled / expired\n",
                 (long long)c->mail_hits, (long long)c->mail_misses);
     hipDeviceSynchronize();
+    {   // buffers this context registered on its callers' behalf
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t k = 0; k < g_pools.size();) {
+            if (g_pools[k].owner == c && g_pools[k].kind == 2) {
+                if (hipHostUnregister((void*)g_pools[k].base) != hipSuccess) (void)hipGetLastError();  // (the caller may have freed it already)
+                g_pools.erase(g_pools.begin() + k);
+            } else {
+                if (g_pools[k].owner == c) g_pools[k].owner = nullptr;
+                ++k;
+            }
+        }
+    }
     void* dev[] = {c->d_ring, c->d_hist, c->d_zero, c->d_state, c->d_act, c->d_trig, c->d_hdbg, c->d_expand, c->d_xchg, c->d_read_count};
     for (void* p : dev)
         if (p) hipFree(p);
@@ -710,6 +744,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_LEAN_DUE")) c->lean_due_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_MAIL")) c->mail_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_MAIL_GAP")) c->mail_gap_us = atof(v);
+    if (const char* v = getenv("MDH_AUTO_REGISTER")) c->auto_register_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_DENSE")) c->dense_cfg = atoi(v) != 0;
     if (const char* v = getenv("MDH_DENSE_LEAVE")) c->dense_leave = atof(v);
     c->dense_now = c->dense_cfg == 1;
@@ -997,7 +1032,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
             constexpr int nch = (MAIL_ARG_DW + 2 * N + 14) / 15;
             for (int ch = 0; ch < nch; ++ch) memcpy((void*)&c->h_mail->line[ch][0], pay + 15 * ch, 60);
             __atomic_thread_fence(__ATOMIC_RELEASE);
-            for (int ch = nch - 1; ch >= 0; --ch) __atomic_store_n(&c->h_mail->line[ch][15], c->mail_seq, __ATOMIC_RELEASE);
+            for (int ch = nch - 1; ch >= 0; --ch) __atomic_store_n(&c->h_mail->line[ch][15], mail_line_tag(pay + 15 * ch, c->mail_seq), __ATOMIC_RELEASE);
             c->mail_armed = false;
             // Taken or given up?  The kernel decides once (one lane) and says so: the frame's other launches are only queued
             // behind a window kernel that IS working on the frame.  (The wait is a bus round trip while the frame's 2 MB start
@@ -1012,6 +1047,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
                 if ((spin & 4095) == 4095 && now_us() - t_spin > 2e6) {  // (a kernel that neither takes its frame nor expires: the device is gone)
                     set_err("the window kernel waiting for this frame does not answer");
                     c->poisoned = true;
+                    __atomic_store_n(&c->h_mail->line[0][15], ~c->mail_seq, __ATOMIC_RELEASE);  // a kernel that turns up late gives up
                     st = ~c->mail_seq;
                     break;
                 }
@@ -1478,49 +1514,6 @@ static int retire_frames(mdh_ctx* c, Slot& sl, int K, int on_device) {
     return MDH_OK;
 }
 
-extern "C" int mdh_lineset_nms(const int32_t* lines, int n, int32_t* out_lines, double* nonline) {
-    // utils.py:780-839.  Order: squared length descending; ties: later index first (stable ascending sort, reversed).
-    if (n <= 0) return 0;
-    std::vector<int64_t> len2(n);
-    std::vector<int> order(n);
-    for (int i = 0; i < n; ++i) {
-        const int64_t dx = (int64_t)lines[4 * i + 2] - lines[4 * i], dy = (int64_t)lines[4 * i + 3] - lines[4 * i + 1];
-        len2[i] = dx * dx + dy * dy;
-        order[i] = i;
-    }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len2[a] < len2[b]; });
-    std::reverse(order.begin(), order.end());
-    std::vector<char> taken(n, 0);
-    int kept = 0;
-    for (int pos = 0; pos < n; ++pos) {
-        const int p = order[pos];
-        if (taken[p]) continue;
-        taken[p] = 1;
-        const int32_t* L = lines + 4 * p;
-        const int64_t A = (int64_t)L[3] - L[1], B = (int64_t)L[0] - L[2], C = (int64_t)L[2] * L[1] - (int64_t)L[3] * L[0];
-        const int64_t pcx = ((int64_t)L[2] + L[0]) >> 1, pcy = ((int64_t)L[3] + L[1]) >> 1;  // floor //2
-        int64_t widest = 0;
-        for (int qp = pos; qp < n; ++qp) {
-            const int q = order[qp];
-            if (taken[q]) continue;
-            const int32_t* M = lines + 4 * q;
-            const int64_t qcx = ((int64_t)M[2] + M[0]) >> 1, qcy = ((int64_t)M[3] + M[1]) >> 1;
-            const int64_t d2 = (pcx - qcx) * (pcx - qcx) + (pcy - qcy) * (pcy - qcy);
-            if (d2 < len2[p] / 4) {
-                taken[q] = 1;
-                widest = std::max<int64_t>(widest, std::llabs(A * qcx + B * qcy + C));
-            }
-        }
-        if (out_lines) memcpy(out_lines + 4 * kept, L, 4 * sizeof(int32_t));
-        if (nonline) {
-            const double v = (double)widest / std::sqrt((double)(A * A + B * B)) / std::sqrt((double)len2[p]) * 2;
-            nonline[kept] = v > 1 ? 1 : v;
-        }
-        ++kept;
-    }
-    return kept;
-}
-
 // Take the next slot for a pass of K frames.  The slot's previous pass must have been collected.
 static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     if (K < 1 || K > c->Kmax) { set_err("pass size must be 1..max_batch"); return MDH_E_ARG; }
@@ -1582,6 +1575,41 @@ static int poison(mdh_ctx* c, int rc) {
         return MDH_E_STATE;                                                                              \
     }
 
+// Wait for a pass's completion event.  A pass that contains a collective (row bands over RCCL) never completes when a peer has
+// died; with a timeout set the wait gives up, poisons the context and says so -- the host then aborts its communicator, which
+// releases the stuck kernels, and destroys the context.
+static int wait_event(mdh_ctx* c, hipEvent_t ev, const char* who) {
+    if (!(c->wait_timeout_ms > 0)) {
+        HIPCHK(hipEventSynchronize(ev));
+        return MDH_OK;
+    }
+    const double t0 = now_us();
+    for (int spin = 0;; ++spin) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return MDH_OK;
+        if (e != hipErrorNotReady) {
+            set_err(std::string(who) + ": hipEventQuery: " + hipGetErrorString(e));
+            return MDH_E_HIP;
+        }
+        (void)hipGetLastError();
+        if (now_us() - t0 > c->wait_timeout_ms * 1e3) {
+            c->poisoned = true;
+            set_err(std::string(who) + ": the pass did not complete within " + std::to_string((long long)c->wait_timeout_ms) +
+                    " ms (a collective whose peer is gone?) -- abort the communicator, then destroy the context");
+            return MDH_E_TIMEOUT;
+        }
+        if (spin > 64) {
+            timespec ts{0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+}
+extern "C" int mdh_set_wait_timeout_ms(mdh_ctx* c, double ms) {
+    if (!c || ms < 0) { set_err("mdh_set_wait_timeout_ms: bad argument"); return MDH_E_ARG; }
+    c->wait_timeout_ms = ms;
+    return MDH_OK;
+}
+
 static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) {
     Slot* sl = nullptr;
     int rc;
@@ -1635,7 +1663,10 @@ static int collect_pass(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_lines, in
             else if ((spin & 1023) == 1023 && now_us() - t_spin > 2000) break;
         }
     }
-    if (!seen) HIPCHK(hipEventSynchronize(sl.ev_done));
+    if (!seen) {
+        const int wrc = wait_event(c, sl.ev_done, "collect");
+        if (wrc != MDH_OK) return wrc;
+    }
     host_log("collect woke", c->pass_seq - c->in_flight);
     const double t1 = now_us();
     spans_collect(c, sl);
@@ -1721,25 +1752,50 @@ static const uint8_t* lean_direct_source(mdh_ctx* c, const Slot& sl, const uint8
     const int64_t std_interval = (int64_t)c->cfg.interval * c->n;
     c->lean_due = t > c->n && std_interval > 0 && t % std_interval == 0;
     if (t <= c->n || (c->lean_due && !c->lean_due_on)) { c->lean_due = false; return nullptr; }
-    for (const HostPool& hp : c->host_pools)
-        if ((uintptr_t)frame >= hp.base && (uintptr_t)frame + c->HW <= hp.base + hp.bytes) {
-            const uintptr_t dp = hp.dev + ((uintptr_t)frame - hp.base);
-            if (dp & 15) return nullptr;
-            for (int e = 0; e < c->n - 1; ++e)
-                if ((uintptr_t)c->hist[e] & 15) return nullptr;
-            return (const uint8_t*)dp;
-        }
+    // sums the caller supplied for this frame (mdh_inject_sums after mdh_seek) are applied by the general path's noise chain only
+    if (c->lean_due && !c->injected.empty()) { c->lean_due = false; return nullptr; }
+    auto usable = [&](uintptr_t dp) -> const uint8_t* {
+        if (dp & 15) return nullptr;
+        for (int e = 0; e < c->n - 1; ++e)
+            if ((uintptr_t)c->hist[e] & 15) return nullptr;
+        return (const uint8_t*)dp;
+    };
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (const HostPool& hp : g_pools)
+            if (hp.device == c->device && (uintptr_t)frame >= hp.base && (uintptr_t)frame + c->HW <= hp.base + hp.bytes)
+                return usable(hp.dev + ((uintptr_t)frame - hp.base));
+    }
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, frame) != hipSuccess) {
-        (void)hipGetLastError();  // pageable memory: not an error, just not reachable from a kernel
+    if (hipPointerGetAttributes(&a, frame) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+        return usable((uintptr_t)a.devicePointer);  // pinned by the caller (hipHostMalloc / hipHostRegister of its own)
+    (void)hipGetLastError();  // pageable memory: not an error, just not reachable from a kernel -- yet
+    // A caller that hands over the same address again and again recycles a fixed set of buffers: the third time round the
+    // buffer is registered (pinned and mapped, ~0.2 ms once) and from then on read in place like a pool of mdh_host_alloc.
+    if (!c->auto_register_on || c->auto_registered >= AUTO_REG_MAX_BUFFERS) return nullptr;
+    int hits = 0;
+    for (auto& e : c->reg_seen)
+        if (e.addr == (uintptr_t)frame) { hits = ++e.hits; break; }
+    if (!hits) {
+        c->reg_seen[c->reg_seen_next] = {(uintptr_t)frame, 1};
+        c->reg_seen_next = (c->reg_seen_next + 1) % AUTO_REG_SEEN;
         return nullptr;
     }
-    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
-    const uintptr_t dp = (uintptr_t)a.devicePointer;
-    if (dp & 15) return nullptr;
-    for (int e = 0; e < c->n - 1; ++e)
-        if ((uintptr_t)c->hist[e] & 15) return nullptr;
-    return (const uint8_t*)dp;
+    if (hits < AUTO_REG_HITS) return nullptr;
+    void* dp = nullptr;
+    if (hipHostRegister((void*)frame, c->HW, hipHostRegisterMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&dp, (void*)frame, 0) != hipSuccess || !dp) {
+        (void)hipGetLastError();
+        for (auto& e : c->reg_seen)
+            if (e.addr == (uintptr_t)frame) e.hits = -(1 << 30);  // (cannot be registered: never asked again)
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_pools.push_back({(uintptr_t)frame, (uintptr_t)c->HW, (uintptr_t)dp, c->device, 2, c});
+    }
+    c->auto_registered += 1;
+    return usable((uintptr_t)dp);
 }
 
 // The reference's per-frame protocol (MetDetPy.py:197-198).  mdh_update queues the WHOLE pass of the frame -- copy, noise /
@@ -1787,6 +1843,7 @@ extern "C" int mdh_update(mdh_ctx* c, const uint8_t* frame) {
     const bool direct = c->lean_direct != nullptr;
     c->lean_direct = nullptr;
     if (rc != MDH_OK) return poison(c, rc);
+    (direct ? c->direct_frames : c->copied_frames) += 1;
     c->lean_commit = true;
     slot_commit(c, *sl);
     c->lean_commit = false;
@@ -1898,6 +1955,7 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     if (!c || !sums_total || !dst_rows) { set_err("mdh_band_pixels: null argument"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_pixels: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
     if (!c->band_slot) { set_err("mdh_band_pixels: call mdh_band_noise first"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_band_pixels");
     if (own_row0 < 0 || own_rows < 1 || own_row0 + own_rows > c->H || rows_stride < own_rows || nsplit < 1 || !(roi_px_total > 0)) {
         set_err("mdh_band_pixels: bad owned rows / stride / split / roi_px_total");
         return MDH_E_ARG;
@@ -1995,6 +2053,7 @@ extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, d
         set_err("mdh_band_pixels_submit: bad owned rows / stride / split / roi_px_total");
         return MDH_E_ARG;
     }
+    CHECK_POISON(c, "mdh_band_pixels_submit");
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = *c->band_slot;
     const int K = sl.K, nj = c->band_nj;
@@ -2032,10 +2091,14 @@ extern "C" int mdh_band_collect(mdh_ctx* c, mdh_frame_info* info) {
     if (!c) { set_err("mdh_band_collect: null context"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_collect: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
     if (c->in_flight <= 0) { set_err("mdh_band_collect: no pass in flight"); return MDH_E_STATE; }
+    CHECK_POISON(c, "mdh_band_collect");
     HIPCHK(hipSetDevice(c->device));
     Slot& sl = c->slot[c->oldest];
     const int K = sl.K;
-    HIPCHK(hipEventSynchronize(sl.ev_done));
+    {
+        const int wrc = wait_event(c, sl.ev_done, "mdh_band_collect");
+        if (wrc != MDH_OK) return wrc;
+    }
     spans_collect(c, sl);
     format_cue(c, sl);
     if (info) {
@@ -2062,6 +2125,12 @@ extern "C" int mdh_chain(mdh_ctx* producer, int pwhich, mdh_ctx* consumer, int c
     if (!producer || !consumer) { set_err("mdh_chain: null context"); return MDH_E_ARG; }
     hipStream_t ps = pick_stream(producer, pwhich), cs = pick_stream(consumer, cwhich);
     if (!ps || !cs) { set_err("mdh_chain: unknown stream designator"); return MDH_E_ARG; }
+    if (producer->device != consumer->device) {  // (the event lives on one device; cross-GPU ordering is the collective's job)
+        set_err("mdh_chain: the two contexts are on different devices");
+        return MDH_E_ARG;
+    }
+    CHECK_POISON(producer, "mdh_chain");
+    CHECK_POISON(consumer, "mdh_chain");
     HIPCHK(hipSetDevice(consumer->device));
     if (consumer->chain_ev.empty()) {
         consumer->chain_ev.resize(64, nullptr);
@@ -2078,6 +2147,7 @@ extern "C" int mdh_device_copy_on(mdh_ctx* c, int which, void* dst, const void* 
     if (!c || !dst || !src) { set_err("mdh_device_copy_on: null argument"); return MDH_E_ARG; }
     hipStream_t st = pick_stream(c, which);
     if (!st) { set_err("mdh_device_copy_on: unknown stream designator"); return MDH_E_ARG; }
+    CHECK_POISON(c, "mdh_device_copy_on");
     HIPCHK(hipSetDevice(c->device));
     // a copy KERNEL, not hipMemcpyAsync: same-device copies of tens of megabytes go through an SDMA engine at ~65 GB/s
     // (8 bands x 8 pieces of 16.6 MB per pass: 16 ms), a grid of waves moves them at HBM speed
@@ -2227,6 +2297,7 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
         set_err(std::string(who) + ": the bands do not cover the frame");
         return MDH_E_ARG;
     }
+    CHECK_POISON(c, "mdh_hough_planes_submit");
     HIPCHK(hipSetDevice(c->device));
     Slot* slp = nullptr;
     int rc;
@@ -2346,8 +2417,10 @@ extern "C" void* mdh_host_alloc(mdh_ctx* c, uint64_t bytes) {
     // (the per-frame protocol asks for a frame's device-visible address at every mdh_update: a pool the library handed out is
     // answered from this list instead of by the runtime)
     void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess && dp) c->host_pools.push_back({(uintptr_t)p, (uintptr_t)bytes, (uintptr_t)dp});
-    else (void)hipGetLastError();
+    if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess && dp) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_pools.push_back({(uintptr_t)p, (uintptr_t)bytes, (uintptr_t)dp, c->device, 0, c});
+    } else (void)hipGetLastError();
     return p;
 }
 extern "C" int mdh_host_free(mdh_ctx* c, void* p) {
@@ -2355,9 +2428,70 @@ extern "C" int mdh_host_free(mdh_ctx* c, void* p) {
     HIPCHK(hipSetDevice(c->device));
     mail_cancel(c);
     HIPCHK(hipDeviceSynchronize());
-    for (size_t k = 0; k < c->host_pools.size(); ++k)
-        if (c->host_pools[k].base == (uintptr_t)p) { c->host_pools.erase(c->host_pools.begin() + k); break; }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t k = 0; k < g_pools.size(); ++k)
+            if (g_pools[k].base == (uintptr_t)p && g_pools[k].kind == 0) { g_pools.erase(g_pools.begin() + k); break; }
+    }
     HIPCHK(hipHostFree(p));
+    return MDH_OK;
+}
+// A loader that owns its frame buffers (a fixed ring in ordinary memory: multiprocessing.RawArray, a NumPy array it refills)
+// registers them once; mdh_update then reads such a frame in place.  Without the call the library finds out by itself the third
+// time an address comes by (mdh_set_auto_register).
+extern "C" int mdh_host_register(mdh_ctx* c, void* p, uint64_t bytes) {
+    if (!c || !p || bytes == 0) { set_err("mdh_host_register: bad argument"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (const HostPool& hp : g_pools)
+            if (hp.device == c->device && (uintptr_t)p < hp.base + hp.bytes && hp.base < (uintptr_t)p + bytes) {
+                set_err("mdh_host_register: the range overlaps memory that is registered already");
+                return MDH_E_STATE;
+            }
+    }
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterMapped));
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) {
+        (void)hipGetLastError();
+        hipHostUnregister(p);
+        set_err("mdh_host_register: the registered range has no device-visible address");
+        return MDH_E_HIP;
+    }
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pools.push_back({(uintptr_t)p, (uintptr_t)bytes, (uintptr_t)dp, c->device, 1, c});
+    return MDH_OK;
+}
+extern "C" int mdh_host_unregister(mdh_ctx* c, void* p) {
+    if (!c || !p) { set_err("mdh_host_unregister: null argument"); return MDH_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    mail_cancel(c);
+    HIPCHK(hipDeviceSynchronize());
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t k = 0; k < g_pools.size(); ++k)
+            if (g_pools[k].base == (uintptr_t)p && g_pools[k].kind != 0) {
+                if (g_pools[k].kind == 2 && g_pools[k].owner) g_pools[k].owner->auto_registered -= 1;
+                g_pools.erase(g_pools.begin() + k);
+                found = true;
+                break;
+            }
+    }
+    if (!found) { set_err("mdh_host_unregister: not a range registered through this library"); return MDH_E_ARG; }
+    HIPCHK(hipHostUnregister(p));
+    return MDH_OK;
+}
+extern "C" int mdh_set_auto_register(mdh_ctx* c, int on) {
+    if (!c) { set_err("mdh_set_auto_register: null context"); return MDH_E_ARG; }
+    c->auto_register_on = on != 0;
+    return MDH_OK;
+}
+extern "C" int mdh_update_stats(const mdh_ctx* c, int64_t* direct_frames, int64_t* copied_frames, int* auto_registered) {
+    if (!c) return MDH_E_ARG;
+    if (direct_frames) *direct_frames = c->direct_frames;
+    if (copied_frames) *copied_frames = c->copied_frames;
+    if (auto_registered) *auto_registered = c->auto_registered;
     return MDH_OK;
 }
 extern "C" int mdh_device_upload(mdh_ctx* c, void* dst, const void* src, uint64_t bytes) {
@@ -2553,69 +2687,3 @@ extern "C" int mdh_frame_sums(int device, const uint8_t* frames, int K, uint64_t
     return MDH_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ native collector
-extern "C" mdh_collector* mdh_collector_create(const mdh_collector_cfg* cfg) {
-    if (!cfg) { set_err("mdh_collector_create: null cfg"); return nullptr; }
-    if (cfg->struct_size != sizeof(mdh_collector_cfg)) {
-        set_err("mdh_collector_create: cfg.struct_size is " + std::to_string(cfg->struct_size) + ", this library's mdh_collector_cfg has " +
-                std::to_string(sizeof(mdh_collector_cfg)) + " bytes: the caller was built against another include/metdet_hip.h");
-        return nullptr;
-    }
-    if (!(cfg->fps > 0) || cfg->num_cls < 2 || cfg->exp_frame < 1 || cfg->runtime_w < 1 || cfg->runtime_h < 1) {
-        set_err("mdh_collector_create: bad configuration");
-        return nullptr;
-    }
-    mdh_collector* c = new mdh_collector();
-    c->cfg = *cfg;
-    c->max_interval = cfg->max_interval * cfg->fps;
-    c->max_acti_frame = (int64_t)(cfg->max_interval * cfg->fps);  // int(): truncation
-    c->thre2 = cfg->thre2 * cfg->exp_frame;
-    c->runtime_length = (double)std::max(cfg->runtime_w, cfg->runtime_h);
-    c->time_prob = mdc::ProbFunc{cfg->time_range[0], cfg->time_range[1]};
-    c->speed_prob = mdc::ProbFunc{cfg->speed_range[0], cfg->speed_range[1]};
-    c->len_prob = mdc::ProbFunc{cfg->min_len, std::numeric_limits<double>::infinity()};
-    c->drct_prob = mdc::ProbFunc{cfg->drct_range[0], cfg->drct_range[1]};
-    return c;
-}
-extern "C" void mdh_collector_destroy(mdh_collector* c) { delete c; }
-extern "C" int mdh_collector_active(const mdh_collector* c) { return c ? (int)c->active.size() : -1; }
-
-extern "C" int mdh_collector_update(mdh_collector* c, int64_t cur_frame, const int32_t* lines, const double* cates, int n) {
-    if (!c || (n > 0 && (!lines || !cates))) { set_err("mdh_collector_update: null argument"); return MDH_E_ARG; }
-    const int rc = c->update(cur_frame, lines, cates, n);
-    if (rc != MDH_OK) set_err("mdh_collector_update: " + c->err);
-    return rc;
-}
-
-extern "C" int mdh_collector_update_batch(mdh_collector* c, int K, int64_t frame0, int64_t it0, int eq_int_fps,
-                                          const mdh_frame_info* info, const int32_t* nms_lines, const double* nonline) {
-    if (!c || !info || !nms_lines || !nonline || K < 0 || eq_int_fps < 1) { set_err("mdh_collector_update_batch: bad argument"); return MDH_E_ARG; }
-    const int num_cls = c->cfg.num_cls;
-    std::vector<double> cates;
-    for (int i = 0; i < K; ++i) {
-        const int n = (info[i].n_raw > 0 && info[i].n_raw <= 500) ? info[i].n_nms : 0;  // NUM_LINES_TOOMUCH (Detector.py:30, 358-360)
-        if (n == 0 && (it0 + i) % eq_int_fps != 0) continue;
-        cates.assign((size_t)n * num_cls, 0.0);
-        const double* p = nonline + (size_t)i * MDH_MAX_LINES;
-        for (int k = 0; k < n; ++k) {
-            cates[(size_t)k * num_cls + num_cls - 1] = p[k];
-            cates[(size_t)k * num_cls] = 1 - p[k];
-        }
-        const int rc = c->update(frame0 + (int64_t)i * c->cfg.exp_frame, nms_lines + (size_t)i * MDH_MAX_LINES * 4, cates.data(), n);
-        if (rc != MDH_OK) { set_err("mdh_collector_update_batch: " + c->err); return rc; }
-    }
-    return MDH_OK;
-}
-
-extern "C" int mdh_collector_events(mdh_collector* c, mdh_target* out, int cap, double* centers, int cap_centers, int* n_centers) {
-    if (!c) { set_err("mdh_collector_events: null collector"); return MDH_E_ARG; }
-    const int n = (int)c->events.size(), nc = (int)(c->centers.size() / 2);
-    if (n_centers) *n_centers = nc;
-    if (n <= cap && nc <= cap_centers && out && (centers || nc == 0)) {
-        if (n) memcpy(out, c->events.data(), sizeof(mdh_target) * n);
-        if (nc) memcpy(centers, c->centers.data(), sizeof(double) * 2 * nc);
-        c->events.clear();
-        c->centers.clear();
-    }
-    return n;
-}

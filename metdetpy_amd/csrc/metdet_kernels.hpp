@@ -167,8 +167,15 @@ struct FrameScalars {
     int thr, pad;
 };
 
-// a3: EMA update (utils.py:352-358) and T = round(a*snr^2 + b) (Detector.py:227-229).  The chain over the due
-// frames is sequential (one thread); the per-frame tables are then filled by the whole block.
+// a3: EMA update (utils.py:352-358) and T = round(a*snr^2 + b) (Detector.py:227-229).
+// Only the EMA itself is a chain (v_j = m_j * v_(j-1) + (1 - m_j) * sigma_j: two multiplies and an add per due frame, in the
+// reference's order, no contraction); everything around it is independent per due frame.  Round 3 ran the whole body -- global
+// loads of the job and its sums, two divisions, a square root, the threshold, a 32-byte global store -- inside the one-lane loop:
+// 0.5 us per due frame (0.53 ms per 16 000-frame pass at 960x540, a third of the window kernel's time).  Now, per chunk of
+// NF_CHUNK due frames: (A) all threads: sigma_j and the momenta into LDS; (B) one lane: the bare chain out of LDS (the loads do
+// not depend on the chain, so they are issued eight steps ahead); (C) all threads: thresholds and the job results.  The values
+// are those of the sequential loop bit for bit (same operations on the same operands; timeshard.NoiseChain replays them on the host).
+#define NF_CHUNK 1024
 __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
                                                         const long long* __restrict__ sums, ScalarState* __restrict__ st,
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
@@ -177,24 +184,71 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
     RAISE_WAVE_PRIORITY();
     // the slot's list counters ([0] lit words, [1] morphology blocks): k_pass_prepare, earlier on this stream, was their last reader
     if (nzcount && threadIdx.x < 4) nzcount[threadIdx.x] = 0;  // ([2..3]: the window kernel's count of words with set bits)
+    __shared__ double s_sig[NF_CHUNK], s_m[NF_CHUNK], s_om[NF_CHUNK], s_ema[NF_CHUNK];
+    __shared__ double s_ema_in, s_thrf_in;  // state on entry of the chunk
+    __shared__ int s_thr_in;
+    const int tid = threadIdx.x;
     // jobres[0] = state on entry, jobres[j+1] = state after job j
-    if (threadIdx.x == 0) {
-        ScalarState s = *st;
-        jobres[0] = s;
-        for (int j = 0; j < njobs; ++j) {
-            const double cnt = (double)jobs[j].k_used * roi_px;
-            const double mu = (double)sums[2 * j] / cnt;
-            double var = (double)sums[2 * j + 1] / cnt - mu * mu;
+    const ScalarState s0 = *st;
+    if (tid == 0) {
+        jobres[0] = s0;
+        s_ema_in = s0.ema_v;
+        s_thrf_in = s0.thr_f;
+        s_thr_in = s0.thr;
+    }
+    __syncthreads();
+    for (int base = 0; base < njobs; base += NF_CHUNK) {
+        const int cnt = min(NF_CHUNK, njobs - base);
+        for (int j = tid; j < cnt; j += blockDim.x) {  // (A)
+            const NoiseJob job = jobs[base + j];
+            const double c = (double)job.k_used * roi_px;
+            const double mu = (double)sums[2 * (base + j)] / c;
+            double var = (double)sums[2 * (base + j) + 1] / c - mu * mu;
             if (var < 0) var = 0;
-            s.sigma = sqrt(var);
-            s.ema_v = jobs[j].m_cur * s.ema_v + jobs[j].one_minus * s.sigma;
-            if (adaptive && s.ema_v != 0) {
-                s.thr_f = coef_a * (s.ema_v * s.ema_v) + coef_b;
-                s.thr = (int)rint(s.thr_f);  // Python round(): half to even
-            }
-            jobres[j + 1] = s;
+            s_sig[j] = sqrt(var);
+            s_m[j] = job.m_cur;
+            s_om[j] = job.one_minus;
         }
-        *st = s;
+        __syncthreads();
+        if (tid == 0) {  // (B)
+            double v = s_ema_in;
+#pragma unroll 8
+            for (int j = 0; j < cnt; ++j) {
+                v = s_m[j] * v + s_om[j] * s_sig[j];
+                s_ema[j] = v;
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < cnt; j += blockDim.x) {  // (C)
+            // the threshold follows the EMA only while that is non-zero (Detector.py:227: `if self.stack.snr`); otherwise it stays
+            // what the last job with a non-zero EMA -- or the state on entry -- made it
+            int k = j;
+            while (k >= 0 && !(adaptive && s_ema[k] != 0)) --k;
+            ScalarState r;
+            r.ema_v = s_ema[j];
+            r.sigma = s_sig[j];
+            if (k >= 0) {
+                r.thr_f = coef_a * (s_ema[k] * s_ema[k]) + coef_b;
+                r.thr = (int)rint(r.thr_f);  // Python round(): half to even
+            } else {
+                r.thr_f = s_thrf_in;
+                r.thr = s_thr_in;
+            }
+            r.pad = 0;
+            jobres[base + j + 1] = r;
+            if (j == cnt - 1 && base + cnt == njobs) *st = r;
+        }
+        __syncthreads();
+        if (tid == 0 && base + cnt < njobs) {  // entry state of the next chunk (this thread wrote job 0's lane ... reads its own LDS)
+            int k = cnt - 1;
+            while (k >= 0 && !(adaptive && s_ema[k] != 0)) --k;
+            if (k >= 0) {
+                s_thrf_in = coef_a * (s_ema[k] * s_ema[k]) + coef_b;
+                s_thr_in = (int)rint(s_thrf_in);
+            }
+            s_ema_in = s_ema[cnt - 1];
+        }
+        __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
@@ -801,6 +855,12 @@ struct __attribute__((aligned(64))) MailBox {
     unsigned state;                  // kernel -> host: `s` = taken, `~s` = given up (expired or cancelled)
     unsigned pad1[15];
 };
+// tag of a mailbox line: the sequence number plus a weighted sum of the line's payload (see the poll loop of k_stack_threshold_mail)
+__host__ __device__ inline unsigned mail_line_tag(const unsigned* payload15, unsigned seq) {
+    unsigned c = 0;
+    for (int k = 0; k < 15; ++k) c += payload15[k] * (2u * (unsigned)k + 1u);
+    return seq + c;
+}
 #define MAIL_ARG_DW ((int)((sizeof(MailArgs) + 7) / 8) * 2)  // dwords of the arguments in the payload (the table follows, 8-byte aligned)
 // What k_hough_single zeroes behind its results (clean-after-use) the waiting kernel can zero instead, in front of its poll and
 // with every workgroup: the previous frame's last launch then ends with its results, and this kernel is resident that much earlier.
@@ -849,15 +909,24 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* 
                 w0 = n0; w1 = n1;  // (the older pair: the compiler waits for it with the younger pair still in flight)
                 n0 = m0; n1 = m1;
                 const bool tag_lane = (lane & 15) == 15;
-                const u64 ok0 = __ballot(tag_lane && w0 == seq), ok1 = __ballot(tag_lane && w1 == seq);
-                const unsigned tag0 = __builtin_amdgcn_readlane(w0, 15);
+                // A line's tag is seq + checksum(its 15 payload dwords) (weights 1, 3, 5 ...: mail_line_tag on the host), so a line
+                // whose tag arrived ahead of its payload -- nothing in the ISA or the bus promises that a wave-wide 4-byte-per-lane
+                // load returns a 64-byte line as ONE read -- does not pass for a frame: it is simply read again.
+                unsigned c0 = tag_lane ? 0u : w0 * (2u * (unsigned)(lane & 15) + 1u), c1 = tag_lane ? 0u : w1 * (2u * (unsigned)(lane & 15) + 1u);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    c0 += (unsigned)__shfl_xor((int)c0, o);
+                    c1 += (unsigned)__shfl_xor((int)c1, o);
+                }
+                const u64 ok0 = __ballot(tag_lane && w0 - c0 == seq), ok1 = __ballot(tag_lane && w1 - c1 == seq);
+                const unsigned tag0 = __builtin_amdgcn_readlane(w0, 15), sum0 = __builtin_amdgcn_readlane(c0, 15);
                 // tags of lines 0 .. NCH-1: lanes 15, 31, 47, 63 of w0, then of w1
                 int good = 0;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) good += (int)(((ch < 4 ? ok0 : ok1) >> (16 * (ch & 3) + 15)) & 1);
                 if (good == NCH) { v = seq; break; }
                 // (cancelled -- or the mailbox already speaks to this kernel's successor: cancelled before it became resident)
-                if (tag0 == ~seq || tag0 == seq + 1 || tag0 == ~(seq + 1)) { v = ~seq; break; }
+                if (tag0 == ~seq || tag0 - sum0 == seq + 1 || tag0 == ~(seq + 1)) { v = ~seq; break; }
                 if (wall_clock64() - t0 > MAIL_EXPIRE_TICKS) { v = ~seq; break; }
             }
             if (v == seq) {  // payload dword p of line ch sits at mailbox dword 16 ch + p -> device dword 15 ch + p

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmetdet_oracle.so")
+# MDH_ORACLE_LIB: another build of the same file (the ASan / UBSan one of `make -C oracle san`, tests/test_sanitizers.py)
+_SO = os.environ.get("MDH_ORACLE_LIB") or os.path.join(_HERE, "libmetdet_oracle.so")
 _lib = None
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")

@@ -124,13 +124,14 @@ def test_config4_bench_two_ranks_as_the_driver_launches_it():
     env = dict(os.environ, MDH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--batch", "128", "--unique", "64"]
+           "--batch", "128", "--passes-per-step", "2", "--unique", "64"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
-    assert abs(d["value"] - 2 * 6 * 128 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
+    assert d["config"]["frames_per_step"] == 256 and d["config"]["passes_per_step"] == 2
+    assert abs(d["value"] - 2 * 6 * 256 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d, "the CPU baseline is timed at N = 1 only"
     assert d["detections"]["raw_segments"] > 0 and d["config"]["parallelism"] == "streams x2"

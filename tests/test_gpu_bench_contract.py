@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--batch", "128",
-                          "--cpu-seconds", "2", "--parity-frames", "48"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--passes-per-step", "3", "--no-secondary", "--cpu-seconds", "2", "--parity-frames", "48"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -23,7 +23,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["dtype"] == "u8" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["unit"] == "frames/s" and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 8 * 128 / (d["ms_per_step"] * 8 / 1e3)) / d["value"] < 1e-6
+    # a step = passes_per_step native passes of frames_per_pass frames each (>= 2 s timed at the default sizes)
+    assert d["config"]["passes_per_step"] == 3 and d["config"]["frames_per_pass"] == 128 and d["config"]["frames_per_step"] == 384
+    assert abs(d["value"] - 8 * 384 / (d["ms_per_step"] * 8 / 1e3)) / d["value"] < 1e-6
+    assert abs(d["ms_per_pass"] - d["ms_per_step"] / 3) < 1e-9 and "secondary" not in d
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches"] >= 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
@@ -55,6 +58,33 @@ def test_bench_per_frame_protocol_entry():
     d = _run(["--protocol", "per-frame", "--steps", "300", "--cpu-seconds", "0", "--parity-frames", "32"])
     assert d["config"]["frames_per_step"] == 1 and "update(frame) / detect()" in d["config"]["workload"]
     assert d["value"] > 1000 and d["parity"]["verdict"] == "identical" and d["detections"]["raw_segments"] > 0
+    pf = d["per_frame"]
+    assert pf["frames"] == "pinned" and pf["update_stats"]["copied_frames"] <= 8 + 300 // 16 + 2
+    assert pf["frames_by_kind"]["quiet"] + pf["frames_by_kind"]["streak"] == 300
+    assert pf["us_per_frame"]["quiet"] < pf["us_per_frame"]["streak"]  # a streak frame pays a serial Hough replay
+    # a ring of ordinary buffers refilled in turn: registered by the library, read in place; no host_alloc anywhere
+    d = _run(["--protocol", "per-frame", "--frames", "recycled", "--steps", "300", "--cpu-seconds", "0", "--parity-frames", "0"])
+    assert d["per_frame"]["update_stats"]["auto_registered"] == 8 and d["per_frame"]["update_stats"]["direct_frames"] >= 250
+    # a fresh array per frame: every frame copied
+    d = _run(["--protocol", "per-frame", "--frames", "pageable", "--steps", "200", "--cpu-seconds", "0", "--parity-frames", "0"])
+    assert d["per_frame"]["update_stats"]["direct_frames"] == 0 and d["value"] > 500
+
+
+def test_bench_secondary_block_of_the_headline_run():
+    """The plain headline command on one GPU also runs the other BASELINE workloads and the per-frame protocol (subprocesses of
+    the same script, after the headline region) and reports them in ONE line: `secondary`."""
+    d = _run(["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-pmc", "--parity-frames", "16", "--standalone-passes", "4"], timeout=1500)
+    assert d["config"]["passes_per_step"] == 64 and d["config"]["frames_per_step"] == 256000
+    sec = d["secondary"]
+    assert set(sec) == {"C3_4k_n16_mask", "C5_8k_high", "C1s_960x540", "per_frame_pinned", "per_frame_recycled_ring", "per_frame_pageable"}
+    for name, e in sec.items():
+        assert "error" not in e, (name, e)
+        assert e["value"] > 0 and e["timed_s"] >= 0.3 and e["parity"] == "identical" and e["parity_frames"] == 64, (name, e)
+    for name in ("C3_4k_n16_mask", "C5_8k_high", "C1s_960x540"):
+        assert 0.2 < sec[name]["frac_at_pipeline_pace"] < 1 and 0.2 < sec[name]["frac"] < 1 and sec[name]["timed_s"] >= 1.0, (name, sec[name])
+    assert sec["per_frame_recycled_ring"]["per_frame"]["update_stats"]["auto_registered"] == 8
+    assert sec["per_frame_recycled_ring"]["value"] > 0.9 * sec["per_frame_pinned"]["value"]
+    assert sec["per_frame_pageable"]["per_frame"]["update_stats"]["direct_frames"] == 0
 
 
 def test_bench_row_band_mode_on_one_device():
@@ -83,7 +113,7 @@ def test_bench_rccl_branch_with_one_rank():
     env = dict(os.environ, MDH_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "128", "--steps", "6", "--warmup", "2",
-                          "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0"],
+                          "--passes-per-step", "2", "--no-secondary", "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -93,8 +123,8 @@ def test_bench_rccl_branch_with_one_rank():
 
 
 def test_bench_classic_and_accumulator_entries():
-    d = _run(["--detector", "classic", "--batch", "128", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--parity-frames", "24"])
+    d = _run(["--detector", "classic", "--batch", "128", "--passes-per-step", "2", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--parity-frames", "24"])
     assert d["parity"]["verdict"] == "identical" and "ClassicDetector" in d["config"]["workload"] and d["roofline"]["kernel"] == "classic"
-    d = _run(["--hough-mode", "accumulator", "--batch", "128", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--parity-frames", "128"])
+    d = _run(["--hough-mode", "accumulator", "--batch", "128", "--passes-per-step", "2", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--parity-frames", "128"])
     assert d["parity"]["verdict"] == "matched under tolerance" and d["parity"]["records_exact"] >= 1
     assert "accumulator" in d["config"]["workload"]
