@@ -262,7 +262,8 @@ def parity_check(frames, n, mask, local, count):
     from metdetpy_amd import M3Detector
     from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
-    count = min(count, len(frames))
+    if count > len(frames):  # (the resident period is shorter -- C5's 50 frames: the stream wraps seamlessly, and so does the check)
+        frames = frames[np.arange(count) % len(frames)]
     det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=count)
     info, raw, nms, prob = det._ctx.process_batch(np.ascontiguousarray(frames[:count]))
     det.close()
@@ -392,6 +393,9 @@ class Dist:
                 self.tdev = torch.device("cpu")
                 dist.init_process_group(backend)
             self.d = dist
+            if os.environ.get("MDH_BENCH_VERBOSE_RANKS") == "1":  # tools/run_8gpu.sh: who sits where
+                print(f"[rank {self.rank}] of {self.world}: HIP device {self.local} of {torch.cuda.device_count()} visible "
+                      f"({torch.cuda.get_device_name(self.local)}), process group backend {backend}", file=sys.stderr, flush=True)
 
     def fence(self):
         # the library has no work in flight between run() calls; the barrier aligns the ranks
@@ -429,7 +433,7 @@ def make_stream_frames(wl, rank, mask, B, unique):
     return stream.take(uniq)
 
 
-def pmc_traffic_live(a, dense):
+def pmc_traffic_live(a, dense, kern=None):
     """roofline.traffic measured IN THIS RUN: the same command re-executed for 4 passes (one at a time) under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md's HBM section
     prescribes -- and the dominant kernel's counter summed per dispatch, averaged over its launches.  FETCH_SIZE (KB) is doubled:
@@ -443,7 +447,7 @@ def pmc_traffic_live(a, dense):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 is not on PATH"
-    kern = "k_classic_diff" if DETECTOR == "classic" else "k_stack_threshold"
+    kern = kern or ("k_classic_diff" if DETECTOR == "classic" else "k_stack_threshold")
     base = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--batch", str(a.batch), "--unique", str(a.unique),
             "--steps", "3", "--warmup", "1", "--passes-per-step", "1", "--no-secondary", "--depth", "1", "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0",
             "--no-profile", "--no-pmc", "--detector", a.detector, "--hough-mode", a.hough_mode]
@@ -511,14 +515,17 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=Fal
     compulsory = frame * (B + nchunks * (n - 1))
     if dense:
         compulsory += words * 8 * B  # the dense output format writes every word of the thresholded difference (1 bit per pixel)
+    if DETECTOR == "classic":
+        compulsory += 2 * words * 8 * B  # k_classic_diff_tb stores TWO plain bit planes per frame (|f1 - f0| > T and |f3 - f2| > T), every word
     avg_ms = ms / launches
     frac_of = lambda t_ms: compulsory / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out.update({
         "bytes_per_launch": compulsory, "frames_per_launch": B,
         "bytes_model": f"H*W*(frames + chunks*(n-1)) = {frame}*({B}+{nchunks}*{n - 1}): each frame byte once per launch plus the "
                        "window history per time chunk"
-                       + (f"; + {words}*8*{B} bytes written: the run was in the DENSE output format (every word of the bit image stored)"
-                          if dense else "; stores (sparse tagged words) not counted"),
+                       + (f"; + 2*{words}*8*{B} bytes written: the difference kernel stores two plain bit planes per frame" if DETECTOR == "classic"
+                          else f"; + {words}*8*{B} bytes written: the run was in the DENSE output format (every word of the bit image stored)"
+                          if dense else "; stores (sparse tagged words, ~0.6 % of the reads: measured) not counted"),
         "launch_ms_in_pipeline": avg_ms, "launches_in_pipeline": launches,
         "frac_in_pipeline_per_launch": frac_of(avg_ms),
         "launches_overlapping_in_pipeline": avg_ms / ms_per_pass,
@@ -881,6 +888,8 @@ def main():
                 out["parity"] = parity_check(frames, n, mask, D.local, a.parity_frames)
         if (D.world == 1 and not a.no_secondary and plain_streams and a.workload == "C2" and DETECTOR == "m3" and HOUGH_MODE == "exact"
                 and not a.host_input and a.depth == 0 and a.sensitivity is None):
+            from metdetpy_amd import _lib
+            _lib.device_reset(D.local)  # this process is done with the GPU: its hardware queues must not count against the children's
             out["secondary"] = run_secondary(a)
         print(json.dumps(out), flush=True)
     D.close()

@@ -11,6 +11,7 @@
 All three are "strong scaling" entries: the job is one stream of steps x batch frames however many GPUs work on it.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -57,6 +58,13 @@ def run_bands(a, D, wl, mask, cfg):
     if D.world > 1:
         det = BandedM3Detector(1, n, mask, 10, cfg, None, rank=D.rank, world=D.world, dist=D.d, device=D.local, max_batch=B)
         plan, ctx = det.plan, det.engine.band
+        if os.environ.get("MDH_BENCH_VERBOSE_RANKS") == "1":
+            kp = -(-B // D.world)
+            print(f"[rank {D.rank}] band rows {plan.bands[D.rank]['own0']}..{plan.bands[D.rank]['own1']} of {H}; "
+                  + (f"RCCL communicator {det.comm.describe()}; " if det.comm is not None else "no RCCL communicator (host buffers over the process group); ")
+                  + f"per pass: all-reduce of 2 x {B // (2 * n) + 1} int64 noise sums (<= {16 * (B // (2 * n) + 1)} B), all-to-all of "
+                    f"{kp * plan.band_rows * plan.WW * 8} B per peer ({kp} frames x {plan.band_rows} rows x {plan.WW} words), gather of the results to rank 0",
+                  file=sys.stderr, flush=True)
         sub = plan.crop(frames, D.rank)
         ptr = ctx.device_alloc(B * sub[0].size)
         for s in range(0, B, uniq):
@@ -168,8 +176,16 @@ def run_timeshard(a, D, wl, mask, cfg):
     D.fence()
     t0 = time.perf_counter()
     mine = {}
-    for s in shards:  # first sweep: the noise sums of the due frames of every window
-        mine.update(s.scan())
+    if len(shards) > 1:
+        # one process, several windows on this device: the first sweep is a chain of short blocking calls per window (launch, wait,
+        # 16 bytes per due frame back) -- the windows' chains run side by side from a few host threads (the library releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(4, len(shards))) as ex:
+            for got in ex.map(lambda s_: s_.scan(), shards):
+                mine.update(got)
+    else:
+        for s in shards:  # first sweep: the noise sums of the due frames of every window
+            mine.update(s.scan())
     t_scan = time.perf_counter() - t0
     if D.world > 1:
         tables = [None] * D.world
@@ -180,12 +196,30 @@ def run_timeshard(a, D, wl, mask, cfg):
     else:
         table = mine
     part = []
-    for s in shards:  # second sweep: the detector passes of every window
-        blk = s.finish_blocks(table)
-        if blk is None:
+    # second sweep: the detector passes of every window.  Several windows in one process: window r + 1's first passes are queued
+    # when window r's last pass has been, BEFORE the host collects r's tail -- the next window's pipeline fills under this one's
+    # drain (each window alone never reaches the pipeline's steady state: fill + drain are 3-4 ms of a 16-pass window's 10)
+    draining = None
+    gens = [s.finish_blocks_steps(table) for s in shards]  # (every context positioned before the first pass is queued)
+    for s, gen in zip(shards, gens):
+        if gen is None:
             part.extend(s.finish(table))
-        else:
-            part.extend(("block",) + b for b in blk)
+            continue
+        for ev in gen:
+            if ev == "primed":
+                break
+        if draining is not None:
+            for _ in draining[0]:
+                pass
+            part.extend(("block",) + b for b in draining[1].blocks)
+        for ev in gen:
+            if ev == "submitted":
+                break
+        draining = (gen, s)
+    if draining is not None:
+        for _ in draining[0]:
+            pass
+        part.extend(("block",) + b for b in draining[1].blocks)
     if D.world > 1:
         gathered = [None] * D.world if D.rank == 0 else None
         D.d.gather_object(part, gathered, dst=0)  # the final detection gather
@@ -310,11 +344,21 @@ def run_c1e(a, D, wl, mask, cfg):
     dt = time.perf_counter() - t0
     dt_all, tot = D.max_time_and_sum(dt, tally)
     pre_ms = state["pre_s"] / steps * 1e3
-    extra = {"roofline": {"bound": "hbm", "kernel": "preprocess (resize INTER_LINEAR 4x down + BGR2GRAY + mask, one launch per pass)", "peak": bench.HBM_PEAK_GBS,
-                          "unit": "GB/s", "achieved": B * fbytes / (pre_ms * 1e-3) / 1e9, "frac": B * fbytes / (pre_ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS,
-                          "bytes_per_launch": B * fbytes, "launch_ms": pre_ms, "launches": steps, "traffic": None,
-                          "launch_ms_note": "host-timed blocking call (launch + kernel + stream sync); bytes = every source byte once (the bilinear taps of a "
-                                            "4x reduction touch 2 of 4 source rows and columns: the kernel may move less)"},
+    # Priced on the bytes the kernel MUST move: the source rows the resize's vertical taps touch (2 of every 4 at this 4x
+    # reduction -- whole rows: the horizontal taps use bytes of every cache line of a touched row) + mask + output.  Round 3 priced
+    # it on every source byte once (`frac_every_source_byte`, kept for comparison): half of those the kernel never reads.
+    must = B * pre.traffic_model(1)
+    live = None
+    if D.rank == 0 and D.world == 1 and not a.no_pmc:
+        live = bench.pmc_traffic_live(a, False, kern="k_preprocess")
+    extra = {"roofline": {"bound": "hbm", "kernel": "preprocess (resize INTER_LINEAR 4x down + BGR2GRAY + mask, one launch per pass, source rows staged through LDS)",
+                          "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "achieved": must / (pre_ms * 1e-3) / 1e9,
+                          "frac": must / (pre_ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, "bytes_per_launch": must, "launch_ms": pre_ms, "launches": steps,
+                          "bytes_model": f"{B} frames x (source rows touched x row bytes + mask + output) = {B} x {pre.traffic_model(1)}",
+                          "frac_every_source_byte": B * fbytes / (pre_ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS,
+                          "traffic": live[0] if live else None, "traffic_source": live[1] if live else None,
+                          "traffic_over_compulsory": (live[0] / must) if live and live[0] else None,
+                          "launch_ms_note": "host-timed blocking call (launch + kernel + stream sync)"},
              "records": len(col.met_exporter.meteor_list)}
     if D.rank == 0 and a.parity_frames > 0:
         from oracle import m3_oracle as mo

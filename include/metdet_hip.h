@@ -61,6 +61,9 @@ int mdh_abi_version(void);
 int mdh_hw_queues_hint(void);
 /* hipSetDevice(device) for hosts without a HIP binding of their own (the RCCL communicator binds to the current device). */
 int mdh_set_device(int device);
+/* hipDeviceReset(device): releases everything this process holds on the device (every mdh_ctx / mdh_pre on it must have been
+ * destroyed first).  For a host that is done with the GPU but stays alive while other processes use it. */
+int mdh_device_reset(int device);
 
 typedef struct mdh_cfg {
     uint32_t struct_size;        /* sizeof(mdh_cfg): checked first by mdh_create */
@@ -198,6 +201,8 @@ int mdh_pre_run(mdh_pre* pre, const uint8_t* bgr, int exp_frame, int src_on_devi
  * frames reach the detector without leaving HBM. */
 int mdh_pre_run_batch(mdh_pre* pre, const uint8_t* bgr, int n_out, int exp_frame, int src_on_device, uint8_t* out, int out_on_device);
 void mdh_pre_destroy(mdh_pre* pre);
+/* bytes a launch must move per output frame: the source rows the resize touches (exp_frame frames) + mask + output */
+uint64_t mdh_pre_traffic_model(const mdh_pre* pre, int exp_frame);
 
 /* stacker.max_stacker / MaxImgContainer (stacker.py:43-49, 197-213): elementwise max over K frames of frame_bytes
  * bytes each (any channel layout). */

@@ -80,7 +80,7 @@ EXPORTS = [
     "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
     "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes",
     "mdh_host_register", "mdh_host_unregister", "mdh_set_auto_register", "mdh_update_stats", "mdh_set_device",
-    "mdh_set_wait_timeout_ms"
+    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset"
 ]
 
 _lib = None
@@ -151,6 +151,7 @@ def load():
     L.mdh_host_alloc.restype = vp
     L.mdh_host_free.argtypes = [vp, vp]
     L.mdh_set_device.argtypes = [i32]
+    L.mdh_device_reset.argtypes = [i32]
     L.mdh_set_wait_timeout_ms.argtypes = [vp, dbl]
     L.mdh_host_register.argtypes = [vp, vp, u64]
     L.mdh_host_unregister.argtypes = [vp, vp]
@@ -168,6 +169,8 @@ def load():
     L.mdh_pre_create.restype = vp
     L.mdh_pre_run.argtypes = [vp, vp, i32, i32, vp, i32]
     L.mdh_pre_run_batch.argtypes = [vp, vp, i32, i32, i32, vp, i32]
+    L.mdh_pre_traffic_model.argtypes = [vp, i32]
+    L.mdh_pre_traffic_model.restype = u64
     L.mdh_pre_destroy.argtypes = [vp]
     L.mdh_pre_destroy.restype = None
     L.mdh_max_stack.argtypes = [i32, vp, i32, u64, i32, vp, i32]
@@ -226,6 +229,11 @@ def last_error() -> str:
 def check(rc: int, what: str):
     if rc != 0:
         raise MetDetHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def device_reset(device: int = 0):
+    """hipDeviceReset: releases what this process holds on the device (all contexts must be closed)."""
+    check(load().mdh_device_reset(int(device)), "mdh_device_reset")
 
 
 def set_device(device: int):

@@ -236,7 +236,9 @@ struct mdh_ctx {
     int64_t direct_frames = 0, copied_frames = 0;  // mdh_update: frames read in place by the window kernel / copied first
     int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
     double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
-    double mail_gap_us = 40;               //   caller is in a tight loop (MDH_LEAN_MAIL_GAP: a waiting kernel spins, so only then)
+    double mail_gap_us = 110;              //   caller is in a tight loop (MDH_LEAN_MAIL_GAP: a waiting kernel spins, so only then).  110 us
+                                           //   (round 3: 40): a loader that refills a ring buffer between frames (a 2 MB copy: 60-100 us) still counts;
+                                           //   the kernel's patience is 150 us (MAIL_EXPIRE_TICKS)
     bool tight_loop = false;
     // time-window sharding on a full context: noise sums of due frames supplied by the caller (the frames of a window that
     // restarted empty cannot produce them: mdh_inject_sums), and frames whose Hough stage is skipped (mdh_mute_hough_until)
@@ -441,6 +443,25 @@ static int perm_table(int device, const unsigned short** out) {
     return MDH_OK;
 }
 
+// hipDeviceReset: everything this PROCESS holds on the device goes -- contexts (which must have been destroyed), the visiting-order
+// tables, the runtime's hardware queues.  For a host that is done with the GPU but stays alive while other processes use it
+// (bench.py before it runs its secondary workloads in subprocesses: an idle parent's queues still count when the command
+// processor decides whether the device is oversubscribed and starts time-slicing).
+extern "C" int mdh_device_reset(int device) {
+    HIPCHK(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> lock(g_perm_mutex);
+        if (device >= 0 && device < 64) g_perm[device] = nullptr;  // (freed by the reset)
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t k = 0; k < g_pools.size();)
+            if (g_pools[k].device == device) g_pools.erase(g_pools.begin() + k); else ++k;
+    }
+    HIPCHK(hipDeviceReset());
+    return MDH_OK;
+}
+
 static int create_impl(mdh_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     // Stream priorities (experiment switches): MDH_PRIO_{MAIN,NOISE,HOUGH} = -1 low, 0 normal (default), 1 high.
@@ -573,7 +594,8 @@ static int create_impl(mdh_ctx* c) {
             } else {
                 TRY(dev_alloc(s.d_planes, 2 * K * words));
             }
-            TRY(dev_alloc(s.d_bandflag, K * nb * c->WW));
+            // [K][nb][WW] block bit counts | [K][nb * WW] touched block ids | [K * WORKCNT_STRIDE] touched blocks per frame (note_block)
+            TRY(dev_alloc(s.d_bandflag, 2 * K * nb * c->WW + (size_t)WORKCNT_STRIDE * K));
             TRY(dev_alloc(s.d_nzlist, K * words, false));
         }
         TRY(dev_alloc(s.d_nzcount, 4));  // [0] listed words, [1] listed morphology blocks, [2..3] u64: words of b with set bits (window kernel)
@@ -838,7 +860,7 @@ static inline hipStream_t post_stream(const mdh_ctx* c, int64_t seq) { return c-
 
 static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
     PassGeom g;
-    g.H = c->H; g.W = c->W; g.WW = c->WW; g.n = c->n; g.K = K; g.t_base = t_base; g.R = c->R;
+    g.H = c->H; g.W = c->W; g.WW = c->WW; g.n = c->n; g.K = K; g.Kcap = c->Kmax; g.t_base = t_base; g.R = c->R;
     return g;
 }
 
@@ -1003,16 +1025,19 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
         // waves at <= 168 VGPRs, x 2 above): a band of an 8K frame (548 rows: 1028 workgroups) in one chunk is 1.34 rounds -- the
         // launch lasts two, a third of the machine idle in the second -- in two chunks 2.68 of 3.  Whole frames at the bench's
         // sizes are unchanged (1080p: 3 chunks = 1.98 rounds; 4K / n = 16: 3.95; 8K: 10.5).
-        static const bool balance = getenv("MDH_WIN_BALANCE") && atoi(getenv("MDH_WIN_BALANCE")) != 0;  // experiment switch, off: measured
-        // slower (960x540: 4.03 -> 3.76 M frames/s with 12 chunks instead of 9; 8 bands of 8K: 49.8 -> 48.3 k: every chunk re-reads n - 1
-        // frames and the launches of neighbouring passes / bands fill each other's tails anyway)
-        const double resident = 256.0 * (N <= 8 ? 3 : 2) * 4 / wpb;
+        // Round 4: on by default (MDH_WIN_BALANCE=0 for A/B).  Round 3 measured it slower at 960x540 (4.03 -> 3.76 M frames/s) when the
+        // pass was bound by its other stages; with those out of the way it is the launch's own tail that shows: 960x540 in 9 chunks
+        // is 1143 workgroups on 768 resident slots, 1.49 rounds (the isolated launch 0.47 -> 0.53-0.56 of the peak with 12-16 chunks,
+        // +2 % at the pipeline's pace, where the next pass's launch fills the tail anyway).
+        static const bool balance = !(getenv("MDH_WIN_BALANCE") && atoi(getenv("MDH_WIN_BALANCE")) == 0);
+        const int occ = N <= 2 ? 8 : (N == 3 ? 5 : (N <= 6 ? 4 : (N <= 9 ? 3 : 2)));  // waves per SIMD the 16-pixel kernel is built for
+        const double resident = 256.0 * occ * 4 / wpb;
         const double wgs = (double)((waves + wpb - 1) / wpb);
         auto eff = [&](int nc) { const double r = wgs * nc / resident; return r / std::ceil(r); };
-        if (balance) {
+        if (balance && PPL == 16) {
             int best = nchunks;
-            for (int nc = nchunks + 1; nc <= std::min(cap, nchunks + 3); ++nc)
-                if (eff(nc) > eff(best) + 0.05) best = nc;
+            for (int nc = nchunks + 1; nc <= std::min(cap, 2 * nchunks + 2); ++nc)
+                if (eff(nc) > eff(best) + 0.04) best = nc;
             nchunks = best;
         }
     }
@@ -1125,7 +1150,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const bool m3 = c->cfg.detector == MDH_DET_M3;
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
                        (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag,
-                       sl.dense ? 0u : (unsigned)((size_t)K * nb * c->WW),  // (the dense format has no block counters)
+                       (unsigned)(nb * c->WW), (unsigned)c->Kmax,  // (only what the slot's previous pass touched)
                        (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
@@ -1169,7 +1194,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
 // then everything the pixel stages of the pass wait for.
 static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
     span_begin(c, KK_NOISE_FINAL, c->nstream);
-    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
                        sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
@@ -1199,7 +1224,7 @@ static int run_noise_direct(mdh_ctx* c, Slot& sl) {
                        r[0], r[1], rh, rw);
     span_end(c, c->nstream);
     span_begin(c, KK_NOISE_FINAL, c->nstream);
-    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(256), 0, c->nstream, c->d_jobs, 1, c->d_sums, c->d_state, c->d_jobres, sl.d_fscal, c->d_thr, 1,
+    hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), 0, c->nstream, c->d_jobs, 1, c->d_sums, c->d_state, c->d_jobres, sl.d_fscal, c->d_thr, 1,
                        (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, (unsigned*)nullptr);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
@@ -1285,8 +1310,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         if (all_dense) {
             hipLaunchKernelGGL(k_morph_close_dense, dim3(8192), dim3(64), 0, post, sl.d_bbits, (const unsigned*)nullptr, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
         } else {
-        hipLaunchKernelGGL(k_morph_select, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_bandflag,
-                           sl.d_worklist, sl.d_workcnt, g);
+        hipLaunchKernelGGL(k_morph_select_touched, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g);
         // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
         // waves leave after one load when the pass has none (MDH_MORPH_DENSE=0: everything through the list, A/B and parity testing)
         static const bool dense = !(getenv("MDH_MORPH_DENSE") && atoi(getenv("MDH_MORPH_DENSE")) == 0);
@@ -2510,6 +2534,8 @@ struct mdh_pre {
     short *d_xw = nullptr, *d_yw = nullptr;
     uint8_t *d_mask = nullptr, *d_src = nullptr, *d_out = nullptr;
     size_t src_cap = 0, out_cap = 0;
+    int span_cap = 0;          // k_preprocess_rows: bytes of a source row one workgroup stages (0: the layout does not allow that kernel)
+    uint64_t rows_touched = 0; // source rows the resize reads per source frame (the kernel's compulsory traffic: mdh_pre_traffic_model)
 };
 
 // OpenCV resize(INTER_LINEAR) coefficient tables: fx = (float)((d+0.5)*scale-0.5), clamp, weights cvRound(w*2048)
@@ -2547,6 +2573,21 @@ static int pre_init(mdh_pre* p, const uint8_t* mask01) {
     std::vector<short> xw, yw;
     linear_table(p->g.dw, p->g.sw, xi, xw);
     linear_table(p->g.dh, p->g.sh, yi, yw);
+    {   // source rows the vertical taps touch (distinct values among yi[dy] and yi[dy] + 1)
+        std::vector<char> used(p->g.sh, 0);
+        for (int dy = 0; dy < p->g.dh; ++dy) { used[yi[dy]] = 1; used[std::min(yi[dy] + 1, p->g.sh - 1)] = 1; }
+        for (char u : used) p->rows_touched += u;
+    }
+    if (p->g.sw % 16 == 0 && !(getenv("MDH_PRE_ROWS") && atoi(getenv("MDH_PRE_ROWS")) == 0)) {  // (MDH_PRE_ROWS=0: the one-thread-per-pixel kernel, A/B and parity)
+        int cap = 0;
+        for (int dx0 = 0; dx0 < p->g.dw; dx0 += PRE_SEG) {
+            const int cnt = std::min(PRE_SEG, p->g.dw - dx0);
+            const int c_first = xi[dx0], c_last = std::min(xi[dx0 + cnt - 1] + 1, p->g.sw - 1);
+            const int byte0 = (c_first * 3) & ~15;
+            cap = std::max(cap, (((c_last + 1) * 3 - byte0) + 15) & ~15);
+        }
+        if (2 * cap <= 64 * 1024) p->span_cap = cap;
+    }
     int rc;
     if ((rc = dev_alloc(p->d_xi, xi.size(), false)) || (rc = dev_alloc(p->d_yi, yi.size(), false)) ||
         (rc = dev_alloc(p->d_xw, xw.size(), false)) || (rc = dev_alloc(p->d_yw, yw.size(), false)) ||
@@ -2616,12 +2657,25 @@ extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int 
         p->out_cap = (size_t)px * n_out;
     }
     uint8_t* dst = out_on_device ? out : p->d_out;
+    if (p->span_cap > 0 && ((uintptr_t)src & 15) == 0 && n_out <= 65535 && p->g.dh <= 65535)
+        hipLaunchKernelGGL(k_preprocess_rows, dim3((p->g.dw + PRE_SEG - 1) / PRE_SEG, p->g.dh, n_out), dim3(PRE_SEG), 2 * (size_t)p->span_cap, p->stream,
+                           src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap);
+    else
     hipLaunchKernelGGL(k_preprocess, dim3((px + 255) / 256, n_out), dim3(256), 0, p->stream, src, exp_frame, p->g, p->d_xi, p->d_xw,
                        p->d_yi, p->d_yw, p->d_mask, dst);
     HIPCHK(hipGetLastError());
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, p->d_out, (size_t)px * n_out, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return MDH_OK;
+}
+
+// Bytes one launch of the preprocessing kernel must move per OUTPUT frame: the source rows the resize's vertical taps touch (whole
+// rows: the horizontal taps of a reduction use bytes of every cache line of such a row), exp_frame source frames each, + the
+// mask + the output.  (bench.py prices the kernel's roofline on this, next to the PMC-measured traffic.)
+extern "C" uint64_t mdh_pre_traffic_model(const mdh_pre* p, int exp_frame) {
+    if (!p || exp_frame < 1) return 0;
+    const uint64_t out = (uint64_t)p->g.dh * p->g.dw;
+    return p->rows_touched * (uint64_t)p->g.sw * 3 * (uint64_t)exp_frame + out + (p->d_mask ? out : 0);
 }
 
 extern "C" int mdh_max_stack(int device, const uint8_t* frames, int K, uint64_t frame_bytes, int on_device, uint8_t* out,

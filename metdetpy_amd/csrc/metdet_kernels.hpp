@@ -37,6 +37,7 @@ struct PassGeom {
     int H, W, WW;       // frame size, words per bit row
     int n;              // window length
     int K;              // frames in this pass
+    int Kcap;           // frames a pass of this context holds at most (max_batch): the stride of the per-slot [Kcap][...] tables
     long long t_base;   // frames consumed before this pass (frame i of the pass has timer t = t_base + 1 + i)
     int R;              // slots in the act/alive bit rings
 };
@@ -176,7 +177,9 @@ struct FrameScalars {
 // not depend on the chain, so they are issued eight steps ahead); (C) all threads: thresholds and the job results.  The values
 // are those of the sequential loop bit for bit (same operations on the same operands; timeshard.NoiseChain replays them on the host).
 #define NF_CHUNK 1024
-__global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
+#define NF_THREADS 1024
+#define NF_FRAMES 4096  // due frames whose frame numbers are searched in LDS when the per-frame tables are filled
+__global__ void __launch_bounds__(NF_THREADS) k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
                                                         const long long* __restrict__ sums, ScalarState* __restrict__ st,
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
                                                         int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
@@ -184,7 +187,8 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
     RAISE_WAVE_PRIORITY();
     // the slot's list counters ([0] lit words, [1] morphology blocks): k_pass_prepare, earlier on this stream, was their last reader
     if (nzcount && threadIdx.x < 4) nzcount[threadIdx.x] = 0;  // ([2..3]: the window kernel's count of words with set bits)
-    __shared__ double s_sig[NF_CHUNK], s_m[NF_CHUNK], s_om[NF_CHUNK], s_ema[NF_CHUNK];
+    __shared__ double s_buf[4 * NF_CHUNK];
+    double *const s_sig = s_buf, *const s_m = s_buf + NF_CHUNK, *const s_om = s_buf + 2 * NF_CHUNK, *const s_ema = s_buf + 3 * NF_CHUNK;
     __shared__ double s_ema_in, s_thrf_in;  // state on entry of the chunk
     __shared__ int s_thr_in;
     const int tid = threadIdx.x;
@@ -252,12 +256,19 @@ __global__ void __launch_bounds__(256) k_noise_finalize(const NoiseJob* __restri
     }
     __threadfence_block();
     __syncthreads();
+    // per-frame tables: frame i takes the state after the last job whose frame is <= i (jobs are sorted by frame).  The search
+    // runs on a copy of the jobs' frame numbers in LDS (ten dependent global loads per frame otherwise: the whole block waits
+    // on L2 latency -- 0.1 ms per 16 000-frame pass)
+    int* s_frame = (int*)s_buf;  // (the chain's arrays are free again: NF_FRAMES ints are half of them)
+    const bool in_lds = njobs <= NF_FRAMES;
+    if (in_lds)
+        for (int j = tid; j < njobs; j += blockDim.x) s_frame[j] = jobs[j].frame;
+    __syncthreads();
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
-        // number of jobs whose frame is <= i (jobs are sorted by frame)
         int lo = 0, hi = njobs;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (jobs[mid].frame <= i) lo = mid + 1; else hi = mid;
+            if ((in_lds ? s_frame[mid] : jobs[mid].frame) <= i) lo = mid + 1; else hi = mid;
         }
         const ScalarState s = jobres[lo];
         thr_tab[i] = s.thr;
@@ -282,6 +293,28 @@ __device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw,
     const ActWord a = row[gw];
     return a.tag == t ? a.bits : 0ull;
 }
+// Block bit counts of b (sparse format) and the list of TOUCHED blocks.
+// blockcnt is one per-slot allocation  [Kcap][nb][WW] counts | [Kcap][nb * WW] touched block ids | [Kcap * WORKCNT_STRIDE] counts of
+// touched blocks per frame.  The counts are all-zero between passes; a word of b with set bits adds its population to its block,
+// and the add that finds the count at zero also appends the block to its frame's touched list.  The morphology's work selection
+// (k_morph_select_touched) then walks the touched blocks' neighbourhoods instead of every block of every frame, and the slot's
+// next k_pass_prepare zeroes exactly the touched counts again -- round 3 zeroed (65 MB per 4000-frame 1080p pass) and scanned
+// (k_morph_select: a thread per block, 16 M threads per pass) the whole table for the < 1 % of it that a quiet sky touches.
+template <bool LIST>
+__device__ __forceinline__ void note_block(unsigned* __restrict__ blockcnt, const PassGeom& g, int i, int gw, unsigned pop) {
+    const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const unsigned per_frame = (unsigned)(nbands * g.WW);
+    const unsigned blk = (unsigned)(gw / g.WW / MORPH_RB) * (unsigned)g.WW + (unsigned)(gw % g.WW);
+    const unsigned old = atomicAdd(&blockcnt[(size_t)i * per_frame + blk], pop);
+    if constexpr (LIST) {
+        if (old == 0) {
+            unsigned* touched = blockcnt + (size_t)g.Kcap * per_frame;
+            unsigned* tcnt = touched + (size_t)g.Kcap * per_frame;
+            touched[(size_t)i * per_frame + atomicAdd(&tcnt[(size_t)i * WORKCNT_STRIDE], 1u)] = blk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a1 + a4 + a6 (pointwise part): b = (max - floor(sum/len) > T), bit-packed.
 // floor(s/len) < c  <=>  s < c*len for integer c, so no division is needed:
@@ -314,7 +347,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* 
     const u64 m = __ballot(b);
     if (lane == 0) {
         if (m) bbits[((size_t)i * g.H + y) * g.WW + w] = ActWord{m, (u64)(g.t_base + 1 + i)};
-        if (m) atomicAdd(&blockcnt[((size_t)i * ((g.H + MORPH_RB - 1) / MORPH_RB) + y / MORPH_RB) * g.WW + w], (unsigned)__popcll(m));
+        if (m) note_block<true>(blockcnt, g, i, gw, (unsigned)__popcll(m));
     }
 }
 
@@ -336,7 +369,6 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
     const int i0 = blockIdx.y * Tc;
     const int steps = min(Tc, g.K - i0);
     if (steps <= 0) return;
-    const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
     // Frames are read through raw buffer descriptors (uniform base in SGPRs + 32-bit lane offset, no 64-bit
     // address math; offsets past the frame return 0, which is how padding lanes are handled).
     int off[4];
@@ -415,7 +447,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
                         if (lane < 4 && gw0 + lane < words) {
                             const u64 v = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
                             if (v) bbits[(size_t)i * words + gw0 + lane] = ActWord{v, (u64)(g.t_base + 1 + i)};
-                            if (v) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)((gw0 + lane) / g.WW / MORPH_RB) * g.WW + (gw0 + lane) % g.WW], (unsigned)__popcll(v));  // rare
+                            if (v) note_block<true>(blockcnt, g, i, gw0 + lane, (unsigned)__popcll(v));  // rare
                         }
                     }
                 }
@@ -443,6 +475,12 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #endif
 #ifndef WIDE_MAX3
 #define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
+#endif
+#ifndef WIDE_RAW_MINN
+#define WIDE_RAW_MINN 99  // window length from which the wide kernel keeps its window as raw bytes (A/B builds: -DWIDE_RAW_MINN=2)
+#endif
+#ifndef WIDE_PTR_AHEAD
+#define WIDE_PTR_AHEAD 1  // frame bases requested one burst ahead of the loads that use them (A/B builds: -DWIDE_PTR_AHEAD=0)
 #endif
 #ifndef WIDE_RAREBITS
 #define WIDE_RAREBITS 1  // gather the result bits only for waves that have one set (A/B builds: -DWIDE_RAREBITS=0)
@@ -523,7 +561,6 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
         if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * (blockDim.x >> 6));
         return;
     }
-    const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
     const int q = lane % LPW;
     const int gw = gw0 + lane / LPW;
     const int frame_bytes = g.H * g.W;
@@ -534,6 +571,14 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     };
     auto fetch = [&](int e) -> dvec {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
+        if constexpr (PPL == 16) {
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : 0));
+        } else {
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : 0));
+        }
+    };
+    auto fetchp = [&](const uint8_t* base) -> dvec {  // the same with the frame's base already in scalar registers
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, frame_bytes, 0x00020000);
         if constexpr (PPL == 16) {
             return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : 0));
         } else {
@@ -553,6 +598,23 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     constexpr int GL = NG - 1;             // the last group; its last slot, N-1, is where the first frame of a block goes
     constexpr int GSL = N - GL * GS;       // size of the last group
     PK win[N][RW];
+    // WIDE_RAW (round 4, A/B: -DWIDE_RAW_MINN=n switches it on from window length n): the window is kept as the RAW 16 bytes per
+    // lane and frame (4 registers) instead of 8 registers of unpacked pairs, and a pair is unpacked (one v_perm_b32) where it is
+    // used: when its frame leaves the window (the running sum) and when its group is refilled (the sliding maximum) -- two more
+    // permutes per pair and frame, half the window's registers: n = 16: 128 -> 64, n = 8: 64 -> 32 (a wave more per SIMD).
+    constexpr bool MAX3_ = WIDE_MAX3 != 0 && GS == 4 && !LEAN;
+    constexpr bool RAW = MAX3_ && PPL == 16 && N >= WIDE_RAW_MINN;
+    dvec raw[N];
+    auto W = [&](int k, int r) -> PK {
+        if constexpr (RAW) {
+            PK p;
+            const unsigned sel = 0x0C000C00u | (unsigned)(r & 3) | ((unsigned)(4 + (r & 3)) << 16);
+            p.u = __builtin_amdgcn_perm(raw[k][r / 4 + DW / 2], raw[k][r / 4], sel);
+            return p;
+        } else {
+            return win[k][r];
+        }
+    };
     // Sliding maximum in 3 packed max per frame instead of (group size - 1) + (NG - 1).  The window slots are filled
     // cyclically; while group g is being refilled the maxima of the other groups do not change (oth), the part of g not
     // yet overwritten only shrinks (suffix maxima, taken once when the refill starts: R_k = max(old_{k+1}.., oth)) and the
@@ -583,26 +645,32 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     }
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
-        unpack(fetch(i0 + k), win[k]);
+        if constexpr (RAW) raw[k] = fetch(i0 + k);
+        else unpack(fetch(i0 + k), win[k]);
 #pragma unroll
-        for (int r = 0; r < RW; ++r) sum[r] += win[k][r].u;
+        for (int r = 0; r < RW; ++r) sum[r] += W(k, r).u;
     }
+    if constexpr (RAW) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) raw[N - 1][d] = 0;
+    } else {
 #pragma unroll
     for (int r = 0; r < RW; ++r) win[N - 1][r].u = 0;
+    }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         // complete groups from the prologue; the state below is "about to fill slot N-1, the last slot of group GL"
 #pragma unroll
         for (int gi = 0; gi < GL; ++gi) {
-            u16x2 m = win[gi * GS][r].v;
+            u16x2 m = W(gi * GS, r).v;
 #pragma unroll
-            for (int k = gi * GS + 1; k < (gi + 1) * GS; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
+            for (int k = gi * GS + 1; k < (gi + 1) * GS; ++k) m = __builtin_elementwise_max(m, W(k, r).v);
             gmax[gi][r] = m;
         }
         if constexpr (GSL > 1) {
-            u16x2 m = win[GL * GS][r].v;
+            u16x2 m = W(GL * GS, r).v;
 #pragma unroll
-            for (int k = GL * GS + 1; k < N - 1; ++k) m = __builtin_elementwise_max(m, win[k][r].v);
+            for (int k = GL * GS + 1; k < N - 1; ++k) m = __builtin_elementwise_max(m, W(k, r).v);
             pre[r] = m;
             if constexpr (NG > 1) {
                 u16x2 o = gmax[0][r];
@@ -613,7 +681,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
         }
     }
 #ifndef WIDE_FOLD_TL
-#define WIDE_FOLD_TL (DENSE || N >= 12)  // (sparse, n = 8: +5 registers with it, one step over three-waves-plus-a-Hough-wave per SIMD; n = 9..11: 164 -> 181, three waves per SIMD -> two; from n = 12 on two waves either way: 4K / n = 16 +2.5 %)
+#define WIDE_FOLD_TL 1  // (round 3: only DENSE || N >= 12 -- at n = 8 it cost five registers then; with the sums taken apart as "minus the leaving frame, unpack in place, plus the new one" it costs none: 152 -> 151)
 #endif
     constexpr bool FOLD_TL = WIDE_FOLD_TL;
     unsigned tl_cur = 0;  // the (T * len) * 0x10001 the sums carry at the moment (wave-uniform)
@@ -628,15 +696,27 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
 #pragma unroll
         for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
     }
-    for (int sb = 0; sb < steps; sb += N) {
-        // thresholds of the whole window period up front (scalar loads, off the per-frame critical path)
-        int Tp[N];
+    // Frame bases one burst AHEAD of the loads that use them (round 4).  A load needs its frame's table entry in scalar registers;
+    // fetched right in front of it, every one of a burst's U loads waited for its own scalar load (s_load, s_waitcnt, buffer_load,
+    // four times over).  pq[] holds the entries of the burst after the one being computed, requested while the previous one was.
+    constexpr bool PTR_AHEAD = WIDE_PTR_AHEAD != 0 && !LEAN;
+    const uint8_t* pq[U];
+    if constexpr (PTR_AHEAD) {
+        constexpr int pp = 1 / NB, bb = 1 % NB;
 #pragma unroll
-        for (int u = 0; u < N; ++u)  // T >= 256 can never fire (diff <= 255); the clamp keeps T * len inside 16 bits
-            Tp[u] = min(__builtin_amdgcn_readfirstlane(thr_tab[min(i0 + sb + u, g.K - 1)]), 256);
+        for (int u = 0; u < U; ++u)
+            if (bb * U + u < N) pq[u] = ptrtab[min(i0 + pp * N + bb * U + u + N - 1, e_max)];
+    }
+    for (int sb = 0; sb < steps; sb += N) {
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
             const int ub = bi * U;
+            // thresholds of the burst up front (scalar loads, off the per-frame critical path; per burst, not per window period:
+            // sixteen of them at n = 16 pushed the kernel's scalar registers into spills once the frame bases travelled ahead too)
+            int Tp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)  // T >= 256 can never fire (diff <= 255); the clamp keeps T * len inside 16 bits
+                if (ub + u < N) Tp[u] = min(__builtin_amdgcn_readfirstlane(thr_tab[min(i0 + sb + ub + u, g.K - 1)]), 256);
             dvec(&cur)[U] = buf2[PINGPONG ? (bi & 1) : 0];
             dvec(&nxt)[U] = buf2[PINGPONG ? ((bi + 1) & 1) : 1];
             // (measured in round 2c: a workgroup barrier here, to keep the four waves on the same frames so that their loads of a
@@ -647,7 +727,13 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool in_period = (bi + 1 < NB) ? ((bi + 1) * U + u < N) : (u < N);
-                if (in_period) nxt[u] = fetch(min(i0 + nb_first + u + N - 1, e_max));
+                if (in_period) nxt[u] = PTR_AHEAD ? fetchp(pq[u]) : fetch(min(i0 + nb_first + u + N - 1, e_max));
+            }
+            if constexpr (PTR_AHEAD) {  // table entries of the burst after that one
+                const int pp = (bi + 2) / NB, bb = (bi + 2) % NB;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (bb * U + u < N) pq[u] = ptrtab[min(i0 + sb + pp * N + bb * U + u + N - 1, e_max)];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -655,8 +741,18 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                     const int s = sb + ub + u;
                     if (s < steps) {
                         const int slot = (ub + u + N - 1) % N;
-                        PK a[RW];
-                        unpack(cur[u], a);
+                        // The frame leaving the window is taken out of the sums BEFORE the new one is unpacked into its slot's
+                        // registers (round 4: written as "sum + new - old" the compiler kept the old pairs alive in eight copies
+                        // per frame -- v_mov, unpack in place, subtract the copy: 8 of the frame's 64 vector instructions)
+                        PK a_tmp[RW];
+                        if constexpr (!RAW) {
+#pragma unroll
+                            for (int r = 0; r < RW; ++r) sum[r] -= win[slot][r].u;
+                            unpack(cur[u], win[slot]);
+                        } else {
+                            unpack(cur[u], a_tmp);
+                        }
+                        PK(&a)[RW] = RAW ? a_tmp : win[slot];
                         const int i = i0 + s;
                         if constexpr (LEAN) {
                             if (copy_dst != nullptr && i == 0 && gw < words) *(dvec*)(copy_dst + off) = cur[u];
@@ -667,7 +763,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         // keeps T * len in 16 bits).
                         const int len = min(g.n, len0 + s);  // window_len(g, i)
                         const unsigned short nlen = (unsigned short)(0 - len);
-                        const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[ub + u] * len) * 0x10001u;  // scalar unit
+                        const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[u] * len) * 0x10001u;  // scalar unit
                         // FOLD_TL: the addend T * len lives INSIDE the running sums (round 3: one add per pixel pair and frame less): it
                         // changes with the threshold -- at most at every (interval * n)-th frame -- and with the window length
                         // during the first n frames of a stream; then every sum takes the difference (32-bit arithmetic on two
@@ -686,7 +782,8 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         const int gsz = grp == GL ? GSL : GS;
 #pragma unroll
                         for (int r = 0; r < RW; ++r) {
-                            sum[r] = sum[r] + a[r].u - win[slot][r].u;
+                            if constexpr (RAW) sum[r] = sum[r] + a[r].u - W(slot, r).u;
+                            else sum[r] += a[r].u;
                             u16x2 m;
                             if constexpr (MAX3) {
                                 const int g0 = grp * GS;
@@ -704,31 +801,34 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                                         if (k2 < NG - 1) o = __builtin_elementwise_max(o, o3[k2]);
                                         oth[r] = o;
                                     }
-                                    pre[r] = a[r].v;
+                                    // (no copy of the group's first new frame: the next step takes it from its window slot)
+                                    if (gsz == 1) gmax[grp][r] = a[r].v;
                                 } else {
-                                    pre[r] = __builtin_elementwise_max(pre[r], a[r].v);
+                                    // running maximum of the group's new frames; the last one completes the group's maximum in place
+                                    const u16x2 before = kpos == 1 ? W(g0, r).v : pre[r];
+                                    if (kpos == gsz - 1) gmax[grp][r] = __builtin_elementwise_max(before, a[r].v);
+                                    else pre[r] = __builtin_elementwise_max(before, a[r].v);
                                 }
+                                const u16x2 P = kpos == 0 ? a[r].v : (kpos == gsz - 1 ? gmax[grp][r] : pre[r]);
                                 const u16x2 zero2 = {0, 0};
                                 const u16x2 o = NG > 2 ? oth[r] : (NG == 2 ? gmax[grp == 0 ? 1 : 0][r] : zero2);
                                 if (kpos == 0 && gsz >= 3) {
                                     // T = max(old slots 2 .. gsz-1 of the group, other groups): serves this frame and the next
-                                    u16x2 T = win[g0 + 2][r].v;
-                                    if (gsz == 4) T = NG > 1 ? pk_max3_u8(T, win[g0 + 3][r].v, o) : __builtin_elementwise_max(T, win[g0 + 3][r].v);
+                                    u16x2 T = W(g0 + 2, r).v;
+                                    if (gsz == 4) T = NG > 1 ? pk_max3_u8(T, W(g0 + 3, r).v, o) : __builtin_elementwise_max(T, W(g0 + 3, r).v);
                                     else if (NG > 1) T = __builtin_elementwise_max(T, o);
                                     t23[r] = T;
-                                    m = pk_max3_u8(a[r].v, win[g0 + 1][r].v, T);
+                                    m = pk_max3_u8(a[r].v, W(g0 + 1, r).v, T);
                                 } else if (kpos == 1 && gsz >= 3) {
-                                    m = __builtin_elementwise_max(pre[r], t23[r]);
+                                    m = __builtin_elementwise_max(P, t23[r]);
                                 } else {
                                     // at most one old slot of the group is left (kpos >= gsz - 2)
                                     const bool one_old = kpos == gsz - 2;
-                                    if (one_old && NG > 1) m = pk_max3_u8(pre[r], win[g0 + gsz - 1][r].v, o);
-                                    else if (one_old) m = __builtin_elementwise_max(pre[r], win[g0 + gsz - 1][r].v);
-                                    else if (NG > 1) m = __builtin_elementwise_max(pre[r], o);
-                                    else m = pre[r];
+                                    if (one_old && NG > 1) m = pk_max3_u8(P, W(g0 + gsz - 1, r).v, o);
+                                    else if (one_old) m = __builtin_elementwise_max(P, W(g0 + gsz - 1, r).v);
+                                    else if (NG > 1) m = __builtin_elementwise_max(P, o);
+                                    else m = P;
                                 }
-                                win[slot][r] = a[r];
-                                if (kpos == gsz - 1) gmax[grp][r] = pre[r];
                             } else {
                             if (kpos == 0) {  // the refill of group grp starts: maxima of the other groups, suffix maxima of this one
                                 if constexpr (NG > 1) {
@@ -752,7 +852,6 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                             } else {
                                 pre[r] = __builtin_elementwise_max(pre[r], a[r].v);
                             }
-                            win[slot][r] = a[r];
                             m = pre[r];
                             if (kpos < gsz - 1) m = __builtin_elementwise_max(m, suf[kpos][r]);
                             else if (NG > 1) m = __builtin_elementwise_max(m, oth[r]);
@@ -770,6 +869,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                                 acc = (acc >> 1) | (d.u & 0x80008000u);
                             }
                         }
+                        if constexpr (RAW) raw[slot] = cur[u];  // (behind the loop: the leaving frame's pairs were unpacked from it above)
                         if constexpr (RAREBITS) {
                             // a wave of 1024 pixels rarely holds a pixel over the threshold (noise at 4-5 sigma, a streak every few
                             // dozen waves): the sign bits are only gathered when the OR of the wave's results has one set
@@ -800,7 +900,8 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             bbits[(size_t)i * words + gw] = ActWord{v, (u64)(g.t_base + 1 + i)};
-                            if (blockcnt != nullptr) atomicAdd(&blockcnt[(size_t)i * nbands * g.WW + (size_t)(gw / g.WW / MORPH_RB) * g.WW + gw % g.WW], (unsigned)__popcll(v));  // rare
+                            // (LEAN: one frame, its morphology looks at the frame's block counts directly: no list)
+                            if (blockcnt != nullptr) note_block<!LEAN>(blockcnt, g, i, gw, (unsigned)__popcll(v));  // rare
                         }
                         }
                     }
@@ -1057,24 +1158,62 @@ __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ bl
     return keep;
 }
 // The work list is kept PER FRAME (segment i = entries [i * blocks_per_frame, ...), count in workcount[i]).  One list with one
-// counter serialised this kernel on a dense binary (a lowered threshold lets noise through: every block of every frame is kept):
-// 130 k same-address atomics, 1.35 ms per 128 frames at 8K -- more than the stencil kernel behind it (rocprofv3 PMC: SQ_WAIT_ANY ~
-// SQ_WAVE_CYCLES).  With a counter per frame the appends of different frames go to different L2 channels.  (Aggregating over
-// 1024-thread workgroups instead cost the 4K pipeline 9 %: such a workgroup needs 16 wave slots on one CU at once.)
-__global__ void __launch_bounds__(256) k_morph_select(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
-                                                      unsigned* __restrict__ workcount, PassGeom g) {
+// counter serialised the selection on a dense binary (a lowered threshold lets noise through: every block of every frame is kept):
+// 130 k same-address atomics, 1.35 ms per 128 frames at 8K.  With a counter per frame the appends of different frames go to
+// different L2 channels.
+// Round 4: the candidates are the 3x3 neighbourhoods of the TOUCHED blocks (note_block's lists), not every block of the frame.  One
+// wave per frame; a lane takes a (touched block B, neighbour o) pair, evaluates the output block O = B + o exactly as
+// morph_block_keep does, and reports it if B is the first block with a non-zero count in O's own neighbourhood (scan order), so
+// that every kept block is listed exactly once whatever the order of the touched list.
+__global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
+                                                              unsigned* __restrict__ workcount, PassGeom g) {
     RAISE_WAVE_PRIORITY();
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
-    const int i = blockIdx.y;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool keep = morph_block_keep(blockcnt, g, i, tid);
-    const u64 m = __ballot(keep);
-    if (!m) return;
+    const unsigned per_frame = (unsigned)(nb * g.WW);
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= g.K) return;
     const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&workcount[(size_t)i * WORKCNT_STRIDE], (unsigned)__popcll(m));
-    base = __shfl(base, 0);
-    if (keep) worklist[(size_t)i * (nb * g.WW) + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * (unsigned)(nb * g.WW) + (unsigned)tid;
+    const unsigned* touched = blockcnt + (size_t)g.Kcap * per_frame;
+    const unsigned* tcnt = touched + (size_t)g.Kcap * per_frame;
+    const unsigned cnt = tcnt[(size_t)i * WORKCNT_STRIDE];
+    const unsigned* f = blockcnt + (size_t)i * per_frame;
+    for (unsigned p0 = 0; p0 < 9u * cnt; p0 += 64) {
+        const unsigned p = p0 + lane;
+        bool keep = false;
+        int out_blk = 0;
+        if (p < 9u * cnt) {
+            const unsigned e = p / 9u, o = p - 9u * e;
+            const int blk = (int)touched[(size_t)i * per_frame + e];
+            const int bband = blk / g.WW, bw = blk - bband * g.WW;
+            const int band = bband + (int)(o / 3u) - 1, w = bw + (int)(o % 3u) - 1;  // the output block O
+            if (band >= 0 && band < nb && w >= 0 && w < g.WW) {
+                unsigned total = 0;
+                int first = -1;
+                for (int db = -1; db <= 1; ++db) {
+                    const int bb = band + db;
+                    if (bb < 0 || bb >= nb) continue;
+                    for (int dw = -1; dw <= 1; ++dw) {
+                        const int ww = w + dw;
+                        if (ww < 0 || ww >= g.WW) continue;
+                        const unsigned c = f[bb * g.WW + ww];
+                        total += c;
+                        if (c && first < 0) first = bb * g.WW + ww;
+                    }
+                }
+                const int y0 = band * MORPH_RB;
+                const unsigned my = (y0 - 3 < 0 || y0 + MORPH_RB + 2 > g.H - 1) ? 2u : 1u;
+                const unsigned mx = (w == 0 || 64 * (w + 1) + 3 > g.W - 1) ? 2u : 1u;
+                keep = first == blk && total * my * mx >= 5u;
+                out_blk = band * g.WW + w;
+            }
+        }
+        const u64 m = __ballot(keep);
+        if (!m) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&workcount[(size_t)i * WORKCNT_STRIDE], (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (keep) worklist[(size_t)i * per_frame + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * per_frame + (unsigned)out_blk;
+    }
 }
 
 // One thread owns one block (a word column x a band of ROWS rows) and slides down it with 3-row pipelines.  `load_row(yc)` returns
@@ -1520,10 +1659,10 @@ __global__ void __launch_bounds__(256) k_sparse_clear(u64* __restrict__ dst_bits
 
 // Everything a pass needs zeroed before its kernels run, in ONE launch (each separate memset / kernel costs a trip through
 // the command processor, and the noise chain that follows is on the critical path of the pass): the counters the pixel
-// stages accumulate into, the block bit counts, the noise sums, and the dst words the slot's previous pass left behind
+// stages accumulate into, the block bit counts the slot's previous pass touched, the noise sums, and the dst words that pass left behind
 // (listed in nzlist; nzcount itself is reset by k_noise_finalize, which runs next on the same stream).
 __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ counters, unsigned n_counters,
-                                                      unsigned* __restrict__ blockcnt, unsigned n_blockcnt,
+                                                      unsigned* __restrict__ blockcnt, unsigned per_frame, unsigned Kcap,
                                                       unsigned* __restrict__ sums32, unsigned n_sums32, u64* __restrict__ dst_bits,
                                                       const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount) {
     RAISE_WAVE_PRIORITY();
@@ -1531,12 +1670,24 @@ __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ cou
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (unsigned e = tid; e < n_counters / 4; e += nth) ((uint4*)counters)[e] = z;
     for (unsigned e = (n_counters & ~3u) + tid; e < n_counters; e += nth) counters[e] = 0;
-    for (unsigned e = tid; e < n_blockcnt / 4; e += nth) ((uint4*)blockcnt)[e] = z;
-    for (unsigned e = (n_blockcnt & ~3u) + tid; e < n_blockcnt; e += nth) blockcnt[e] = 0;
     for (unsigned e = tid; e < n_sums32; e += nth) sums32[e] = 0;
     if (nzcount) {
         const unsigned total = *nzcount;
         for (unsigned e = tid; e < total; e += nth) dst_bits[nzlist[e]] = 0;
+    }
+    // the block bit counts the slot's previous pass touched (note_block's lists), and the lists' counts: a workgroup per frame
+    if (blockcnt != nullptr) {
+        unsigned* touched = blockcnt + (size_t)Kcap * per_frame;
+        unsigned* tcnt = touched + (size_t)Kcap * per_frame;
+        __shared__ unsigned s_cnt;
+        for (unsigned i = blockIdx.x; i < Kcap; i += gridDim.x) {
+            if (threadIdx.x == 0) s_cnt = tcnt[(size_t)i * WORKCNT_STRIDE];
+            __syncthreads();
+            const unsigned cnt = s_cnt;
+            for (unsigned e = threadIdx.x; e < cnt; e += blockDim.x) blockcnt[(size_t)i * per_frame + touched[(size_t)i * per_frame + e]] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0 && cnt) tcnt[(size_t)i * WORKCNT_STRIDE] = 0;
+        }
     }
 }
 

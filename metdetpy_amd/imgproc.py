@@ -48,6 +48,10 @@ class Preprocessor:
         """Device to device: out_ptr (n_out * dst_h * dst_w bytes) can be handed to the detector with on_device=True."""
         _lib.check(self.L.mdh_pre_run_batch(self._h, int(src_ptr), int(n_out), int(exp_frame), 1, int(out_ptr), 1), "mdh_pre_run_batch")
 
+    def traffic_model(self, exp_frame: int = 1) -> int:
+        """Bytes a launch must move per output frame: the source rows the resize touches + mask + output (mdh_pre_traffic_model)."""
+        return int(self.L.mdh_pre_traffic_model(self._h, int(exp_frame)))
+
     def run_device(self, src_ptr: int, exp_frame: int, out_ptr: int):
         _lib.check(self.L.mdh_pre_run(self._h, int(src_ptr), int(exp_frame), 1, int(out_ptr), 1), "mdh_pre_run")
 

@@ -194,6 +194,33 @@ class TimeShard:
     def _finish_pipelined(self, table, chain, blocks=False):
         """Second sweep on a full detector context: seek, inject the sums its restarted window cannot produce, mute the
         warm-up frames' Hough stage, then passes in flight like any stream."""
+        self._finish_prepare(table, chain)
+        for _ in self._finish_steps(blocks):
+            pass
+        return self._res
+
+    def finish_blocks_steps(self, table: dict):
+        """finish_blocks() as a generator, for a host that drives SEVERAL windows on one device (bench.py --mode timeshard with one
+        process): yields "primed" once the window's pipeline is full (or all its passes are queued), "submitted" when its last
+        pass is queued -- the moment to start the next window's passes, so that its fill runs under this window's drain -- and
+        ends after the last collect; the records are then in `.blocks`.  The context is positioned (mdh_seek: a device-wide
+        synchronisation) HERE, not at the generator's first step: a host that overlaps windows creates all its generators first.
+        None when the engine is not the HIP one."""
+        if not self.pipelined or self.end <= self.start:
+            return None
+        chain = self._chain()
+        for t in sorted(table):
+            if t > self.warm:
+                break
+            chain.update(*table[t])
+        self._finish_prepare(table, chain)
+        return self._finish_steps(True)
+
+    @property
+    def blocks(self):
+        return self._res
+
+    def _finish_prepare(self, table, chain):
         n = self.s.n
         ctx = self.det._ctx
         ctx.seek(self.warm, **chain.state())
@@ -202,10 +229,14 @@ class TimeShard:
                 if self.warm < t < self.warm + n:  # fewer than n frames since the seek: the window is still filling
                     ctx.inject_sums(t, table[t][1], table[t][2])
         ctx.mute_hough_until(self.start)
+
+    def _finish_steps(self, blocks):
+        ctx = self.det._ctx
         B = self.B
         bufs = [(np.zeros(B, _lib.FRAME_INFO_DTYPE), np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32),
                  np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32), np.zeros((B, _lib.MDH_MAX_LINES), np.float64))]
         queue, res = [], []
+        self._res = res
 
         def collect():
             lo, K, _keep = queue.pop(0)
@@ -224,9 +255,14 @@ class TimeShard:
                 lines, pred = _package(self.s.num_cls, info[j], raw[j], nms[j], prob[j])
                 res.append((lo + j, info[j].copy(), lines, pred))
 
-        for lo in range(self.warm, self.end, B):
+        starts = list(range(self.warm, self.end, B))
+        primed = False
+        for k, lo in enumerate(starts):
             hi = min(self.end, lo + B)
             if ctx.in_flight >= ctx.max_in_flight:
+                if not primed:
+                    primed = True
+                    yield "primed"
                 collect()
             if self.read_device is not None:
                 ctx.submit(self.read_device(lo, hi), hi - lo, True)
@@ -235,9 +271,11 @@ class TimeShard:
                 frames = np.ascontiguousarray(self.read(lo, hi))
                 ctx.submit(frames.ctypes.data, hi - lo, False)
                 queue.append((lo, hi - lo, frames))  # the frames must stay valid until the pass is collected
+        if not primed:
+            yield "primed"
+        yield "submitted"
         while queue:
             collect()
-        return res
 
     def close(self):
         self.engine.close()

@@ -8,7 +8,7 @@ from metdetpy_amd import M3Detector, _lib
 from metdetpy_amd.synth import SkyStream
 
 WL = os.environ.get("WL", "C2")
-H, W, n, B, uniq = (1080, 1920, 8, 1024, 250) if WL == "C2" else ((2160, 3840, 16, 256, 100) if WL == "C3" else (4320, 7680, 8, 64, 50))
+H, W, n, B, uniq = {"C2": (1080, 1920, 8, 1024, 250), "C3": (2160, 3840, 16, 256, 100), "C5": (4320, 7680, 8, 64, 50), "C1s": (540, 960, 8, 2048, 250)}[WL]
 mask = np.ones((H, W), np.uint8)
 bench.SENSITIVITY = bench.WORKLOADS[WL].get("sensitivity", "normal")
 frames = SkyStream(H, W, bench.WORKLOADS[WL]["seed"]).take(uniq)
