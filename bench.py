@@ -779,6 +779,7 @@ def run_secondary(a):
         if "per_frame" in d:
             e["per_frame"] = {k: d["per_frame"][k] for k in ("frames", "update_stats", "us_per_frame", "frames_by_kind", "frames_per_s_by_kind")}
         out[name] = e
+        time.sleep(2.0)  # (a child that held ~100 GB of HBM has just exited: the driver releases -- and wipes -- its memory in the background)
     return out
 
 

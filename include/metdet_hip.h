@@ -292,6 +292,10 @@ int mdh_band_collect(mdh_ctx* ctx, mdh_frame_info* info);   /* waits for the old
 int mdh_chain(mdh_ctx* producer, int producer_stream, mdh_ctx* consumer, int consumer_stream);
 int mdh_device_copy_on(mdh_ctx* ctx, int which_stream, void* dst_device, const void* src_device, uint64_t bytes);  /* queued */
 int mdh_bands_allreduce_local(mdh_ctx** bands, int n);      /* n band contexts of one process and device, passes staged */
+/* Several contexts of one process on one device queue their stages on the SAME streams (ctx gives up its own main / noise / post
+ * streams and uses donor's): the runtime multiplexes streams onto a few hardware queues, and unrelated streams sharing a queue
+ * serialise.  Right after mdh_create, before ctx's first pass; donor must outlive ctx. */
+int mdh_share_streams(mdh_ctx* ctx, mdh_ctx* donor);
 /* How long mdh_collect_batch / mdh_band_collect / mdh_detect wait for their pass (0, the default: for ever).  A queued pass that
  * contains a collective never completes when a peer rank has died; with a timeout the wait returns MDH_E_TIMEOUT and poisons the
  * context -- the host then aborts its communicator (ncclCommAbort releases the stuck kernels) and destroys the context. */

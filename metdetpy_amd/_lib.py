@@ -80,7 +80,7 @@ EXPORTS = [
     "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
     "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes",
     "mdh_host_register", "mdh_host_unregister", "mdh_set_auto_register", "mdh_update_stats", "mdh_set_device",
-    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset"
+    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset", "mdh_share_streams"
 ]
 
 _lib = None
@@ -150,6 +150,7 @@ def load():
     L.mdh_host_alloc.argtypes = [vp, u64]
     L.mdh_host_alloc.restype = vp
     L.mdh_host_free.argtypes = [vp, vp]
+    L.mdh_share_streams.argtypes = [vp, vp]
     L.mdh_set_device.argtypes = [i32]
     L.mdh_device_reset.argtypes = [i32]
     L.mdh_set_wait_timeout_ms.argtypes = [vp, dbl]
@@ -497,6 +498,11 @@ class Context:
         if K < 0:
             check(K, "mdh_band_collect")
         return info[:K]
+
+    def share_streams_of(self, donor: "Context"):
+        """Queue this context's stages on `donor`'s streams (several contexts of one process on one device); before the first pass."""
+        check(self.L.mdh_share_streams(self.handle, donor.handle), "mdh_share_streams")
+        self._stream_donor = donor  # (keeps the donor alive as long as this context)
 
     def chain_to(self, my_stream: int, consumer: "Context", consumer_stream: int):
         """Everything queued on my stream so far precedes what is queued on the consumer's stream from now on."""

@@ -196,6 +196,11 @@ class LocalBands:
         if self.shared:
             self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device, with_hough=False) for b in range(p.nbands)]
             self.hough = self.engines[0].shared_hough_context(max_batch)
+            # the bands of one process queue their stages on band 0's streams (mdh_share_streams: unrelated streams that land on
+            # one hardware queue serialise; MDH_BANDS_SHARE_STREAMS=0 keeps a set of streams per band, A/B)
+            if os.environ.get("MDH_BANDS_SHARE_STREAMS", "1") != "0":
+                for e in self.engines[1:]:
+                    e.band.share_streams_of(self.engines[0].band)
         else:
             self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device) for b in range(p.nbands)]
             self.hough = None
@@ -351,7 +356,7 @@ class LocalBands:
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None
-        for e in self.engines:
+        for e in reversed(self.engines):  # (borrowers of band 0's streams first)
             e.close()
 
 

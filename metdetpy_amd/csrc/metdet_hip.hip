@@ -255,6 +255,7 @@ struct mdh_ctx {
     size_t chain_next = 0;
     bool poisoned = false;
     double wait_timeout_ms = 0;  // mdh_set_wait_timeout_ms: how long a collect waits for its pass (0 = for ever)
+    bool streams_borrowed = false;  // mdh_share_streams: the main / noise / post / copy streams belong to another context
     // Format of b = (diff > T) between the window kernel and the morphology: sparse + tagged (a quiet sky: nothing is written for
     // 99 % of the wave-frames) or dense + plain (binaries with noise in them: 8K at m3det_high).  Chosen per pass from the share
     // of words with set bits the last collected pass reported (both formats report it); identical results either way.
@@ -397,7 +398,7 @@ static void free_all(mdh_ctx* c) {
     }
     hipStream_t st[] = {c->mstream[0], c->mstream[1], c->nstream, c->cstream, c->pstream[0], c->pstream[1]};
     for (hipStream_t q : st)
-        if (q) hipStreamDestroy(q);
+        if (q && !c->streams_borrowed) hipStreamDestroy(q);
     delete c;
 }
 
@@ -594,8 +595,8 @@ static int create_impl(mdh_ctx* c) {
             } else {
                 TRY(dev_alloc(s.d_planes, 2 * K * words));
             }
-            // [K][nb][WW] block bit counts | [K][nb * WW] touched block ids | [K * WORKCNT_STRIDE] touched blocks per frame (note_block)
-            TRY(dev_alloc(s.d_bandflag, 2 * K * nb * c->WW + (size_t)WORKCNT_STRIDE * K));
+            // [K][nb][WW] block bit counts | [K][nb][ceil(WW / 32)] bitmap of the blocks with a non-zero count (note_block)
+            TRY(dev_alloc(s.d_bandflag, K * nb * c->WW + K * nb * (size_t)((c->WW + 31) / 32)));
             TRY(dev_alloc(s.d_nzlist, K * words, false));
         }
         TRY(dev_alloc(s.d_nzcount, 4));  // [0] listed words, [1] listed morphology blocks, [2..3] u64: words of b with set bits (window kernel)
@@ -1150,7 +1151,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const bool m3 = c->cfg.detector == MDH_DET_M3;
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
                        (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag,
-                       (unsigned)(nb * c->WW), (unsigned)c->Kmax,  // (only what the slot's previous pass touched)
+                       (unsigned)(nb * c->WW), (unsigned)c->WW, (unsigned)c->Kmax,  // (only what the slot's previous pass touched)
                        (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
@@ -1314,6 +1315,12 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
         // waves leave after one load when the pass has none (MDH_MORPH_DENSE=0: everything through the list, A/B and parity testing)
         static const bool dense = !(getenv("MDH_MORPH_DENSE") && atoi(getenv("MDH_MORPH_DENSE")) == 0);
+        // a block's fourteen rows on fourteen lanes, one wave per frame (MDH_MORPH_BT=0: one lane per listed block, A/B and parity)
+        static const bool batched_t = !(getenv("MDH_MORPH_BT") && atoi(getenv("MDH_MORPH_BT")) == 0);
+        if (batched_t)
+            hipLaunchKernelGGL(k_morph_close_t, dim3((unsigned)std::min(K, 16384)), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
+                               sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr);
+        else
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
                            sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr);
         if (dense)
@@ -2225,6 +2232,37 @@ extern "C" int mdh_bands_allreduce_local(mdh_ctx** bands, int n) {
     return MDH_OK;
 }
 
+// Several band contexts of ONE process on one device (row bands tiled on a single GPU): every context brings six streams of its
+// own, and the runtime maps all of them onto a handful of hardware queues -- two unrelated streams that land on one queue wait
+// for each other (rocprofv3 of 8 bands, round 4: band b + 1's window kernel started when band b's export had finished; nothing
+// overlapped, 23 % of the run had a kernel on the GPU).  A band context that borrows the streams of a sibling queues its stages on
+// the SAME main / noise / post streams: the bands' window kernels follow each other on one stream while their post stages run on
+// another, and the process needs no more queues than one context.  Call right after mdh_create, before the first pass; the
+// donor must outlive the borrower.
+extern "C" int mdh_share_streams(mdh_ctx* c, mdh_ctx* donor) {
+    if (!c || !donor || c == donor) { set_err("mdh_share_streams: bad argument"); return MDH_E_ARG; }
+    if (c->device != donor->device) { set_err("mdh_share_streams: the two contexts are on different devices"); return MDH_E_ARG; }
+    if (c->t != 0 || c->in_flight || c->pending || c->band_slot || c->pass_seq != 0) {
+        set_err("mdh_share_streams: the context has already run a pass");
+        return MDH_E_STATE;
+    }
+    if (c->streams_borrowed) { set_err("mdh_share_streams: the context borrows its streams already"); return MDH_E_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    hipStream_t own[] = {c->mstream[0], c->mstream[1], c->nstream, c->cstream, c->pstream[0], c->pstream[1]};
+    for (hipStream_t q : own)
+        if (q) hipStreamDestroy(q);
+    c->mstream[0] = donor->mstream[0];
+    c->mstream[1] = donor->mstream[1];
+    c->nstream = donor->nstream;
+    c->cstream = donor->cstream;
+    c->pstream[0] = donor->pstream[0];
+    c->pstream[1] = donor->pstream[1];
+    c->stream = c->mstream[0];
+    c->streams_borrowed = true;
+    return MDH_OK;
+}
+
 extern "C" int mdh_band_skip(mdh_ctx* c) {
     if (!c) { set_err("mdh_band_skip: null context"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_skip: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
@@ -2586,7 +2624,7 @@ static int pre_init(mdh_pre* p, const uint8_t* mask01) {
             const int byte0 = (c_first * 3) & ~15;
             cap = std::max(cap, (((c_last + 1) * 3 - byte0) + 15) & ~15);
         }
-        if (2 * cap <= 64 * 1024) p->span_cap = cap;
+        if (2 * PRE_ROWS * cap <= 64 * 1024) p->span_cap = cap;
     }
     int rc;
     if ((rc = dev_alloc(p->d_xi, xi.size(), false)) || (rc = dev_alloc(p->d_yi, yi.size(), false)) ||
@@ -2658,7 +2696,8 @@ extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int 
     }
     uint8_t* dst = out_on_device ? out : p->d_out;
     if (p->span_cap > 0 && ((uintptr_t)src & 15) == 0 && n_out <= 65535 && p->g.dh <= 65535)
-        hipLaunchKernelGGL(k_preprocess_rows, dim3((p->g.dw + PRE_SEG - 1) / PRE_SEG, p->g.dh, n_out), dim3(PRE_SEG), 2 * (size_t)p->span_cap, p->stream,
+        hipLaunchKernelGGL(k_preprocess_rows, dim3((p->g.dw + PRE_SEG - 1) / PRE_SEG, (p->g.dh + PRE_ROWS - 1) / PRE_ROWS, n_out), dim3(PRE_SEG),
+                           2 * PRE_ROWS * (size_t)p->span_cap, p->stream,
                            src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap);
     else
     hipLaunchKernelGGL(k_preprocess, dim3((px + 255) / 256, n_out), dim3(256), 0, p->stream, src, exp_frame, p->g, p->d_xi, p->d_xw,

@@ -293,25 +293,31 @@ __device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw,
     const ActWord a = row[gw];
     return a.tag == t ? a.bits : 0ull;
 }
-// Block bit counts of b (sparse format) and the list of TOUCHED blocks.
-// blockcnt is one per-slot allocation  [Kcap][nb][WW] counts | [Kcap][nb * WW] touched block ids | [Kcap * WORKCNT_STRIDE] counts of
-// touched blocks per frame.  The counts are all-zero between passes; a word of b with set bits adds its population to its block,
-// and the add that finds the count at zero also appends the block to its frame's touched list.  The morphology's work selection
-// (k_morph_select_touched) then walks the touched blocks' neighbourhoods instead of every block of every frame, and the slot's
+// Block bit counts of b (sparse format) and the BITMAP of touched blocks.
+// blockcnt is one per-slot allocation  [Kcap][nb][WW] counts | [Kcap][nb][S] bitmap, S = ceil(WW / 32): bit (w & 31) of dword
+// (band, w >> 5) of frame i says that block (band, w) has a non-zero count.  The counts and the bitmap are all-zero between passes; a
+// word of b with set bits adds its population to its block and sets the block's bit.  The morphology's work selection
+// (k_morph_select_touched) walks the 3x3 neighbourhoods of the set bits instead of every block of every frame, and the slot's
 // next k_pass_prepare zeroes exactly the touched counts again -- round 3 zeroed (65 MB per 4000-frame 1080p pass) and scanned
-// (k_morph_select: a thread per block, 16 M threads per pass) the whole table for the < 1 % of it that a quiet sky touches.
+// (k_morph_select: a thread per block, 16 M threads per pass) the whole table for the < 1 % of it that a quiet sky touches; the
+// bitmap of such a pass is 2 MB.
+// Both atomics are NON-RETURNING on purpose.  The first version of this (lists of touched block ids, appended by the add that
+// found its count at zero) needed the old count and a list position back: two returning atomics in the window kernel's rare path,
+// each behind an s_waitcnt vmcnt(0) that also drained the wave's eight prefetched frame loads -- 1 % of the wave-frames, and the
+// launch 12-15 % slower (1080p: 1.58 -> 1.79 ms, 4K: 1.55 -> 1.85 ms on one box, gpurun_out/r04_09-10).
+__device__ __forceinline__ unsigned block_bitmap_stride(const PassGeom& g) {  // dwords per frame
+    return (unsigned)((g.H + MORPH_RB - 1) / MORPH_RB) * (unsigned)((g.WW + 31) >> 5);
+}
 template <bool LIST>
 __device__ __forceinline__ void note_block(unsigned* __restrict__ blockcnt, const PassGeom& g, int i, int gw, unsigned pop) {
     const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
     const unsigned per_frame = (unsigned)(nbands * g.WW);
-    const unsigned blk = (unsigned)(gw / g.WW / MORPH_RB) * (unsigned)g.WW + (unsigned)(gw % g.WW);
-    const unsigned old = atomicAdd(&blockcnt[(size_t)i * per_frame + blk], pop);
+    const unsigned band = (unsigned)(gw / g.WW / MORPH_RB), w = (unsigned)(gw % g.WW);
+    atomicAdd(&blockcnt[(size_t)i * per_frame + band * (unsigned)g.WW + w], pop);
     if constexpr (LIST) {
-        if (old == 0) {
-            unsigned* touched = blockcnt + (size_t)g.Kcap * per_frame;
-            unsigned* tcnt = touched + (size_t)g.Kcap * per_frame;
-            touched[(size_t)i * per_frame + atomicAdd(&tcnt[(size_t)i * WORKCNT_STRIDE], 1u)] = blk;
-        }
+        const unsigned S = (unsigned)((g.WW + 31) >> 5);
+        unsigned* bitmap = blockcnt + (size_t)g.Kcap * per_frame;
+        atomicOr(&bitmap[(size_t)i * (nbands * S) + band * S + (w >> 5)], 1u << (w & 31));
     }
 }
 
@@ -1161,10 +1167,9 @@ __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ bl
 // counter serialised the selection on a dense binary (a lowered threshold lets noise through: every block of every frame is kept):
 // 130 k same-address atomics, 1.35 ms per 128 frames at 8K.  With a counter per frame the appends of different frames go to
 // different L2 channels.
-// Round 4: the candidates are the 3x3 neighbourhoods of the TOUCHED blocks (note_block's lists), not every block of the frame.  One
-// wave per frame; a lane takes a (touched block B, neighbour o) pair, evaluates the output block O = B + o exactly as
-// morph_block_keep does, and reports it if B is the first block with a non-zero count in O's own neighbourhood (scan order), so
-// that every kept block is listed exactly once whatever the order of the touched list.
+// Round 4: the candidates are the 3x3 neighbourhoods of the TOUCHED blocks (note_block's bitmap), not every block of the frame.
+// One wave per frame; a lane takes a dword of the bitmap (32 blocks of one band), dilates it by one block in both directions from
+// the dwords around it, and the wave evaluates the candidate blocks one per lane and round exactly as morph_block_keep does.
 __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
                                                               unsigned* __restrict__ workcount, PassGeom g) {
     RAISE_WAVE_PRIORITY();
@@ -1173,46 +1178,53 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= g.K) return;
     const int lane = threadIdx.x & 63;
-    const unsigned* touched = blockcnt + (size_t)g.Kcap * per_frame;
-    const unsigned* tcnt = touched + (size_t)g.Kcap * per_frame;
-    const unsigned cnt = tcnt[(size_t)i * WORKCNT_STRIDE];
-    const unsigned* f = blockcnt + (size_t)i * per_frame;
-    for (unsigned p0 = 0; p0 < 9u * cnt; p0 += 64) {
-        const unsigned p = p0 + lane;
-        bool keep = false;
-        int out_blk = 0;
-        if (p < 9u * cnt) {
-            const unsigned e = p / 9u, o = p - 9u * e;
-            const int blk = (int)touched[(size_t)i * per_frame + e];
-            const int bband = blk / g.WW, bw = blk - bband * g.WW;
-            const int band = bband + (int)(o / 3u) - 1, w = bw + (int)(o % 3u) - 1;  // the output block O
-            if (band >= 0 && band < nb && w >= 0 && w < g.WW) {
-                unsigned total = 0;
-                int first = -1;
-                for (int db = -1; db <= 1; ++db) {
-                    const int bb = band + db;
-                    if (bb < 0 || bb >= nb) continue;
-                    for (int dw = -1; dw <= 1; ++dw) {
-                        const int ww = w + dw;
-                        if (ww < 0 || ww >= g.WW) continue;
-                        const unsigned c = f[bb * g.WW + ww];
-                        total += c;
-                        if (c && first < 0) first = bb * g.WW + ww;
-                    }
-                }
-                const int y0 = band * MORPH_RB;
-                const unsigned my = (y0 - 3 < 0 || y0 + MORPH_RB + 2 > g.H - 1) ? 2u : 1u;
-                const unsigned mx = (w == 0 || 64 * (w + 1) + 3 > g.W - 1) ? 2u : 1u;
-                keep = first == blk && total * my * mx >= 5u;
-                out_blk = band * g.WW + w;
-            }
-        }
+    const int S = (g.WW + 31) >> 5;
+    const unsigned stride = (unsigned)(nb * S);
+    const unsigned* bm = blockcnt + (size_t)g.Kcap * per_frame + (size_t)i * stride;
+    unsigned cnt = 0;
+    for (unsigned d = (unsigned)lane; d < stride; d += 64) cnt += (unsigned)__popc(bm[d]);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (cnt == 0) return;
+    auto append = [&](bool keep, int blk) {
         const u64 m = __ballot(keep);
-        if (!m) continue;
+        if (!m) return;
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(&workcount[(size_t)i * WORKCNT_STRIDE], (unsigned)__popcll(m));
         base = __shfl(base, 0);
-        if (keep) worklist[(size_t)i * per_frame + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * per_frame + (unsigned)out_blk;
+        if (keep) worklist[(size_t)i * per_frame + base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)i * per_frame + (unsigned)blk;
+    };
+    if (9u * cnt >= per_frame) {
+        // a frame with most of its blocks touched (a binary with noise in it, before the pass format flips to dense): every block
+        // tests itself, as round 3's selection did for all frames
+        for (unsigned b0 = 0; b0 < per_frame; b0 += 64) {
+            const int tid = (int)b0 + lane;
+            append(morph_block_keep(blockcnt, g, i, tid), tid);
+        }
+        return;
+    }
+    for (unsigned d0 = 0; d0 < stride; d0 += 64) {
+        const unsigned d = d0 + (unsigned)lane;
+        const int band = (int)(d / (unsigned)S), seg = (int)(d - (unsigned)band * (unsigned)S);
+        unsigned cand = 0;
+        if (d < stride) {
+            for (int db = -1; db <= 1; ++db) {
+                const int bb = band + db;
+                if (bb < 0 || bb >= nb) continue;
+                const unsigned x = bm[bb * S + seg];
+                const unsigned l = seg > 0 ? bm[bb * S + seg - 1] : 0u;
+                const unsigned r = seg + 1 < S ? bm[bb * S + seg + 1] : 0u;
+                cand |= x | (x << 1) | (x >> 1) | (l >> 31) | (r << 31);
+            }
+            const int left = g.WW - 32 * seg;  // blocks of this band the dword covers
+            if (left < 32) cand &= (1u << left) - 1u;
+        }
+        while (__ballot(cand != 0)) {
+            const bool have = cand != 0;
+            const int b = have ? __builtin_ctz(cand) : 0;
+            cand &= cand - 1u;  // (0 stays 0)
+            const int tid = band * g.WW + 32 * seg + b;
+            append(have && morph_block_keep(blockcnt, g, i, tid), tid);
+        }
     }
 }
 
@@ -1505,15 +1517,67 @@ __device__ __forceinline__ u128 dpp_row_u128(u128 v, bool from_below) {
                           : (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x111, 0xF, 0xF, false);  // row_shr:1
     return (u128)w[0] | ((u128)w[1] << 32) | ((u128)w[2] << 64) | ((u128)w[3] << 96);
 }
+// One listed block per 16-lane group (see above).  src / dst: word 0 of the frame's b image / of its row in the ring of binaries;
+// idx_base: the frame's first word in the pass-wide numbering of the non-zero list.  Whole waves call it together (DPP, ballot).
+// The words that come out are stored at once; their list entries are QUEUED in the wave's LDS (q, qn) and appended by
+// morph_nz_flush with ONE atomic on the pass's list counter per flush: every append of every wave of a pass meets in that one
+// counter, and an atomic per group of four blocks (25 k per 16 000-frame pass at 960x540) made the launch wait on it.
+#define MORPH_NZQ 512
+__device__ __forceinline__ void morph_nz_flush(unsigned* __restrict__ q, unsigned& qn, unsigned* __restrict__ nzlist,
+                                               unsigned* __restrict__ nzcount, int lane) {
+    if (qn == 0) return;  // (wave-uniform)
+    __syncthreads();      // (one wave per workgroup: orders the queue's LDS writes before the reads below)
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(nzcount, qn);
+    base = __shfl(base, 0);
+    for (unsigned e = (unsigned)lane; e < qn; e += 64) nzlist[base + e] = q[e];
+    __syncthreads();
+    qn = 0;
+}
+__device__ __forceinline__ void morph_close_group_t(const ActWord* __restrict__ src, u64 t, ActWord* __restrict__ dst, unsigned idx_base,
+                                                    bool have, int blk, unsigned* __restrict__ q, unsigned& qn, const PassGeom& g,
+                                                    int lane, int j) {
+    const u128 ones = ~(u128)0;
+    const int band = blk / g.WW, w = blk - band * g.WW;
+    const int y0 = band * MORPH_RB;
+    const int yy = y0 - 3 + j;  // this lane's row (j = 14, 15: spare lanes, harmless)
+    const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
+    const Win wq = make_win(w, g.W);
+    u128 b = 0;
+    if (have && j < 14) b = load_win_act(src + (size_t)yc * g.WW, w, g.WW, t);
+    // median of this lane's row from the rows above and below (lanes j - 1, j + 1)
+    u128 h0, h1;
+    hsum3_replicate(b, wq, h0, h1);
+    const u128 a0 = dpp_row_u128(h0, false), a1 = dpp_row_u128(h1, false);
+    const u128 c0 = dpp_row_u128(h0, true), c1 = dpp_row_u128(h1, true);
+    u128 med = 0;
+    if (yy >= 0 && yy < g.H && j >= 1 && j <= 12) med = count_ge5(a0, a1, h0, h1, c0, c1) & wq.valid;
+    // dilate
+    const u128 dil = hor_or3(dpp_row_u128(med, false) | med | dpp_row_u128(med, true)) & wq.valid;
+    // erode: horizontal part per row (a dilate row outside the image never wins), then the three rows
+    const u128 e = (yy >= 0 && yy < g.H) ? hor_and3_open(dil, wq) : ones;
+    const u128 ea = dpp_row_u128(e, false), ec = dpp_row_u128(e, true);
+    u64 a = 0;
+    if (have && j >= 3 && j <= 10 && yy < g.H) a = (u64)((ea & e & ec & wq.valid) >> 3);
+    const u64 havem = __ballot(a != 0);
+    if (havem) {
+        if (a) {
+            dst[(size_t)yy * g.WW + w] = ActWord{a, t};
+            q[qn + __popcll(havem & ((1ull << lane) - 1))] = idx_base + (unsigned)((size_t)yy * g.WW + w);
+        }
+        qn += (unsigned)__popcll(havem);
+    }
+}
 __global__ void __launch_bounds__(64) k_morph_close_frame_t(const ActWord* __restrict__ bbits, const unsigned* __restrict__ blockcnt,
                                                             ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
                                                             unsigned* __restrict__ nzcount, PassGeom g) {
     RAISE_WAVE_PRIORITY();
+    __shared__ unsigned q[MORPH_NZQ];
+    unsigned qn = 0;
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15;
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     const long long t = g.t_base + 1;
     ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * g.H * g.WW;
-    const u128 ones = ~(u128)0;
     for (int b0 = blockIdx.x * 64; b0 < nb * g.WW; b0 += gridDim.x * 64) {
         u64 todo = __ballot(morph_block_keep(blockcnt, g, 0, b0 + lane));
         while (todo) {  // four listed blocks at a time, one per 16-lane group
@@ -1522,40 +1586,48 @@ __global__ void __launch_bounds__(64) k_morph_close_frame_t(const ActWord* __res
             const bool have = m != 0;
             const int blk = b0 + (have ? __builtin_ctzll(m) : 0);
             for (int k = 0; k < 4 && todo; ++k) todo &= todo - 1;
-            const int band = blk / g.WW, w = blk - band * g.WW;
-            const int y0 = band * MORPH_RB;
-            const int yy = y0 - 3 + j;  // this lane's row (j = 14, 15: spare lanes, harmless)
-            const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
-            const Win q = make_win(w, g.W);
-            u128 b = 0;
-            if (have && j < 14) b = load_win_act(bbits + (size_t)yc * g.WW, w, g.WW, (u64)t);
-            // median of this lane's row from the rows above and below (lanes j - 1, j + 1)
-            u128 h0, h1;
-            hsum3_replicate(b, q, h0, h1);
-            const u128 a0 = dpp_row_u128(h0, false), a1 = dpp_row_u128(h1, false);
-            const u128 c0 = dpp_row_u128(h0, true), c1 = dpp_row_u128(h1, true);
-            u128 med = 0;
-            if (yy >= 0 && yy < g.H && j >= 1 && j <= 12) med = count_ge5(a0, a1, h0, h1, c0, c1) & q.valid;
-            // dilate
-            const u128 dil = hor_or3(dpp_row_u128(med, false) | med | dpp_row_u128(med, true)) & q.valid;
-            // erode: horizontal part per row (a dilate row outside the image never wins), then the three rows
-            const u128 e = (yy >= 0 && yy < g.H) ? hor_and3_open(dil, q) : ones;
-            const u128 ea = dpp_row_u128(e, false), ec = dpp_row_u128(e, true);
-            u64 a = 0;
-            if (have && j >= 3 && j <= 10 && yy < g.H) a = (u64)((ea & e & ec & q.valid) >> 3);
-            const u64 havem = __ballot(a != 0);
-            if (havem) {
-                const int leader = __builtin_ctzll(havem);
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(nzcount, (unsigned)__popcll(havem));
-                base = __shfl(base, leader);
-                if (a) {
-                    dst[(size_t)yy * g.WW + w] = ActWord{a, (u64)t};
-                    nzlist[base + __popcll(havem & ((1ull << lane) - 1))] = (unsigned)((size_t)yy * g.WW + w);
-                }
-            }
+            morph_close_group_t(bbits, (u64)t, dst, 0u, have, blk, q, qn, g, lane, j);
+            if (qn > MORPH_NZQ - 64) morph_nz_flush(q, qn, nzlist, nzcount, lane);
         }
     }
+    morph_nz_flush(q, qn, nzlist, nzcount, lane);
+}
+// The batched passes' list kernel, TRANSPOSED as well (round 4).  k_morph_close gives a listed block to ONE lane, which walks its
+// fourteen input rows as fourteen dependent steps of three tagged loads each; on a quiet sky a pass lists a few dozen blocks for
+// one frame in three and none for the others, so the launch is a handful of lanes per wave on a serial chain of ~30 us: 0.58 ms
+// per 16 000-frame pass at 960x540, a third of the window kernel's time, at a few per cent of the machine.  Here a wave takes a
+// frame and four of its listed blocks at a time, a block's fourteen rows on fourteen lanes of a 16-lane group: sixteen times the
+// waves, each a fraction as long.  Frames with at least half of their blocks listed go to k_morph_close_dense as before.
+__global__ void __launch_bounds__(64) k_morph_close_t(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
+                                                      const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
+                                                      unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g,
+                                                      unsigned* __restrict__ dense) {
+    RAISE_WAVE_PRIORITY();
+    __shared__ unsigned q[MORPH_NZQ];
+    unsigned qn = 0;
+    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15;
+    const unsigned per_frame = (unsigned)(((g.H + MORPH_RB - 1) / MORPH_RB) * g.WW);
+    const size_t words = (size_t)g.H * g.WW;
+    for (unsigned i = blockIdx.x; i < (unsigned)g.K; i += gridDim.x) {
+        const unsigned cnt = workcount[(size_t)i * WORKCNT_STRIDE];
+        if (cnt == 0) continue;
+        if (dense != nullptr && 2u * cnt >= per_frame) {
+            if (lane == 0) dense[1 + atomicAdd(&dense[0], 1u)] = i;
+            continue;
+        }
+        const unsigned* seg = worklist + (size_t)i * per_frame;
+        const long long t = g.t_base + 1 + (long long)i;
+        const ActWord* src = bbits + (size_t)i * words;
+        ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * words;
+        for (unsigned e0 = 0; e0 < cnt; e0 += 4) {
+            const unsigned e = e0 + (unsigned)grp;
+            const bool have = e < cnt;
+            const int blk = have ? (int)(seg[e] - i * per_frame) : 0;
+            morph_close_group_t(src, (u64)t, dst, (unsigned)(i * words), have, blk, q, qn, g, lane, j);
+            if (qn > MORPH_NZQ - 64) morph_nz_flush(q, qn, nzlist, nzcount, lane);
+        }
+    }
+    morph_nz_flush(q, qn, nzlist, nzcount, lane);  // (one append for all the frames this wave walked)
 }
 __global__ void __launch_bounds__(64) k_morph_close(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                     const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
@@ -1662,7 +1734,7 @@ __global__ void __launch_bounds__(256) k_sparse_clear(u64* __restrict__ dst_bits
 // stages accumulate into, the block bit counts the slot's previous pass touched, the noise sums, and the dst words that pass left behind
 // (listed in nzlist; nzcount itself is reset by k_noise_finalize, which runs next on the same stream).
 __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ counters, unsigned n_counters,
-                                                      unsigned* __restrict__ blockcnt, unsigned per_frame, unsigned Kcap,
+                                                      unsigned* __restrict__ blockcnt, unsigned per_frame, unsigned WW, unsigned Kcap,
                                                       unsigned* __restrict__ sums32, unsigned n_sums32, u64* __restrict__ dst_bits,
                                                       const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount) {
     RAISE_WAVE_PRIORITY();
@@ -1675,18 +1747,22 @@ __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ cou
         const unsigned total = *nzcount;
         for (unsigned e = tid; e < total; e += nth) dst_bits[nzlist[e]] = 0;
     }
-    // the block bit counts the slot's previous pass touched (note_block's lists), and the lists' counts: a workgroup per frame
+    // the block bit counts the slot's previous pass touched (the set bits of note_block's bitmap), and the bitmap itself
     if (blockcnt != nullptr) {
-        unsigned* touched = blockcnt + (size_t)Kcap * per_frame;
-        unsigned* tcnt = touched + (size_t)Kcap * per_frame;
-        __shared__ unsigned s_cnt;
-        for (unsigned i = blockIdx.x; i < Kcap; i += gridDim.x) {
-            if (threadIdx.x == 0) s_cnt = tcnt[(size_t)i * WORKCNT_STRIDE];
-            __syncthreads();
-            const unsigned cnt = s_cnt;
-            for (unsigned e = threadIdx.x; e < cnt; e += blockDim.x) blockcnt[(size_t)i * per_frame + touched[(size_t)i * per_frame + e]] = 0;
-            __syncthreads();
-            if (threadIdx.x == 0 && cnt) tcnt[(size_t)i * WORKCNT_STRIDE] = 0;
+        unsigned* bitmap = blockcnt + (size_t)Kcap * per_frame;
+        const unsigned S = (WW + 31) >> 5, stride = (per_frame / WW) * S;
+        const size_t total = (size_t)Kcap * stride;
+        for (size_t e = tid; e < total; e += nth) {
+            unsigned v = bitmap[e];
+            if (v == 0) continue;
+            const unsigned i = (unsigned)(e / stride), d = (unsigned)(e - (size_t)i * stride);
+            const unsigned band = d / S, seg = d - band * S;
+            unsigned* f = blockcnt + (size_t)i * per_frame + band * WW + 32 * seg;
+            do {
+                f[__builtin_ctz(v)] = 0;
+                v &= v - 1u;
+            } while (v);
+            bitmap[e] = 0;
         }
     }
 }

@@ -57,60 +57,80 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint8_t* __restrict__ 
 // rows of a multiple of 16 bytes and a 16-byte aligned base (sw % 16 == 0: 3840, 2560, 1920, 1280 ...); other sizes keep the
 // kernel above.  Bytes the launch must move: the source rows the resize touches (2 of every 4 at a 4x reduction) + the output.
 #define PRE_SEG 256
+#define PRE_ROWS 4  // output rows per workgroup: eight source-row spans in flight per workgroup before its one barrier
 __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __restrict__ src, int exp_frame, PreGeom g,
                                                               const int* __restrict__ xi, const short* __restrict__ xw,
                                                               const int* __restrict__ yi, const short* __restrict__ yw,
                                                               const uint8_t* __restrict__ mask01, uint8_t* __restrict__ out, int span_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_rows[];  // [2][span_cap]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_rows[];  // [PRE_ROWS][2][span_cap]
     const int t = threadIdx.x;
-    const int dx0 = blockIdx.x * PRE_SEG, dy = blockIdx.y;
+    const int dx0 = blockIdx.x * PRE_SEG, dy0 = blockIdx.y * PRE_ROWS;
     const int cnt = min(PRE_SEG, g.dw - dx0);
+    const int nrows = min(PRE_ROWS, g.dh - dy0);
     src += (size_t)blockIdx.z * exp_frame * g.sh * g.sw * 3;
     out += (size_t)blockIdx.z * g.dh * g.dw;
     const int c_first = xi[dx0], c_last = min(xi[dx0 + cnt - 1] + 1, g.sw - 1);
     const int byte0 = (c_first * 3) & ~15;
     const int span = (((c_last + 1) * 3 - byte0) + 15) & ~15;  // (<= span_cap: the host sized it from the same table)
-    const int y0 = yi[dy], y1 = min(y0 + 1, g.sh - 1);
     const int dx = dx0 + t;
     const bool live = t < cnt;
-    int o0 = 0, o1 = 0, a0 = 0, a1 = 0, m = 1;
+    int o0 = 0, o1 = 0, a0 = 0, a1 = 0;
     if (live) {
         const int x0 = xi[dx], x1 = min(x0 + 1, g.sw - 1);
         o0 = x0 * 3 - byte0;
         o1 = x1 * 3 - byte0;
         a0 = xw[2 * dx];
         a1 = xw[2 * dx + 1];
-        m = mask01 ? mask01[(size_t)dy * g.dw + dx] : 1;
     }
-    const int b0 = yw[2 * dy], b1 = yw[2 * dy + 1];
     const size_t frame = (size_t)g.sh * g.sw * 3, row_bytes = (size_t)g.sw * 3;
-    int best = 0;
+    int best[PRE_ROWS];
+#pragma unroll
+    for (int r = 0; r < PRE_ROWS; ++r) best[r] = 0;
     for (int e = 0; e < exp_frame; ++e) {
-        const uint8_t* f = src + (size_t)e * frame;
-        const uint8_t* r0 = f + (size_t)y0 * row_bytes + byte0;
-        const uint8_t* r1 = f + (size_t)y1 * row_bytes + byte0;
+        const uint8_t* f = src + (size_t)e * frame + byte0;
         if (e) __syncthreads();
-        for (int o = t * 16; o < span; o += PRE_SEG * 16) {
-            *(uint4*)(lds_rows + o) = *(const uint4*)(r0 + o);
-            *(uint4*)(lds_rows + span_cap + o) = *(const uint4*)(r1 + o);
+#pragma unroll
+        for (int r = 0; r < PRE_ROWS; ++r) {
+            if (r < nrows) {
+                const int y0 = yi[dy0 + r], y1 = min(y0 + 1, g.sh - 1);
+                const uint8_t* r0 = f + (size_t)y0 * row_bytes;
+                const uint8_t* r1 = f + (size_t)y1 * row_bytes;
+                for (int o = t * 16; o < span; o += PRE_SEG * 16) {
+                    *(uint4*)(lds_rows + (size_t)(2 * r) * span_cap + o) = *(const uint4*)(r0 + o);
+                    *(uint4*)(lds_rows + (size_t)(2 * r + 1) * span_cap + o) = *(const uint4*)(r1 + o);
+                }
+            }
         }
         __syncthreads();
         if (live) {
-            const uint8_t* l0 = lds_rows;
-            const uint8_t* l1 = lds_rows + span_cap;
-            int ch[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int s0 = l0[o0 + c] * a0 + l0[o1 + c] * a1;
-                const int s1 = l1[o0 + c] * a0 + l1[o1 + c] * a1;
-                int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
-                ch[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            for (int r = 0; r < PRE_ROWS; ++r) {
+                if (r < nrows) {
+                    const uint8_t* l0 = lds_rows + (size_t)(2 * r) * span_cap;
+                    const uint8_t* l1 = l0 + span_cap;
+                    const int b0 = yw[2 * (dy0 + r)], b1 = yw[2 * (dy0 + r) + 1];
+                    int ch[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int s0 = l0[o0 + c] * a0 + l0[o1 + c] * a1;
+                        const int s1 = l1[o0 + c] * a0 + l1[o1 + c] * a1;
+                        int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+                        ch[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    }
+                    const int gray = (ch[0] * 3735 + ch[1] * 19235 + ch[2] * 9798 + 16384) >> 15;
+                    best[r] = max(best[r], gray & 0xFF);
+                }
             }
-            const int gray = ((ch[0] * 3735 + ch[1] * 19235 + ch[2] * 9798 + 16384) >> 15) * m;
-            best = max(best, gray & 0xFF);
         }
     }
-    if (live) out[(size_t)dy * g.dw + dx] = (uint8_t)best;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < PRE_ROWS; ++r)
+            if (r < nrows) {
+                const size_t p = (size_t)(dy0 + r) * g.dw + dx;
+                out[p] = (uint8_t)(mask01 ? best[r] * mask01[p] : best[r]);
+            }
+    }
 }
 
 // acc = max(acc, frame) over K frames of `bytes` bytes each; 16 bytes per lane (requires bytes % 16 == 0 for the

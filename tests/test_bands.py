@@ -203,13 +203,15 @@ def test_hip_synthetic_sky_in_bands():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shared_hough", [True, False])
-def test_hip_bands_resident_and_pipelined(shared_hough):
+@pytest.mark.parametrize("shared_hough,share_streams", [(True, "1"), (True, "0"), (False, "1")])
+def test_hip_bands_resident_and_pipelined(shared_hough, share_streams, monkeypatch):
     """Band rows resident in HBM, two passes in flight, nothing waits for the GPU between submit and collect (queued band steps,
     device-side sum of the noise sums, event-chained hand-over to the Hough stage): same results as the oracle, pass by pass --
     with ONE Hough context fed directly by the bands' export kernels (the single-process default) and with one Hough context
-    per band behind an all-to-all of device-to-device copies (the multi-GPU structure)."""
+    per band behind an all-to-all of device-to-device copies (the multi-GPU structure).  share_streams: the band contexts of the
+    process queue their stages on band 0's streams (mdh_share_streams, the default) or each on its own."""
     from tests.helpers import binary_cfg
+    monkeypatch.setenv("MDH_BANDS_SHARE_STREAMS", share_streams)
     H, W, n, K, nbands = 272, 512, 8, 24, 4
     cfg = binary_cfg()
     mask = np.ones((H, W), np.uint8)
