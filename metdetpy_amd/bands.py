@@ -196,9 +196,10 @@ class LocalBands:
         if self.shared:
             self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device, with_hough=False) for b in range(p.nbands)]
             self.hough = self.engines[0].shared_hough_context(max_batch)
-            # the bands of one process queue their stages on band 0's streams (mdh_share_streams: unrelated streams that land on
-            # one hardware queue serialise; MDH_BANDS_SHARE_STREAMS=0 keeps a set of streams per band, A/B)
-            if os.environ.get("MDH_BANDS_SHARE_STREAMS", "1") != "0":
+            # MDH_BANDS_SHARE_STREAMS=1: the bands of one process queue their stages on band 0's streams (mdh_share_streams).  Off
+            # by default: measured slower on one MI355X (8 bands of an 8K stream: 30 k frames/s shared against 52 k with a set of
+            # streams per band at 4 hardware queues, 50 k / 47 k at 8 / 12 queues; profiles/EXPERIMENTS.md, round 4)
+            if os.environ.get("MDH_BANDS_SHARE_STREAMS", "0") == "1":
                 for e in self.engines[1:]:
                     e.band.share_streams_of(self.engines[0].band)
         else:
