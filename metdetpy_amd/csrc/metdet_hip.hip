@@ -191,6 +191,7 @@ struct mdh_ctx {
     float* d_trig = nullptr;
     const unsigned short* d_perm = nullptr;  // PPHT visiting-order tables (shared by every context on the device)
     int lds_small = 80 * 1024, lds_large = 160 * 1024;  // dynamic LDS of the two three-wave PPHT launches (MDH_HOUGH_LDS_SMALL / _LARGE)
+    int lds_tiny = 40 * 1024;                           // ... and of the launch for short streaks (MDH_HOUGH_LDS_TINY; 0: no such launch)
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     uint8_t* d_expand = nullptr;
     Slot slot[NSLOT_MAX];
@@ -595,8 +596,8 @@ static int create_impl(mdh_ctx* c) {
             } else {
                 TRY(dev_alloc(s.d_planes, 2 * K * words));
             }
-            // [K][nb][WW] block bit counts | [K][nb][ceil(WW / 32)] bitmap of the blocks with a non-zero count (note_block)
-            TRY(dev_alloc(s.d_bandflag, K * nb * c->WW + K * nb * (size_t)((c->WW + 31) / 32)));
+            // [K][nb * WW] block bit counts | [K][ceil(nb * WW / 32)] bitmap of the blocks with a non-zero count (note_block)
+            TRY(dev_alloc(s.d_bandflag, K * nb * c->WW + K * ((nb * c->WW + 31) / 32)));
             TRY(dev_alloc(s.d_nzlist, K * words, false));
         }
         TRY(dev_alloc(s.d_nzcount, 4));  // [0] listed words, [1] listed morphology blocks, [2..3] u64: words of b with set bits (window kernel)
@@ -760,6 +761,11 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
+    // (frames of up to a megapixel only: at 960x540 the Hough stage is the largest item next to the window kernel and four
+    // short-streak frames per CU are worth 2-6 % at the pipeline's pace; at 1080p and 4K the extra launch buys nothing or costs 1-2 %)
+    if ((size_t)H * W > (size_t)1 << 20) c->lds_tiny = 0;
+    if (const char* v = getenv("MDH_HOUGH_LDS_TINY")) c->lds_tiny = std::max(0, std::min(c->lds_small, atoi(v)));
+    if (c->lds_tiny >= c->lds_small) c->lds_tiny = 0;
     if (role != MDH_ROLE_FULL) c->nmain = 1;  // (see post_stream)
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
     if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
@@ -857,6 +863,11 @@ extern "C" int mdh_profile_read(mdh_ctx* c, double* ms, int64_t* launches, int r
 // queue behind the Hough hand-over of pass p); band / Hough contexts of a tiled stream use ONE: a tiling runs 2 N contexts side by
 // side, and every extra active stream is one more client of the command processor's few hardware queues (8 bands + 8 Hough
 // contexts on one device: 104 active streams, 13 k frames/s).
+// MDH_SKIP_STAGES (timing experiments only -- results are WRONG): bit 0 noise sums, bit 1 morphology, bit 2 dynamic mask, bit 3 Hough
+static inline int skip_stages() {
+    static const int v = getenv("MDH_SKIP_STAGES") ? atoi(getenv("MDH_SKIP_STAGES")) : 0;
+    return v;
+}
 static inline hipStream_t post_stream(const mdh_ctx* c, int64_t seq) { return c->pstream[c->role == MDH_ROLE_FULL ? (seq & 1) : 0]; }
 
 static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
@@ -1151,7 +1162,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     const bool m3 = c->cfg.detector == MDH_DET_M3;
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
                        (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag,
-                       (unsigned)(nb * c->WW), (unsigned)c->WW, (unsigned)c->Kmax,  // (only what the slot's previous pass touched)
+                       (unsigned)(nb * c->WW), (unsigned)c->Kmax,  // (only what the slot's previous pass touched)
                        (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
@@ -1159,6 +1170,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
         span_begin(c, KK_NOISE_SUMS, c->nstream);
         if (rh <= 0 || rw <= 0) {
             // row-band tiling: this band holds no row of the noise ROI; its share of the sums is zero
+        } else if (skip_stages() & 1) {
         } else if (aligned4) {
             const int xa = r[1] & ~3;
             const int nx4 = (r[1] + rw - xa + 3) >> 2;
@@ -1306,6 +1318,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
             else
             hipLaunchKernelGGL(k_morph_close_frame, dim3((unsigned)((nb * c->WW + 63) / 64)), dim3(64), 0, post, sl.d_bbits, sl.d_bandflag, c->d_act,
                                sl.d_nzlist, sl.d_nzcount, g);
+        } else if (skip_stages() & 2) {
         } else {
         static const bool all_dense = getenv("MDH_ALL_DENSE") != nullptr;  // experiment: no block counters, every frame direct-mapped
         if (all_dense) {
@@ -1337,6 +1350,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         if (c->prev_slot >= 0 && c->prev_slot != (int)(&sl - c->slot))
             EV_WAIT(c, post, c->slot[c->prev_slot].ev_close);
         span_begin(c, KK_DY_APPLY, post);
+        if (!(skip_stages() & 4))
         hipLaunchKernelGGL(k_dy_sparse, dim3(c->lean && K == 1 ? 64 : 2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
                            sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
         span_end(c, post);
@@ -1381,6 +1395,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.tier_list = hs.d_tier_list; P.tier_count = hs.d_tier_count; P.K = K;
     // (lean mode: one three-wave launch with the large LDS takes every frame that fits; an empty launch less in the chain)
     P.lds_small = c->lean ? c->lds_large : c->lds_small; P.lds_large = c->lds_large;
+    P.lds_tiny = c->lean ? 0 : c->lds_tiny;
     P.all_one_wave = c->hough_one_wave;
     P.perm = c->d_perm;
     P.mute = (int)std::max<int64_t>(0, std::min<int64_t>(K, c->mute_until - sl.t_base));
@@ -1394,7 +1409,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     EV_WAIT(c, hstream[0], sl.ev_pix);
     bool large_split = false;
     span_begin(c, KK_HOUGH, hstream[0]);
-    static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr;  // timing experiments only: results are wrong
+    static const bool skip_hough = getenv("MDH_SKIP_HOUGH") != nullptr || (skip_stages() & 8);  // timing experiments only: results are wrong
     if (c->lean && K == 1 && !skip_hough) {
         // the per-frame protocol: routing + replay + packing in one launch (k_hough_single), then the one result copy
         P.lds_small = P.lds_large;
@@ -1459,10 +1474,17 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
             tier(1);
             launch_h3(false, std::min(K, grid_l), hstream[1]);
         }
+        if (P.lds_tiny > 0) {  // short streaks, four frames per CU: in front of the (at such sizes empty) launches of this stream
+            tier(4);
+            P.lds_bytes = P.lds_tiny;
+            launch_h3(false, std::min(K, grid_s), hstream[1]);
+            P.lds_bytes = c->lds_large;
+        }
         tier(2);
         if (big && !c->lean) {
-            if (P.dbg_phase) hipLaunchKernelGGL(k_hough3_big<true>, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
-            else hipLaunchKernelGGL(k_hough3_big<false>, dim3(std::min(K, hs.pool)), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+            const int gb = std::min(K, hs.pool);  // (a work queue: any grid is correct; capped at 8 or 1 it changes nothing at 1080p / 960x540, where the launch is empty)
+            if (P.dbg_phase) hipLaunchKernelGGL(k_hough3_big<true>, dim3(gb), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
+            else hipLaunchKernelGGL(k_hough3_big<false>, dim3(gb), dim3(HOUGH3_THREADS), P.lds_bytes, hstream[1], P);
         } else
         launch_h3(true, std::min(K, hs.pool), hstream[1]);
         tier(3);

@@ -16,7 +16,7 @@ typedef unsigned long long u64;
 typedef unsigned __int128 u128;
 
 #define NUM_ANGLE 180
-#define HOUGH_TIERS 4  // launches a pass's frames are routed to (k_hough_classify)
+#define HOUGH_TIERS 5  // launches a pass's frames are routed to (k_hough_classify)
 #define MAX_LINES 512
 #define WORKCNT_STRIDE 32  // the per-frame counts of the morphology work list sit one 128-byte line apart: packed, the appends of 32
                            // frames met in ONE L2 channel (k_morph_select 2.1 ms per pass of 512 dense 8K frames, rocprofv3 round 2c)
@@ -294,8 +294,8 @@ __device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw,
     return a.tag == t ? a.bits : 0ull;
 }
 // Block bit counts of b (sparse format) and the BITMAP of touched blocks.
-// blockcnt is one per-slot allocation  [Kcap][nb][WW] counts | [Kcap][nb][S] bitmap, S = ceil(WW / 32): bit (w & 31) of dword
-// (band, w >> 5) of frame i says that block (band, w) has a non-zero count.  The counts and the bitmap are all-zero between passes; a
+// blockcnt is one per-slot allocation  [Kcap][nb * WW] counts | [Kcap][ceil(nb * WW / 32)] bitmap: bit (blk & 31) of dword blk >> 5
+// of frame i says that block blk = band * WW + w has a non-zero count.  The counts and the bitmap are all-zero between passes; a
 // word of b with set bits adds its population to its block and sets the block's bit.  The morphology's work selection
 // (k_morph_select_touched) walks the 3x3 neighbourhoods of the set bits instead of every block of every frame, and the slot's
 // next k_pass_prepare zeroes exactly the touched counts again -- round 3 zeroed (65 MB per 4000-frame 1080p pass) and scanned
@@ -304,20 +304,20 @@ __device__ __forceinline__ u64 act_word(const ActWord* __restrict__ row, int gw,
 // Both atomics are NON-RETURNING on purpose.  The first version of this (lists of touched block ids, appended by the add that
 // found its count at zero) needed the old count and a list position back: two returning atomics in the window kernel's rare path,
 // each behind an s_waitcnt vmcnt(0) that also drained the wave's eight prefetched frame loads -- 1 % of the wave-frames, and the
-// launch 12-15 % slower (1080p: 1.58 -> 1.79 ms, 4K: 1.55 -> 1.85 ms on one box, gpurun_out/r04_09-10).
-__device__ __forceinline__ unsigned block_bitmap_stride(const PassGeom& g) {  // dwords per frame
-    return (unsigned)((g.H + MORPH_RB - 1) / MORPH_RB) * (unsigned)((g.WW + 31) >> 5);
-}
+// launch 12-15 % slower (1080p: 1.58 -> 1.79 ms, 4K: 1.55 -> 1.85 ms on one box, gpurun_out/r04_09-10).  The bitmap is indexed by
+// the block number itself (no padding per band): the rare path's address arithmetic is the peak of the window kernel's register
+// use, and three registers more there (154 instead of 151 at n = 8: 160 allocated) leave no room for a Hough wave beside three
+// window waves on a SIMD.
+__device__ __forceinline__ unsigned block_bitmap_stride(unsigned per_frame) { return (per_frame + 31u) >> 5; }  // dwords per frame
 template <bool LIST>
 __device__ __forceinline__ void note_block(unsigned* __restrict__ blockcnt, const PassGeom& g, int i, int gw, unsigned pop) {
     const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
     const unsigned per_frame = (unsigned)(nbands * g.WW);
-    const unsigned band = (unsigned)(gw / g.WW / MORPH_RB), w = (unsigned)(gw % g.WW);
-    atomicAdd(&blockcnt[(size_t)i * per_frame + band * (unsigned)g.WW + w], pop);
+    const unsigned blk = (unsigned)(gw / g.WW / MORPH_RB) * (unsigned)g.WW + (unsigned)(gw % g.WW);
+    atomicAdd(&blockcnt[(size_t)i * per_frame + blk], pop);
     if constexpr (LIST) {
-        const unsigned S = (unsigned)((g.WW + 31) >> 5);
         unsigned* bitmap = blockcnt + (size_t)g.Kcap * per_frame;
-        atomicOr(&bitmap[(size_t)i * (nbands * S) + band * S + (w >> 5)], 1u << (w & 31));
+        atomicOr(&bitmap[(size_t)i * block_bitmap_stride(per_frame) + (blk >> 5)], 1u << (blk & 31));
     }
 }
 
@@ -905,9 +905,14 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                             if (q == 0 && gw < words) ((u64*)bbits)[(size_t)i * words + gw] = v;
                         } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
-                            bbits[(size_t)i * words + gw] = ActWord{v, (u64)(g.t_base + 1 + i)};
+                            // (the word index through an opaque move: everything derived from it -- the store's address, the block
+                            // number, the bitmap's dword and bit -- is otherwise hoisted out of the frame loop as per-lane constants
+                            // and held in registers for the whole launch: 154 instead of 148 at n = 8)
+                            int gwr = gw;
+                            asm volatile("" : "+v"(gwr));
+                            bbits[(size_t)i * words + gwr] = ActWord{v, (u64)(g.t_base + 1 + i)};
                             // (LEAN: one frame, its morphology looks at the frame's block counts directly: no list)
-                            if (blockcnt != nullptr) note_block<!LEAN>(blockcnt, g, i, gw, (unsigned)__popcll(v));  // rare
+                            if (blockcnt != nullptr) note_block<!LEAN>(blockcnt, g, i, gwr, (unsigned)__popcll(v));  // rare
                         }
                         }
                     }
@@ -924,8 +929,23 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
         if (nzwords != nullptr && lane == 0 && nz_mine) atomicAdd(nzwords, (unsigned long long)nz_mine);
     }
 }
+// waves per SIMD the instantiation is held to (0: whatever its natural register use allows).  Only the raw-window build asks: its
+// n = 16 kernel lands three registers above the 168 that three waves per SIMD allow (A/B builds: -DWIDE_RAW_MINN=2 -DWIDE_RAW_OCC=1)
+#ifndef WIDE_RAW_OCC
+#define WIDE_RAW_OCC 0
+#endif
+template <int N, int PPL, bool LEAN>
+constexpr int wide_min_waves() {
+    return (WIDE_RAW_OCC != 0 && WIDE_MAX3 != 0 && !LEAN && PPL == 16 && N >= WIDE_RAW_MINN) ? (N <= 8 ? 4 : (N <= 16 ? 3 : 0)) : 0;
+}
 template <int N, int PPL, bool LEAN, bool DENSE = false>
-__global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
+__global__ void
+#if WIDE_RAW_OCC
+__launch_bounds__(256, (wide_min_waves<N, PPL, LEAN>()))
+#else
+__launch_bounds__(256)
+#endif
+WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                               unsigned* __restrict__ blockcnt, PassGeom g, int Tc,
                                                               LeanArgs lean, unsigned long long* __restrict__ nzwords) {
@@ -1178,8 +1198,7 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= g.K) return;
     const int lane = threadIdx.x & 63;
-    const int S = (g.WW + 31) >> 5;
-    const unsigned stride = (unsigned)(nb * S);
+    const unsigned stride = block_bitmap_stride(per_frame);
     const unsigned* bm = blockcnt + (size_t)g.Kcap * per_frame + (size_t)i * stride;
     unsigned cnt = 0;
     for (unsigned d = (unsigned)lane; d < stride; d += 64) cnt += (unsigned)__popc(bm[d]);
@@ -1202,29 +1221,54 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
         }
         return;
     }
+    // 32 bitmap bits starting at bit position pos of the frame's bitmap (positions outside [0, 32 * stride) read as zero)
+    auto bits_at = [&](int pos) -> unsigned {
+        const int d = pos >> 5, sh = pos & 31;  // (arithmetic shift: d = floor(pos / 32))
+        const unsigned lo = (d >= 0 && d < (int)stride) ? bm[d] : 0u;
+        const unsigned hi = (d + 1 >= 0 && d + 1 < (int)stride) ? bm[d + 1] : 0u;
+        return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    };
+    // The candidates of 64 bitmap dwords are first compacted into the wave's queue in LDS (entry = lane << 5 | bit), then evaluated
+    // 64 at a time: a streak's candidates sit in a few dwords (a dozen bits each in two or three lanes), and evaluated straight from
+    // the lanes' own masks the wave ran a dozen rounds of nine dependent loads for three live lanes each.
+    // A block is a candidate when a touched block sits at distance -1, 0, +1 in the linear numbering of its own band or of the bands
+    // above and below: at the ends of a band that also names the neighbouring band's far end -- a few candidates too many, which
+    // morph_block_keep (the exact test, on the counts) turns down like any other.
+    __shared__ unsigned short s_q[4][2048];
+    unsigned short* q = s_q[threadIdx.x >> 6];
     for (unsigned d0 = 0; d0 < stride; d0 += 64) {
         const unsigned d = d0 + (unsigned)lane;
-        const int band = (int)(d / (unsigned)S), seg = (int)(d - (unsigned)band * (unsigned)S);
         unsigned cand = 0;
         if (d < stride) {
-            for (int db = -1; db <= 1; ++db) {
-                const int bb = band + db;
-                if (bb < 0 || bb >= nb) continue;
-                const unsigned x = bm[bb * S + seg];
-                const unsigned l = seg > 0 ? bm[bb * S + seg - 1] : 0u;
-                const unsigned r = seg + 1 < S ? bm[bb * S + seg + 1] : 0u;
-                cand |= x | (x << 1) | (x >> 1) | (l >> 31) | (r << 31);
-            }
-            const int left = g.WW - 32 * seg;  // blocks of this band the dword covers
+            const int p = 32 * (int)d;
+            for (int dy = -g.WW; dy <= g.WW; dy += g.WW) cand |= bits_at(p + dy - 1) | bits_at(p + dy) | bits_at(p + dy + 1);
+            const int left = (int)per_frame - p;  // blocks the dword covers
             if (left < 32) cand &= (1u << left) - 1u;
         }
-        while (__ballot(cand != 0)) {
-            const bool have = cand != 0;
-            const int b = have ? __builtin_ctz(cand) : 0;
-            cand &= cand - 1u;  // (0 stays 0)
-            const int tid = band * g.WW + 32 * seg + b;
+        if (__ballot(cand != 0) == 0) continue;
+        const unsigned pc = (unsigned)__popc(cand);
+        unsigned incl = pc;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const unsigned total = __shfl(incl, 63);
+        unsigned pos = incl - pc;
+        while (cand) {
+            q[pos++] = (unsigned short)((lane << 5) | __builtin_ctz(cand));
+            cand &= cand - 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (one wave: its LDS operations execute in order)
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned e0 = 0; e0 < total; e0 += 64) {
+            const unsigned e = e0 + (unsigned)lane;
+            const bool have = e < total;
+            const unsigned v = have ? q[e] : 0u;
+            const int tid = 32 * (int)(d0 + (v >> 5)) + (int)(v & 31u);
             append(have && morph_block_keep(blockcnt, g, i, tid), tid);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1734,7 +1778,7 @@ __global__ void __launch_bounds__(256) k_sparse_clear(u64* __restrict__ dst_bits
 // stages accumulate into, the block bit counts the slot's previous pass touched, the noise sums, and the dst words that pass left behind
 // (listed in nzlist; nzcount itself is reset by k_noise_finalize, which runs next on the same stream).
 __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ counters, unsigned n_counters,
-                                                      unsigned* __restrict__ blockcnt, unsigned per_frame, unsigned WW, unsigned Kcap,
+                                                      unsigned* __restrict__ blockcnt, unsigned per_frame, unsigned Kcap,
                                                       unsigned* __restrict__ sums32, unsigned n_sums32, u64* __restrict__ dst_bits,
                                                       const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount) {
     RAISE_WAVE_PRIORITY();
@@ -1750,14 +1794,13 @@ __global__ void __launch_bounds__(256) k_pass_prepare(unsigned* __restrict__ cou
     // the block bit counts the slot's previous pass touched (the set bits of note_block's bitmap), and the bitmap itself
     if (blockcnt != nullptr) {
         unsigned* bitmap = blockcnt + (size_t)Kcap * per_frame;
-        const unsigned S = (WW + 31) >> 5, stride = (per_frame / WW) * S;
+        const unsigned stride = block_bitmap_stride(per_frame);
         const size_t total = (size_t)Kcap * stride;
         for (size_t e = tid; e < total; e += nth) {
             unsigned v = bitmap[e];
             if (v == 0) continue;
             const unsigned i = (unsigned)(e / stride), d = (unsigned)(e - (size_t)i * stride);
-            const unsigned band = d / S, seg = d - band * S;
-            unsigned* f = blockcnt + (size_t)i * per_frame + band * WW + 32 * seg;
+            unsigned* f = blockcnt + (size_t)i * per_frame + 32u * d;
             do {
                 f[__builtin_ctz(v)] = 0;
                 v &= v - 1u;
@@ -2117,6 +2160,7 @@ struct HoughParams {
     int* tier_count;       // [HOUGH_TIERS]
     int K;                 // frames in the pass
     int lds_small, lds_large;  // dynamic LDS bytes of the two three-wave launches (the classifier's fit test)
+    int lds_tiny;          // ... and of the launch for frames that need even less (tier 4; 0: no such launch)
     int all_one_wave;      // MDH_HOUGH_ONE_WAVE / MDH_HOUGH_SERIAL: every frame goes to the one-wave kernel
     int lds_bytes;         // dynamic LDS bytes of this launch
     const unsigned short* perm;  // visiting-order tables: the table of an N-point frame starts at N(N-1)/2
@@ -2662,6 +2706,8 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
 // Frame routing.  One wave per frame: the adaptive maxLineGap (Detector.py:342-344), and which launch replays the frame:
 //   tier 0 / 1  three-wave kernel, everything in LDS (point list, working mask over the bounding box, all 180 rho windows),
 //               small / large dynamic LDS (2-3 frames per CU / one frame per CU)
+//   tier 4      the same kernel with 40 KB (four frames per CU): short streaks -- every frame at 960x540, where the Hough stage is
+//               the largest item next to the window kernel (round 4: +3-5 % at the pipeline's pace there, nothing at 1080p)
 //   tier 2      three-wave kernel, hybrid: the rho windows that fit in LDS + a pooled global accumulator for the rest
 //   tier 3      one-wave kernel with a global point list (more than HOUGH_MAX_LIST points)
 //   none        fewer points than the vote threshold: no accumulator cell can reach it, so there is no segment
@@ -2708,6 +2754,7 @@ __device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
     if (N > HOUGH_MAX_LIST || P.all_one_wave) return 3;
     if (P.no_lds_acc) return 2;
     const int need = hough3_lds_need(N, hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1), cells, mask_dw);
+    if (P.lds_tiny > 0 && need <= P.lds_tiny) return 4;
     return need <= P.lds_small ? 0 : (need <= P.lds_large ? 1 : 2);
 }
 

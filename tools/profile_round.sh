@@ -9,7 +9,7 @@ WL=${2:-C2}
 OUT=gpurun_out/profile_${TAG}_$WL
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --steps 8 --warmup 3 --cpu-seconds 0 --parity-frames 0 --standalone-passes 0 --no-pmc ${EXTRA:-}"
+ARGS="bench.py --workload $WL --steps 24 --warmup 6 --passes-per-step 1 --no-secondary --cpu-seconds 0 --parity-frames 0 --standalone-passes 0 --no-pmc ${EXTRA:-}"
 # (C5 flips to the dense output format after its first collected pass: pinned for the profile so that every launch is the same kernel)
 if [ "$WL" = "C5" ]; then export MDH_DENSE=1; fi
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r --output-format csv -- python $ARGS > "$OUT/stats.log" 2>&1
