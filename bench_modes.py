@@ -200,7 +200,8 @@ def run_timeshard(a, D, wl, mask, cfg):
     # when window r's last pass has been, BEFORE the host collects r's tail -- the next window's pipeline fills under this one's
     # drain (each window alone never reaches the pipeline's steady state: fill + drain are 3-4 ms of a 16-pass window's 10)
     draining = None
-    gens = [s.finish_blocks_steps(table) for s in shards]  # (every context positioned before the first pass is queued)
+    from metdetpy_amd.timeshard import chains_at
+    gens = [s.finish_blocks_steps(table, chain=ch) for s, ch in zip(shards, chains_at(shards, table))]  # (every context positioned before the first pass is queued)
     for s, gen in zip(shards, gens):
         if gen is None:
             part.extend(s.finish(table))

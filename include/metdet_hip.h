@@ -317,7 +317,9 @@ int mdh_band_skip(mdh_ctx* ctx);
 
 /* Reposition a context in its stream: the next frame is number t0 + 1 (SlidingWindow.timer == t0), the window and the
  * ring of binaries are empty, the noise EMA has been updated ema_updates times and stands at snr (EMA.cur_value), with
- * sigma / thr_float / thr the values in force after frame t0.  No pass may be in flight. */
+ * sigma / thr_float / thr the values in force after frame t0.  No pass may be in flight.  The 2(n-1) frames that follow are
+ * warm-up (their results are meaningless: the window, then the ring of binaries, is still filling); for t0 > 0 the batched M3
+ * passes leave the binaries of the first n-1 of them empty instead of thresholding windows that hold zero frames. */
 int mdh_seek(mdh_ctx* ctx, int64_t t0, int64_t ema_updates, double snr, double sigma, double thr_float, int thr);
 
 /* Time windows on a MDH_ROLE_FULL context (the pipelined mdh_submit_batch / mdh_collect_batch path, thresholds computed by the

@@ -246,6 +246,7 @@ struct mdh_ctx {
     std::vector<std::pair<int64_t, std::pair<int64_t, int64_t>>> injected;  // (frame number, (S1, S2)), any order
     long long* h_inject = nullptr;         // pinned staging of the injected sums of the pass being queued
     int64_t mute_until = 0;
+    int64_t seek_at = -1;  // mdh_seek to a position > 0: frames up to seek_at + n - 1 have windows that reach in front of it (k_noise_finalize's mute_pix)
     unsigned* d_read_count = nullptr;      // waves of the direct window kernel that have finished (zero between launches)
     unsigned* h_read_flag = nullptr;       // pinned word: read_seq once the caller's frame has been read
     unsigned read_seq = 0;
@@ -1208,7 +1209,8 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
 static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
     span_begin(c, KK_NOISE_FINAL, c->nstream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
-                       sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount);
+                       sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount,
+                       (c->seek_at >= 0 && c->cfg.detector == MDH_DET_M3) ? (int)std::max<int64_t>(0, std::min<int64_t>(K, c->seek_at + c->n - 1 - sl.t_base)) : 0);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     EV_REC(c, sl.ev_noise, c->nstream);
@@ -1238,7 +1240,7 @@ static int run_noise_direct(mdh_ctx* c, Slot& sl) {
     span_end(c, c->nstream);
     span_begin(c, KK_NOISE_FINAL, c->nstream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), 0, c->nstream, c->d_jobs, 1, c->d_sums, c->d_state, c->d_jobres, sl.d_fscal, c->d_thr, 1,
-                       (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, (unsigned*)nullptr);
+                       (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, (unsigned*)nullptr, 0);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     return MDH_OK;
@@ -2341,6 +2343,7 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
     c->t = t0;
     c->injected.clear();
     c->mute_until = 0;
+    c->seek_at = t0 > 0 ? t0 : -1;
     c->hist.assign(c->n - 1, c->d_zero);  // the window restarts empty: the next 2(n-1) frames are warm-up
     c->ema_t = ema_updates;
     c->ema_warm = c->n;  // the schedule (utils.py:360-368) is a function of the update count alone; it re-derives "ramp over"

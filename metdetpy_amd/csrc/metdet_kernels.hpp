@@ -177,13 +177,15 @@ struct FrameScalars {
 // not depend on the chain, so they are issued eight steps ahead); (C) all threads: thresholds and the job results.  The values
 // are those of the sequential loop bit for bit (same operations on the same operands; timeshard.NoiseChain replays them on the host).
 #define NF_CHUNK 1024
-#define NF_THREADS 1024
+#ifndef NF_THREADS
+#define NF_THREADS 1024  // (A/B builds: -DNF_THREADS=256)
+#endif
 #define NF_FRAMES 4096  // due frames whose frame numbers are searched in LDS when the per-frame tables are filled
 __global__ void __launch_bounds__(NF_THREADS) k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
                                                         const long long* __restrict__ sums, ScalarState* __restrict__ st,
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
                                                         int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
-                                                        double coef_a, double coef_b, unsigned* __restrict__ nzcount) {
+                                                        double coef_a, double coef_b, unsigned* __restrict__ nzcount, int mute_pix) {
     RAISE_WAVE_PRIORITY();
     // the slot's list counters ([0] lit words, [1] morphology blocks): k_pass_prepare, earlier on this stream, was their last reader
     if (nzcount && threadIdx.x < 4) nzcount[threadIdx.x] = 0;  // ([2..3]: the window kernel's count of words with set bits)
@@ -271,7 +273,11 @@ __global__ void __launch_bounds__(NF_THREADS) k_noise_finalize(const NoiseJob* _
             if ((in_lds ? s_frame[mid] : jobs[mid].frame) <= i) lo = mid + 1; else hi = mid;
         }
         const ScalarState s = jobres[lo];
-        thr_tab[i] = s.thr;
+        // mute_pix: the first frames of the pass whose windows reach in front of a seek point (mdh_seek emptied the window: they
+        // would see n - 1 zero frames, i.e. a difference image that is lit almost everywhere -- megabytes of binaries for the
+        // morphology and the dynamic mask to chew through, 5 ms per time window, for results that are dropped as warm-up): the
+        // window kernel gets a threshold no pixel can pass (T >= 256), the reported scalars stay the chain's
+        thr_tab[i] = i < mute_pix ? 256 : s.thr;
         out[i].thr_f = s.thr_f;
         out[i].snr = s.ema_v;
         out[i].sigma = s.sigma;

@@ -199,20 +199,22 @@ class TimeShard:
             pass
         return self._res
 
-    def finish_blocks_steps(self, table: dict):
+    def finish_blocks_steps(self, table: dict, chain=None):
         """finish_blocks() as a generator, for a host that drives SEVERAL windows on one device (bench.py --mode timeshard with one
         process): yields "primed" once the window's pipeline is full (or all its passes are queued), "submitted" when its last
         pass is queued -- the moment to start the next window's passes, so that its fill runs under this window's drain -- and
         ends after the last collect; the records are then in `.blocks`.  The context is positioned (mdh_seek: a device-wide
         synchronisation) HERE, not at the generator's first step: a host that overlaps windows creates all its generators first.
-        None when the engine is not the HIP one."""
+        chain: the scalar chain already replayed up to this window's warm-up start (chains_at: one replay for all the windows of a
+        process instead of one per window).  None when the engine is not the HIP one."""
         if not self.pipelined or self.end <= self.start:
             return None
-        chain = self._chain()
-        for t in sorted(table):
-            if t > self.warm:
-                break
-            chain.update(*table[t])
+        if chain is None:
+            chain = self._chain()
+            for t in sorted(table):
+                if t > self.warm:
+                    break
+                chain.update(*table[t])
         self._finish_prepare(table, chain)
         return self._finish_steps(True)
 
@@ -225,8 +227,8 @@ class TimeShard:
         ctx = self.det._ctx
         ctx.seek(self.warm, **chain.state())
         if self.warm > 0:
-            for t in sorted(table):
-                if self.warm < t < self.warm + n:  # fewer than n frames since the seek: the window is still filling
+            for t in range(self.warm + 1, self.warm + n):  # fewer than n frames since the seek: the window is still filling
+                if t in table:
                     ctx.inject_sums(t, table[t][1], table[t][2])
         ctx.mute_hough_until(self.start)
 
@@ -282,6 +284,23 @@ class TimeShard:
         if self.det is not None:
             self.det.close()
             self.det = None
+
+
+def chains_at(shards, table: dict):
+    """The scalar chain replayed ONCE over the gathered table, a copy taken where each shard's warm-up starts: [NoiseChain] in the
+    order of `shards` (for a process that drives several windows: every TimeShard replaying the chain from frame 0 by itself is
+    O(windows x due frames) of interpreter time inside the timed region)."""
+    import copy
+    order = sorted(range(len(shards)), key=lambda k: shards[k].warm)
+    keys = sorted(table)
+    chain = shards[0]._chain()
+    out, j = [None] * len(shards), 0
+    for k in order:
+        while j < len(keys) and keys[j] <= shards[k].warm:
+            chain.update(*table[keys[j]])
+            j += 1
+        out[k] = copy.copy(chain)
+    return out
 
 
 def unpack_block(block, num_cls):
