@@ -1326,15 +1326,19 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         if (all_dense) {
             hipLaunchKernelGGL(k_morph_close_dense, dim3(8192), dim3(64), 0, post, sl.d_bbits, (const unsigned*)nullptr, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
         } else {
-        hipLaunchKernelGGL(k_morph_select_touched, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g);
+        // waves (select) / one-wave workgroups (close) per frame: by the size of a frame's bitmap (MDH_MORPH_WPF: 1, 2, 4; A/B)
+        static const int wpf_env = getenv("MDH_MORPH_WPF") ? atoi(getenv("MDH_MORPH_WPF")) : 0;
+        const size_t bm_dwords = (nb * c->WW + 31) / 32;
+        const int wpf = (wpf_env == 1 || wpf_env == 2 || wpf_env == 4) ? wpf_env : (bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1));
+        hipLaunchKernelGGL(k_morph_select_touched, dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
         // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
         // waves leave after one load when the pass has none (MDH_MORPH_DENSE=0: everything through the list, A/B and parity testing)
         static const bool dense = !(getenv("MDH_MORPH_DENSE") && atoi(getenv("MDH_MORPH_DENSE")) == 0);
         // a block's fourteen rows on fourteen lanes, one wave per frame (MDH_MORPH_BT=0: one lane per listed block, A/B and parity)
         static const bool batched_t = !(getenv("MDH_MORPH_BT") && atoi(getenv("MDH_MORPH_BT")) == 0);
         if (batched_t)
-            hipLaunchKernelGGL(k_morph_close_t, dim3((unsigned)std::min(K, 16384)), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
-                               sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr);
+            hipLaunchKernelGGL(k_morph_close_t, dim3((unsigned)std::min(K * wpf, 16384)), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
+                               sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr, wpf);
         else
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
                            sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr);

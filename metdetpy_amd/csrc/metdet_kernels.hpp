@@ -1196,12 +1196,17 @@ __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ bl
 // Round 4: the candidates are the 3x3 neighbourhoods of the TOUCHED blocks (note_block's bitmap), not every block of the frame.
 // One wave per frame; a lane takes a dword of the bitmap (32 blocks of one band), dilates it by one block in both directions from
 // the dwords around it, and the wave evaluates the candidate blocks one per lane and round exactly as morph_block_keep does.
+// wpf (1, 2 or 4): waves per frame -- the 64-dword rounds of a frame's bitmap are dealt out to them (960x540: 32 dwords, one round,
+// one wave; 4K: 507 dwords, eight rounds, and a long streak's candidates on top: one wave per frame made the launch as long as
+// its longest frame, 0.19 ms per 1000-frame pass).  The waves of a frame share nothing but the frame's list counter.
 __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
-                                                              unsigned* __restrict__ workcount, PassGeom g) {
+                                                              unsigned* __restrict__ workcount, PassGeom g, int wpf) {
     RAISE_WAVE_PRIORITY();
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     const unsigned per_frame = (unsigned)(nb * g.WW);
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wv = (int)(threadIdx.x >> 6);
+    const int i = blockIdx.x * (4 / wpf) + wv / wpf;
+    const unsigned sub = (unsigned)(wv % wpf);
     if (i >= g.K) return;
     const int lane = threadIdx.x & 63;
     const unsigned stride = block_bitmap_stride(per_frame);
@@ -1221,7 +1226,7 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
     if (9u * cnt >= per_frame) {
         // a frame with most of its blocks touched (a binary with noise in it, before the pass format flips to dense): every block
         // tests itself, as round 3's selection did for all frames
-        for (unsigned b0 = 0; b0 < per_frame; b0 += 64) {
+        for (unsigned b0 = 64 * sub; b0 < per_frame; b0 += 64 * (unsigned)wpf) {
             const int tid = (int)b0 + lane;
             append(morph_block_keep(blockcnt, g, i, tid), tid);
         }
@@ -1242,7 +1247,7 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
     // morph_block_keep (the exact test, on the counts) turns down like any other.
     __shared__ unsigned short s_q[4][2048];
     unsigned short* q = s_q[threadIdx.x >> 6];
-    for (unsigned d0 = 0; d0 < stride; d0 += 64) {
+    for (unsigned d0 = 64 * sub; d0 < stride; d0 += 64 * (unsigned)wpf) {
         const unsigned d = d0 + (unsigned)lane;
         unsigned cand = 0;
         if (d < stride) {
@@ -1651,25 +1656,27 @@ __global__ void __launch_bounds__(64) k_morph_close_frame_t(const ActWord* __res
 __global__ void __launch_bounds__(64) k_morph_close_t(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                       const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
                                                       unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g,
-                                                      unsigned* __restrict__ dense) {
+                                                      unsigned* __restrict__ dense, int wpf) {
     RAISE_WAVE_PRIORITY();
     __shared__ unsigned q[MORPH_NZQ];
     unsigned qn = 0;
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15;
     const unsigned per_frame = (unsigned)(((g.H + MORPH_RB - 1) / MORPH_RB) * g.WW);
     const size_t words = (size_t)g.H * g.WW;
-    for (unsigned i = blockIdx.x; i < (unsigned)g.K; i += gridDim.x) {
+    // wpf workgroups (of one wave) per frame share the frame's list, four entries per workgroup and step
+    for (unsigned u = blockIdx.x; u < (unsigned)g.K * (unsigned)wpf; u += gridDim.x) {
+        const unsigned i = u / (unsigned)wpf, sub = u - i * (unsigned)wpf;
         const unsigned cnt = workcount[(size_t)i * WORKCNT_STRIDE];
         if (cnt == 0) continue;
         if (dense != nullptr && 2u * cnt >= per_frame) {
-            if (lane == 0) dense[1 + atomicAdd(&dense[0], 1u)] = i;
+            if (lane == 0 && sub == 0) dense[1 + atomicAdd(&dense[0], 1u)] = i;
             continue;
         }
         const unsigned* seg = worklist + (size_t)i * per_frame;
         const long long t = g.t_base + 1 + (long long)i;
         const ActWord* src = bbits + (size_t)i * words;
         ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * words;
-        for (unsigned e0 = 0; e0 < cnt; e0 += 4) {
+        for (unsigned e0 = 4 * sub; e0 < cnt; e0 += 4 * (unsigned)wpf) {
             const unsigned e = e0 + (unsigned)grp;
             const bool have = e < cnt;
             const int blk = have ? (int)(seg[e] - i * per_frame) : 0;

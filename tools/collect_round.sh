@@ -2,44 +2,49 @@
 # Everything profiles/ holds for a round, in one go on the GPU box:  bash tools/collect_round.sh <tag>   (outputs under gpurun_out/collect_<tag>/)
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/collect_$TAG; mkdir -p $O
-S="--cpu-seconds 6"
-python bench.py > $O/${TAG}_bench_default.json 2> $O/err_default
+S="--cpu-seconds 6 --no-secondary"
+NS="--no-secondary --cpu-seconds 0"
+# the headline line as the driver runs it (secondary block included: the other workloads and the per-frame protocol as subprocesses)
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/err_default
 python bench.py --workload C3 $S > $O/${TAG}_bench_C3_4k_n16_mask.json 2> $O/err_C3
 python bench.py --workload C3 --batch 500 $S > $O/${TAG}_bench_C3_batch500.json 2>> $O/err_C3
 python bench.py --workload C1s $S > $O/${TAG}_bench_C1s_960x540.json 2> $O/err_C1s
 python bench.py --workload C5 --unique 50 $S > $O/${TAG}_bench_C5_8k_single_gpu.json 2> $O/err_C5
-python bench.py --workload C5 --unique 50 --batch 125 --cpu-seconds 0 > $O/${TAG}_bench_C5_batch125.json 2>> $O/err_C5
-python bench.py --batch 2000 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch2000.json 2> $O/err_b2000
-python bench.py --batch 8000 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch8000.json 2> $O/err_b8000
-python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/${TAG}_bench_C2_driver_command.json 2> $O/err_drv
-python bench.py --batch 1000 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch1000.json 2> $O/err_b1000
-python bench.py --workload C3 --batch 2000 --cpu-seconds 0 > $O/${TAG}_bench_C3_batch2000.json 2>> $O/err_C3
-python bench.py --batch 250 --cpu-seconds 0 > $O/${TAG}_bench_C2_batch250.json 2> $O/err_b250
-python bench.py --host-input --cpu-seconds 0 --steps 200 > $O/${TAG}_bench_C2_host_input.json 2> $O/err_host
+python bench.py --workload C5 --unique 50 --batch 125 $NS > $O/${TAG}_bench_C5_batch125.json 2>> $O/err_C5
+python bench.py --batch 2000 $NS > $O/${TAG}_bench_C2_batch2000.json 2> $O/err_b2000
+python bench.py --batch 8000 $NS > $O/${TAG}_bench_C2_batch8000.json 2> $O/err_b8000
+python bench.py --batch 1000 $NS > $O/${TAG}_bench_C2_batch1000.json 2> $O/err_b1000
+python bench.py --workload C3 --batch 2000 $NS > $O/${TAG}_bench_C3_batch2000.json 2>> $O/err_C3
+python bench.py --batch 250 $NS > $O/${TAG}_bench_C2_batch250.json 2> $O/err_b250
+python bench.py --host-input $NS --passes-per-step 1 --steps 200 > $O/${TAG}_bench_C2_host_input.json 2> $O/err_host
 python bench.py --protocol per-frame --cpu-seconds 0 > $O/${TAG}_bench_per_frame_protocol.json 2> $O/err_pf
+python bench.py --protocol per-frame --frames recycled --cpu-seconds 0 > $O/${TAG}_bench_per_frame_recycled_ring.json 2>> $O/err_pf
+python bench.py --protocol per-frame --frames pageable --steps 6000 --cpu-seconds 0 > $O/${TAG}_bench_per_frame_pageable.json 2>> $O/err_pf
 python tools/bench_per_frame.py > $O/${TAG}_per_frame_protocol.json 2>> $O/err_pf
 # kernel trace of the per-frame loop (the window kernel launched ahead of its frame shows up as k_stack_threshold_mail)
 (export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $O/pf_stats -o r --output-format csv -- python bench.py --protocol per-frame --steps 3000 --cpu-seconds 0 --parity-frames 0 > $O/pf_stats.log 2>&1; cp $(find $O/pf_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_rocprofv3_kernel_stats_per_frame.csv 2>/dev/null)
-timeout 600 python bench.py --mode bands --workload C5 --unique 50 --batch 500 --cpu-seconds 0 > $O/${TAG}_bench_mode_bands_C5_8bands_one_gpu.json 2> $O/err_bands
+timeout 600 python bench.py --mode bands --workload C5 --unique 50 --batch 500 --steps 16 --warmup 3 --cpu-seconds 0 > $O/${TAG}_bench_mode_bands_C5_8bands_one_gpu.json 2> $O/err_bands
 python bench.py --mode timeshard --cpu-seconds 0 > $O/${TAG}_bench_mode_timeshard_C2_8windows_one_gpu.json 2> $O/err_ts
 python bench.py --mode timeshard --host-input --steps 16 --cpu-seconds 0 > $O/${TAG}_bench_mode_timeshard_C2_host_input.json 2>> $O/err_ts
-python bench.py --detector classic --cpu-seconds 0 > $O/${TAG}_bench_classic_detector.json 2> $O/err_classic
-python bench.py --hough-mode accumulator --cpu-seconds 0 > $O/${TAG}_bench_C2_hough_accumulator.json 2> $O/err_acc
-python bench.py --workload C3 --hough-mode accumulator --cpu-seconds 0 > $O/${TAG}_bench_C3_hough_accumulator.json 2>> $O/err_acc
-python bench.py --workload C5 --unique 50 --batch 125 --hough-mode accumulator --cpu-seconds 0 > $O/${TAG}_bench_C5_hough_accumulator.json 2>> $O/err_acc
+python bench.py --detector classic $NS > $O/${TAG}_bench_classic_detector.json 2> $O/err_classic
+python bench.py --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C2_hough_accumulator.json 2> $O/err_acc
+python bench.py --workload C3 --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C3_hough_accumulator.json 2>> $O/err_acc
+python bench.py --workload C5 --unique 50 --batch 125 --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C5_hough_accumulator.json 2>> $O/err_acc
 python bench.py --workload C1e --cpu-seconds 0 > $O/${TAG}_bench_C1e_end_to_end.json 2> $O/err_c1e
-MDH_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 300 --cpu-seconds 0 > $O/${TAG}_bench_2ranks_gloo_one_gpu.json 2> $O/err_2r
+MDH_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 1 --cpu-seconds 0 2> $O/err_2r | grep '^{' > $O/${TAG}_bench_2ranks_gloo_one_gpu.json
 for wl in C2 C3 C5; do WL=$wl python tools/hough_frame_times.py > $O/${TAG}_hough_frame_times_$wl.txt 2>&1; done
 ./tools/lds_atomic_rate > $O/${TAG}_lds_atomic_rate.txt 2>&1
 python tools/bench_pre_batch.py > $O/${TAG}_preprocess_batch.json 2> $O/err_pre
 python tools/bench_collector.py > $O/${TAG}_collector.json 2> $O/err_col
 bash tools/profile_round.sh $TAG C2 > $O/profile_C2.log 2>&1
 bash tools/profile_round.sh $TAG C3 > $O/profile_C3.log 2>&1
+bash tools/profile_round.sh $TAG C1s > $O/profile_C1s.log 2>&1
 EXTRA="--unique 50" bash tools/profile_round.sh $TAG C5 > $O/profile_C5.log 2>&1
-MDH_DENSE=0 python bench.py --workload C5 --unique 50 --cpu-seconds 0 --no-pmc > $O/${TAG}_bench_C5_sparse_format.json 2>> $O/err_C5
+MDH_DENSE=0 python bench.py --workload C5 --unique 50 $NS --no-pmc --steps 8 > $O/${TAG}_bench_C5_sparse_format.json 2>> $O/err_C5
 cp gpurun_out/profile_${TAG}_C2/${TAG}_rocprofv3_kernel_stats_C2.csv gpurun_out/profile_${TAG}_C2/${TAG}_rocprofv3_kernel_stats_C2_depth1.csv gpurun_out/profile_${TAG}_C2/pmc_traffic_C2.json $O/ 2>/dev/null
 cp gpurun_out/profile_${TAG}_C5/${TAG}_rocprofv3_kernel_stats_C5.csv gpurun_out/profile_${TAG}_C5/${TAG}_rocprofv3_kernel_stats_C5_depth1.csv gpurun_out/profile_${TAG}_C5/pmc_traffic_C5.json $O/ 2>/dev/null
+cp gpurun_out/profile_${TAG}_C1s/${TAG}_rocprofv3_kernel_stats_C1s.csv gpurun_out/profile_${TAG}_C1s/${TAG}_rocprofv3_kernel_stats_C1s_depth1.csv gpurun_out/profile_${TAG}_C1s/pmc_traffic_C1s.json $O/ 2>/dev/null
 cp gpurun_out/profile_${TAG}_C3/${TAG}_rocprofv3_kernel_stats_C3.csv gpurun_out/profile_${TAG}_C3/${TAG}_rocprofv3_kernel_stats_C3_depth1.csv gpurun_out/profile_${TAG}_C3/pmc_traffic_C3.json $O/ 2>/dev/null
 ls -la $O | head -60
