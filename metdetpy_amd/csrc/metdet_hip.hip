@@ -1175,8 +1175,9 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
         } else if (aligned4) {
             const int xa = r[1] & ~3;
             const int nx4 = (r[1] + rw - xa + 3) >> 2;
-            static const int nblk = getenv("MDH_NOISE_BLOCKS") ? std::max(1, atoi(getenv("MDH_NOISE_BLOCKS"))) : 48;  // workgroups per due frame at most
-            hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, nblk), nj), dim3(256), 0, c->nstream, c->d_ptrtab,
+            // (at most 48 workgroups per due frame; 8 or 16 at 960x540 -- 1000 due frames per pass -- shorten the launch alone, 0.235 -> 0.176 ms,
+            // and change nothing at the pipeline's pace)
+            hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->nstream, c->d_ptrtab,
                                c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
         } else {
             hipLaunchKernelGGL(k_noise_sums_bytes, dim3((rh * rw + 255) / 256, nj), dim3(256), 0, c->nstream, c->d_ptrtab,
