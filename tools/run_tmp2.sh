@@ -1,9 +1,3 @@
-O=gpurun_out/r04_21; mkdir -p $O
-bash tools/run_tmp.sh r04_21 "def=metdetpy_amd/libmetdet_hip.so u2=metdetpy_amd/libmetdet_hip_u2.so" "C3"
-C="--no-pmc --cpu-seconds 0 --parity-frames 0 --standalone-passes 8 --no-secondary --steps 6 --warmup 1"
-for rep in 1 2; do for v in "nb48:" "nb16:MDH_NOISE_BLOCKS=16" "nb8:MDH_NOISE_BLOCKS=8"; do
-   name=${v%%:*}; e=${v#*:}
-   env $e python bench.py --workload C1s $C > $O/x_C1s_${name}_$rep.json 2>>$O/err
-   python -c "
-import json;d=json.loads(open('$O/x_C1s_${name}_$rep.json').read().strip().splitlines()[-1]);print('C1s $name $rep', int(d['value']), round(d['ms_per_step']/d['config']['passes_per_step'],3), round(d['kernels_ms_standalone']['noise_sums'],3))"
-done; done
+O=gpurun_out/r04_22; mkdir -p $O
+MDH_LIB=$PWD/metdetpy_amd/libmetdet_hip_ps256.so timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "wide or format or m3" > $O/pytest_ps256.log 2>&1; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/pytest_ps256.log | tail -3
+bash tools/run_tmp.sh r04_22 "def=metdetpy_amd/libmetdet_hip.so ps16=metdetpy_amd/libmetdet_hip_ps16.so ps64=metdetpy_amd/libmetdet_hip_ps64.so ps256=metdetpy_amd/libmetdet_hip_ps256.so ps1024=metdetpy_amd/libmetdet_hip_ps1024.so" "C2"
