@@ -1734,10 +1734,22 @@ __device__ __forceinline__ void dy_sparse_items(const ActWord* __restrict__ act_
             u64 all = ~0ull, first = 0;
             if (live && row_in) {
                 if (word_in) {
-                    for (int j = 0; j < len; ++j) {
-                        const u64 v = act_word(act_ring + (size_t)((t - 1 - j) % g.R) * words, yy * g.WW + ww, (u64)(t - j));
-                        if (j == 0) first = v;
-                        all &= v;
+                    // AND over the last `len` binaries, four at a time, until nothing is left of it: a moving streak's word is lit in
+                    // two or three consecutive frames, so most lanes are done after the first four loads (round 3 issued all len
+                    // of them -- 144 tagged 16-byte loads per listed word at n = 16 -- each behind a 64-bit modulo for its ring slot)
+                    const int slot0 = (int)((t - 1) % g.R);  // ring slot of frame t; frame t - j sits j slots back (len <= n <= R)
+                    const int cell = yy * g.WW + ww;
+                    for (int j0 = 0; j0 < len && all != 0; j0 += 4) {
+                        u64 v[4];
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) {
+                            const int j = j0 + k2;
+                            int sl = slot0 - j;
+                            if (sl < 0) sl += g.R;
+                            v[k2] = j < len ? act_word(act_ring + (size_t)sl * words, cell, (u64)(t - j)) : ~0ull;
+                        }
+                        if (j0 == 0) first = v[0];
+                        all &= v[0] & v[1] & v[2] & v[3];
                     }
                 } else {
                     all = 0;
