@@ -180,7 +180,7 @@ def run_timeshard(a, D, wl, mask, cfg):
         # one process, several windows on this device: the first sweep is a chain of short blocking calls per window (launch, wait,
         # 16 bytes per due frame back) -- the windows' chains run side by side from a few host threads (the library releases the GIL)
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(min(4, len(shards))) as ex:
+        with ThreadPoolExecutor(min(4, len(shards))) as ex:  # (2 or 8 threads: the same 14-17 ms)
             for got in ex.map(lambda s_: s_.scan(), shards):
                 mine.update(got)
     else:

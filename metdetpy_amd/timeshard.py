@@ -43,6 +43,17 @@ def due_frames(t: int, n: int, interval: int) -> int:
     return 0
 
 
+def due_in(lo: int, hi: int, n: int, interval: int):
+    """[(t, k_used)] for the due frames t in (lo, hi], ascending -- due_frames() for a whole pass without a Python step per frame
+    (the first sweep of a time window walks a thousand frames per call, and a process that drives several windows does so under
+    one interpreter lock)."""
+    out = [(t, t) for t in range(max(lo + 1, 2), min(hi, n) + 1)]
+    period = interval * n
+    first = (max(lo, n) // period + 1) * period
+    out.extend((t, n) for t in range(first, hi + 1, period))
+    return out
+
+
 class NoiseChain:
     """EMA of sigma with the warm-up schedule of utils.py:334-368 and the threshold rule of Detector.py:225-229, in the
     operation order of the library's k_noise_finalize / noise_prepare (IEEE doubles, no fused multiply-add on either side)."""
@@ -131,15 +142,12 @@ class TimeShard:
             else:
                 sums = self.engine.noise(self.read(lo, hi))
             self.engine.skip()
-            j = 0
-            for t in range(lo + 1, hi + 1):
-                k = due_frames(t, n, itv)
-                if k:
-                    if t > self.start:  # owned; its k frames are all behind the warm-up start
-                        assert t - k >= self.warm
-                        out[t] = (k, int(sums[2 * j]), int(sums[2 * j + 1]))
-                    j += 1
-            assert 2 * j == len(sums)
+            due = due_in(lo, hi, n, itv)
+            assert 2 * len(due) == len(sums)
+            for j, (t, k) in enumerate(due):
+                if t > self.start:  # owned; its k frames are all behind the warm-up start
+                    assert t - k >= self.warm
+                    out[t] = (k, int(sums[2 * j]), int(sums[2 * j + 1]))
         return out
 
     def finish(self, table: dict):
@@ -289,17 +297,46 @@ class TimeShard:
 def chains_at(shards, table: dict):
     """The scalar chain replayed ONCE over the gathered table, a copy taken where each shard's warm-up starts: [NoiseChain] in the
     order of `shards` (for a process that drives several windows: every TimeShard replaying the chain from frame 0 by itself is
-    O(windows x due frames) of interpreter time inside the timed region)."""
+    O(windows x due frames) of interpreter time inside the timed region).  The per-update arithmetic that does not depend on the
+    chain -- sigma from the sums, the momentum schedule -- is done on arrays (IEEE doubles, the same operations in the same order
+    as NoiseChain.update: element for element the same values); only the recurrence itself is a loop."""
     import copy
-    order = sorted(range(len(shards)), key=lambda k: shards[k].warm)
+    proto = shards[0]._chain()
     keys = sorted(table)
-    chain = shards[0]._chain()
-    out, j = [None] * len(shards), 0
-    for k in order:
-        while j < len(keys) and keys[j] <= shards[k].warm:
-            chain.update(*table[keys[j]])
+    if not keys:
+        return [copy.copy(proto) for _ in shards]
+    k_used = np.array([table[t][0] for t in keys], np.float64)
+    s1 = np.array([table[t][1] for t in keys], np.int64).astype(np.float64)
+    s2 = np.array([table[t][2] for t in keys], np.int64).astype(np.float64)
+    cnt = k_used * proto.roi_px
+    mu = s1 / cnt
+    var = s2 / cnt - mu * mu
+    var[var < 0] = 0.0
+    sig = np.sqrt(var)
+    upd = np.arange(len(keys), dtype=np.float64)
+    ramp = upd * (1 - proto.m0) * proto.n
+    u = 1 - ramp
+    m = np.where(ramp < 1, proto.m0 * (1 - u * u), proto.m0)
+    om = 1 - m
+    ml, oml, sl = m.tolist(), om.tolist(), sig.tolist()
+    # where each shard's chain stops: the number of table entries with t <= warm
+    stops = np.searchsorted(np.asarray(keys), [sh.warm for sh in shards], side="right").tolist()
+    order = sorted(range(len(shards)), key=lambda q: stops[q])
+    out = [None] * len(shards)
+    snr, j, last_nz = 0.0, 0, None  # last_nz: snr after the last update that left it non-zero (what the threshold follows)
+    for q in order:
+        while j < stops[q]:
+            snr = ml[j] * snr + oml[j] * sl[j]
+            if snr != 0:
+                last_nz = snr
             j += 1
-        out[k] = copy.copy(chain)
+        ch = copy.copy(proto)
+        ch.updates, ch.snr = j, snr
+        ch.sigma = sl[j - 1] if j else 0.0
+        if ch.adaptive and last_nz is not None:
+            ch.thr_f = ch.a * (last_nz * last_nz) + ch.b
+            ch.thr = int(round(ch.thr_f))  # half to even
+        out[q] = ch
     return out
 
 

@@ -279,3 +279,36 @@ def test_band_skip_between_real_passes():
     assert compared >= 6 and lit > 0
     full.close()
     part.close()
+
+
+def test_chains_at_equals_the_sequential_replay():
+    """timeshard.chains_at (one replay of the scalar chain for all windows of a process, sigma and momenta on arrays) against
+    NoiseChain.update entry by entry: identical states -- doubles compared exactly -- wherever a window's warm-up starts; and due_in
+    against due_frames frame by frame."""
+    from metdetpy_amd.timeshard import NoiseChain, chains_at, due_frames, due_in
+
+    class Shard:
+        def __init__(self, warm, adaptive):
+            self.warm, self.adaptive = warm, adaptive
+
+        def _chain(self):
+            return NoiseChain(8, 2, 20736.0, "normal", self.adaptive, 7)
+
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        adaptive = bool(trial % 2)
+        ts = sorted(rng.choice(np.arange(2, 5000), size=int(rng.integers(0, 300)), replace=False).tolist())
+        table = {int(t): (8 if t > 8 else int(t), int(rng.integers(-10**6, 10**6)) if trial % 5 else 0,
+                          int(rng.integers(0, 10**9)) if trial % 5 else 0) for t in ts}
+        shards = [Shard(int(w), adaptive) for w in rng.integers(0, 5200, size=6)]
+        for sh, got in zip(shards, chains_at(shards, table)):
+            ref = sh._chain()
+            for t in sorted(table):
+                if t > sh.warm:
+                    break
+                ref.update(*table[t])
+            assert ref.state() == got.state(), (trial, sh.warm)
+    for _ in range(300):
+        n, itv, lo = int(rng.integers(2, 20)), int(rng.integers(1, 5)), int(rng.integers(0, 300))
+        hi = lo + int(rng.integers(0, 200))
+        assert due_in(lo, hi, n, itv) == [(t, due_frames(t, n, itv)) for t in range(lo + 1, hi + 1) if due_frames(t, n, itv)]

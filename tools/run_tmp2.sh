@@ -1,5 +1,5 @@
-O=gpurun_out/r04_23; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py tests/test_gpu_per_frame_buffers.py tests/test_timeshard.py -m gpu -q -x > $O/pytest.log 2>&1; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/pytest.log | tail -3
-bash tools/run_tmp.sh r04_23 "dy4=metdetpy_amd/libmetdet_hip.so" "C3 C1s C2"
-python bench.py --protocol per-frame --steps 8000 --no-secondary --cpu-seconds 0 --parity-frames 64 > $O/pf.json 2>>$O/err; python -c "
-import json;d=json.loads(open('$O/pf.json').read().strip().splitlines()[-1]);print('pf',int(d['value']),d['per_frame']['us_per_frame'],d['parity']['verdict'])"
+O=gpurun_out/r04_25; mkdir -p $O
+A="--cpu-seconds 0 --no-pmc --no-secondary --parity-frames 0"
+for rep in 1 2; do for th in 4 8 2; do MDH_TS_SCAN_THREADS=$th python bench.py --mode timeshard $A > $O/ts_${th}_$rep.json 2>> $O/err; python -c "
+import json
+d=json.loads(open('$O/ts_${th}_$rep.json').read().strip().splitlines()[-1]);print('ts threads $th',int(d['value']),round(d['ms_per_step'],3), d.get('timeshard',{}).get('first_sweep_s'))"; done; done
