@@ -52,6 +52,7 @@ def run_bands(a, D, wl, mask, cfg):
     from metdetpy_amd.bands import BandedM3Detector, LocalBands
     H, W, n = wl["H"], wl["W"], wl["n"]
     B = a.batch
+    local_shared = False
     frames = bench.make_stream_frames(wl, 0, mask, B, a.unique)  # every rank sees the SAME stream (rank 0's seed)
     uniq = len(frames)
     idx = np.arange(B) % uniq
@@ -85,6 +86,7 @@ def run_bands(a, D, wl, mask, cfg):
             ptrs.append(p)
         step = lambda: det.detect_batch_device(ptrs, B)
         submit = lambda: det.submit_device(ptrs, B)
+        local_shared = det.shared
     tally = [0, 0, 0]
     first = None
     for _ in range(max(a.warmup, 1)):
@@ -101,9 +103,9 @@ def run_bands(a, D, wl, mask, cfg):
             submit()
             queued += 1
         if queued == 2 or (s_ == steps and queued):
-            res, info = det.collect()
+            res, info = det.collect(arrays=True) if local_shared else det.collect()
             queued -= 1
-            if res is not None:
+            if info is not None and (res is not None or local_shared):
                 tally[0] += int(info["n_raw"].sum())
                 tally[1] += int(info["n_nms"].sum())
                 tally[2] += int(info["lit_count"].sum())

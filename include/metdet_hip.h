@@ -281,12 +281,23 @@ void* mdh_band_sums_device(mdh_ctx* ctx);           /* device int64 [2 * n_jobs]
  * mdh_band_pixels' dst_rows with out_on_device = 1. */
 int mdh_band_pixels_submit(mdh_ctx* ctx, const int64_t* sums_total_device, double roi_px_total, int own_row0, int own_rows,
                            int rows_stride, int nsplit, uint64_t* dst_rows_device, int flags);
+/* The thresholds of the staged pass on their own (the sums as for mdh_band_pixels_submit, which then skips this part).  For a
+ * process that drives several bands on one device: queued for ALL bands before the first band's pixel stages, the scalar chains run
+ * while the device is quiet instead of each waiting for a CU between two bands' window kernels. */
+int mdh_band_thresholds_submit(mdh_ctx* ctx, const int64_t* sums_total_device, double roi_px_total);
 #define MDH_EXPORT_NOFILL 1     /* flags: do not zero-fill the slots first (the destination is a plane several bands write into) */
 /* All bands in ONE process: the dst planes ([K][H][WW] u64) the next pass queued on a MDH_ROLE_HOUGH context will read.  Every
  * band exports its rows straight into them (dst_rows_device = planes + own_first_row * WW, rows_stride = H, nsplit = 1,
  * MDH_EXPORT_NOFILL; together the bands cover every row) and mdh_hough_planes_submit(ctx, planes, K, 1, 1, H) assembles in
  * place: the exchange costs nothing. */
 void* mdh_hough_input_planes(mdh_ctx* ctx);
+/* The same in one call, counters included: band `ctx` (thresholds as for mdh_band_pixels_submit) exports its owned rows into the
+ * planes of the pass `hough` queues next, rows full_row0 ..., and adds their row / frame lit counts and bounding box to that pass's
+ * counters (the first band of a pass zeroes them), so that mdh_hough_planes_submit(hough, mdh_hough_input_planes(hough), K, 1, 1, H)
+ * has nothing left to assemble or count.  Every band of the pass must use this entry point; mdh_chain the band's post stream
+ * into the Hough context before submitting, as with mdh_band_pixels_submit. */
+int mdh_band_pixels_submit_to(mdh_ctx* ctx, const int64_t* sums_total_device, double roi_px_total, int own_row0, int own_rows,
+                              mdh_ctx* hough, int full_row0);
 int mdh_band_collect(mdh_ctx* ctx, mdh_frame_info* info);   /* waits for the oldest queued band pass; returns its frame count */
 /* everything queued on producer's stream so far precedes whatever is queued on consumer's stream from now on (same process) */
 int mdh_chain(mdh_ctx* producer, int producer_stream, mdh_ctx* consumer, int consumer_stream);

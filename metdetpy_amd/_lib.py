@@ -80,7 +80,7 @@ EXPORTS = [
     "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
     "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes",
     "mdh_host_register", "mdh_host_unregister", "mdh_set_auto_register", "mdh_update_stats", "mdh_set_device",
-    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset", "mdh_share_streams"
+    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset", "mdh_share_streams", "mdh_band_thresholds_submit", "mdh_band_pixels_submit_to"
 ]
 
 _lib = None
@@ -201,6 +201,8 @@ def load():
     L.mdh_band_sums_device.argtypes = [vp]
     L.mdh_band_sums_device.restype = vp
     L.mdh_band_pixels_submit.argtypes = [vp, vp, dbl, i32, i32, i32, i32, vp, i32]
+    L.mdh_band_thresholds_submit.argtypes = [vp, vp, dbl]
+    L.mdh_band_pixels_submit_to.argtypes = [vp, vp, dbl, i32, i32, vp, i32]
     L.mdh_hough_input_planes.argtypes = [vp]
     L.mdh_hough_input_planes.restype = vp
     L.mdh_band_collect.argtypes = [vp, vp]
@@ -481,10 +483,21 @@ class Context:
         """hipStream_t (as an integer) of one of the context's streams: MDH_STREAM_*; for collectives the host enqueues (RCCL)."""
         return int(self.L.mdh_stream_handle(self.handle, int(which)) or 0)
 
+    def band_thresholds_submit(self, roi_px_total, sums_total_device: int = 0):
+        """The staged pass's thresholds on their own, ahead of band_pixels_submit (several bands of one process: all bands' chains
+        before the first band's window kernel)."""
+        check(self.L.mdh_band_thresholds_submit(self.handle, int(sums_total_device) or None, float(roi_px_total)), "mdh_band_thresholds_submit")
+
     def band_pixels_submit(self, roi_px_total, own_row0, own_rows, rows_stride, nsplit, out: int, sums_total_device: int = 0,
                            nofill: bool = False):
         check(self.L.mdh_band_pixels_submit(self.handle, int(sums_total_device) or None, float(roi_px_total), int(own_row0), int(own_rows),
                                             int(rows_stride), int(nsplit), int(out), 1 if nofill else 0), "mdh_band_pixels_submit")
+
+    def band_pixels_submit_to(self, roi_px_total, own_row0, own_rows, hough: "Context", full_row0, sums_total_device: int = 0):
+        """Owned rows AND their lit counts / bounding box straight into the pass `hough` (a MDH_ROLE_HOUGH context of this process
+        and device) queues next: nothing left for that context to assemble."""
+        check(self.L.mdh_band_pixels_submit_to(self.handle, int(sums_total_device) or None, float(roi_px_total), int(own_row0), int(own_rows),
+                                               hough.handle, int(full_row0)), "mdh_band_pixels_submit_to")
 
     @property
     def hough_input_planes(self) -> int:

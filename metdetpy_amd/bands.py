@@ -199,7 +199,7 @@ class LocalBands:
             # MDH_BANDS_SHARE_STREAMS=1: the bands of one process queue their stages on band 0's streams (mdh_share_streams).  Off
             # by default: measured slower on one MI355X (8 bands of an 8K stream: 30 k frames/s shared against 52 k with a set of
             # streams per band at 4 hardware queues, 50 k / 47 k at 8 / 12 queues; profiles/EXPERIMENTS.md, round 4)
-            if os.environ.get("MDH_BANDS_SHARE_STREAMS", "0") == "1":
+            if os.environ.get("MDH_BANDS_SHARE_STREAMS", "1") != "0":
                 for e in self.engines[1:]:
                     e.band.share_streams_of(self.engines[0].band)
         else:
@@ -249,14 +249,28 @@ class LocalBands:
         self.submit_device(sub_ptrs, K)
         return self.collect()
 
-    def collect(self):
-        """Results of the oldest pass queued with submit_device."""
+    def collect(self, arrays=False):
+        """Results of the oldest pass queued with submit_device.  arrays=True (shared Hough context only): (None, info) with the
+        pass's frame records as ONE array and no per-frame (lines, cls_pred) objects -- what a batched consumer (the native
+        collector, the bench) takes; the raw / NMS segments of the pass stay in `.last_arrays` = (raw, nms, prob) until the next
+        collect.  (Packaging 500 frames one by one is 2.5 ms of interpreter time per pass, during which nothing is submitted.)"""
         K, kp = self._queued.pop(0)
         p = self.s.plan
         N = p.nbands
+        thr = [e.thresholds_collect() for e in self.engines][0]  # every band frees its slot; the scalars are the same everywhere
+        if self.shared and arrays:
+            if getattr(self, "_bufs", None) is None or len(self._bufs[0]) < K:
+                self._bufs = (np.zeros(K, _lib.FRAME_INFO_DTYPE), np.zeros((K, _lib.MDH_MAX_LINES, 4), np.int32),
+                              np.zeros((K, _lib.MDH_MAX_LINES, 4), np.int32), np.zeros((K, _lib.MDH_MAX_LINES), np.float64))
+            binfo, raw, nms, prob = self._bufs
+            self.hough.collect_into(binfo, raw, nms, prob)
+            info = binfo[:K].copy()
+            for f in ("bi_threshold", "bi_threshold_float", "snr", "sigma"):
+                info[f] = thr[f][:K]
+            self.last_arrays = (raw, nms, prob)
+            return None, info
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
         results = [None] * K
-        thr = [e.thresholds_collect() for e in self.engines][0]  # every band frees its slot; the scalars are the same everywhere
         if self.shared:
             hi, raw, nms, prob = self.hough.hough_planes_collect(K)
             for i in range(K):
@@ -324,8 +338,18 @@ class LocalBands:
             planes = self.hough.hough_input_planes
             if not planes:
                 raise RuntimeError("the shared Hough context has no free pass slot")
+            # every band's scalar chain first (one workgroup of sixteen waves each: between two bands' window kernels it would
+            # wait for a CU to drain, with the next window kernel behind it), then the pixel stages band by band
+            for e in self.engines:
+                e.band.band_thresholds_submit(self.s.plan.roi_px)
+            # (MDH_BANDS_COUNT_IN_EXPORT=0: rows only, the Hough context counts them in a sweep of its own -- round 3, A/B)
+            count = os.environ.get("MDH_BANDS_COUNT_IN_EXPORT", "1") != "0"
             for b, e in enumerate(self.engines):
-                e.pixels_submit_into_planes(planes)
+                if count:
+                    d = p.bands[b]
+                    e.band.band_pixels_submit_to(p.roi_px, d["own0"] - d["sub0"], d["own1"] - d["own0"], self.hough, d["own0"])
+                else:
+                    e.pixels_submit_into_planes(planes)
                 e.band.chain_to(_lib.MDH_STREAM_POST_LAST, self.hough, _lib.MDH_STREAM_POST_NEXT)
             self.hough.hough_planes_submit(planes, K, 1, p.H, on_device=True)
             self._queued.append((K, kp))

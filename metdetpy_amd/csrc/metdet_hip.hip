@@ -257,6 +257,9 @@ struct mdh_ctx {
     size_t chain_next = 0;
     bool poisoned = false;
     double wait_timeout_ms = 0;  // mdh_set_wait_timeout_ms: how long a collect waits for its pass (0 = for ever)
+    bool planes_begun = false;      // MDH_ROLE_HOUGH: the next slot's counters are zeroed and being filled by mdh_band_pixels_submit_to
+    hipEvent_t ev_begin = nullptr;  //   ... that zeroing, for the bands' post streams to wait on
+    bool band_thr_done = false;     // mdh_band_thresholds_submit ran for the pass staged by mdh_band_submit
     bool streams_borrowed = false;  // mdh_share_streams: the main / noise / post / copy streams belong to another context
     // Format of b = (diff > T) between the window kernel and the morphology: sparse + tagged (a quiet sky: nothing is written for
     // 99 % of the wave-frames) or dense + plain (binaries with noise in them: 8K at m3det_high).  Chosen per pass from the share
@@ -385,6 +388,7 @@ static void free_all(mdh_ctx* c) {
         }
     }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->ev_begin) hipEventDestroy(c->ev_begin);
     for (hipEvent_t e : c->chain_ev)
         if (e) hipEventDestroy(e);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
@@ -2006,6 +2010,7 @@ extern "C" int mdh_band_noise(mdh_ctx* c, const uint8_t* frames, int K, int on_d
     if (nj) HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof(long long) * 2 * nj, hipMemcpyDeviceToHost, c->nstream));
     HIPCHK(hipStreamSynchronize(c->nstream));
     c->band_slot = sl;
+    c->band_thr_done = false;
     c->band_nj = nj;
     *n_jobs = nj;
     return MDH_OK;
@@ -2099,14 +2104,59 @@ extern "C" int mdh_band_submit(mdh_ctx* c, const uint8_t* frames, int K, int on_
     if ((rc = retire_frames(c, *sl, K, on_device)) != MDH_OK) return poison(c, rc);
     if ((rc = noise_prepare(c, *sl, K, &nj)) != MDH_OK) return poison(c, rc);
     c->band_slot = sl;
+    c->band_thr_done = false;
     c->band_nj = nj;
     *n_jobs = nj;
     return MDH_OK;
 }
 extern "C" void* mdh_band_sums_device(mdh_ctx* c) { return (c && c->band_slot) ? (void*)c->band_slot->d_sums : nullptr; }
 
+// The thresholds of the staged pass on their own, ahead of mdh_band_pixels_submit (which then skips this part).  For a process that
+// drives SEVERAL bands on one device: the scalar chain is one workgroup of sixteen waves and 32 KB of LDS, and queued between two
+// bands' window kernels -- each of which fills every CU -- it waits for a whole CU to drain (0.7 ms) with the next band's window
+// kernel waiting behind it.  Queued for all bands BEFORE the first band's window kernel, the chains run while the device is quiet.
+extern "C" int mdh_band_thresholds_submit(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total) {
+    if (!c) { set_err("mdh_band_thresholds_submit: null context"); return MDH_E_ARG; }
+    if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_thresholds_submit: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
+    if (!c->band_slot) { set_err("mdh_band_thresholds_submit: call mdh_band_submit first"); return MDH_E_STATE; }
+    if (c->band_thr_done) { set_err("mdh_band_thresholds_submit: the staged pass has its thresholds already"); return MDH_E_STATE; }
+    if (!(roi_px_total > 0)) { set_err("mdh_band_thresholds_submit: bad roi_px_total"); return MDH_E_ARG; }
+    CHECK_POISON(c, "mdh_band_thresholds_submit");
+    HIPCHK(hipSetDevice(c->device));
+    Slot& sl = *c->band_slot;
+    const int nj = c->band_nj;
+    if (nj && d_sums_total && (const void*)d_sums_total != (const void*)c->d_sums)
+        HIPCHK(hipMemcpyAsync(c->d_sums, d_sums_total, sizeof(long long) * 2 * nj, hipMemcpyDeviceToDevice, c->nstream));
+    int rc;
+    if ((rc = noise_finish(c, sl, sl.K, nj, roi_px_total)) != MDH_OK) return poison(c, rc);
+    c->band_thr_done = true;
+    return MDH_OK;
+}
+
+static int band_pixels_submit_impl(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total, int own_row0, int own_rows,
+                                   int rows_stride, int nsplit, uint64_t* dst_rows_device, int flags, mdh_ctx* hough, int full_row0);
 extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total, int own_row0, int own_rows,
                                       int rows_stride, int nsplit, uint64_t* dst_rows_device, int flags) {
+    return band_pixels_submit_impl(c, d_sums_total, roi_px_total, own_row0, own_rows, rows_stride, nsplit, dst_rows_device, flags, nullptr, 0);
+}
+// A band of a process whose bands share ONE Hough context (same device): the owned rows go straight into the planes of the pass
+// that context queues next, rows full_row0 ..., and their lit counts and bounding box into that pass's counters (k_export_rows_count)
+// -- mdh_hough_planes_submit(hough, mdh_hough_input_planes(hough), K, 1, 1, H) then has nothing to assemble or count.  The first
+// band of a pass zeroes the counters (on the Hough context's stream; every band's export waits for it).
+extern "C" int mdh_band_pixels_submit_to(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total, int own_row0, int own_rows,
+                                         mdh_ctx* hough, int full_row0) {
+    if (!c || !hough) { set_err("mdh_band_pixels_submit_to: null argument"); return MDH_E_ARG; }
+    if (hough->role != MDH_ROLE_HOUGH) { set_err("mdh_band_pixels_submit_to: the target is not a MDH_ROLE_HOUGH context"); return MDH_E_STATE; }
+    if (hough->device != c->device) { set_err("mdh_band_pixels_submit_to: the two contexts are on different devices"); return MDH_E_ARG; }
+    if (hough->WW != c->WW || hough->W != c->W) { set_err("mdh_band_pixels_submit_to: the two contexts differ in width"); return MDH_E_ARG; }
+    if (hough->in_flight >= hough->nslot) { set_err("mdh_band_pixels_submit_to: the Hough context has no free pass slot"); return MDH_E_STATE; }
+    if (full_row0 < 0 || own_rows < 1 || full_row0 + own_rows > hough->H) { set_err("mdh_band_pixels_submit_to: rows outside the whole frame"); return MDH_E_ARG; }
+    CHECK_POISON(hough, "mdh_band_pixels_submit_to");
+    return band_pixels_submit_impl(c, d_sums_total, roi_px_total, own_row0, own_rows, hough->H, 1,
+                                   (uint64_t*)hough->slot[hough->next_slot].d_dst, MDH_EXPORT_NOFILL, hough, full_row0);
+}
+static int band_pixels_submit_impl(mdh_ctx* c, const int64_t* d_sums_total, double roi_px_total, int own_row0, int own_rows,
+                                   int rows_stride, int nsplit, uint64_t* dst_rows_device, int flags, mdh_ctx* hough, int full_row0) {
     if (!c || !dst_rows_device) { set_err("mdh_band_pixels_submit: null argument"); return MDH_E_ARG; }
     if (c->role != MDH_ROLE_BAND) { set_err("mdh_band_pixels_submit: not a MDH_ROLE_BAND context"); return MDH_E_STATE; }
     if (!c->band_slot) { set_err("mdh_band_pixels_submit: call mdh_band_submit first"); return MDH_E_STATE; }
@@ -2119,10 +2169,13 @@ extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, d
     Slot& sl = *c->band_slot;
     const int K = sl.K, nj = c->band_nj;
     int rc;
-    // the global sums: already in place (in-place all-reduce on the noise stream), or somewhere else in device memory
-    if (nj && d_sums_total && (const void*)d_sums_total != (const void*)c->d_sums)
-        HIPCHK(hipMemcpyAsync(c->d_sums, d_sums_total, sizeof(long long) * 2 * nj, hipMemcpyDeviceToDevice, c->nstream));
-    if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return poison(c, rc);
+    if (!c->band_thr_done) {  // (else: mdh_band_thresholds_submit has queued this part)
+        // the global sums: already in place (in-place all-reduce on the noise stream), or somewhere else in device memory
+        if (nj && d_sums_total && (const void*)d_sums_total != (const void*)c->d_sums)
+            HIPCHK(hipMemcpyAsync(c->d_sums, d_sums_total, sizeof(long long) * 2 * nj, hipMemcpyDeviceToDevice, c->nstream));
+        if ((rc = noise_finish(c, sl, K, nj, roi_px_total)) != MDH_OK) return poison(c, rc);
+    }
+    c->band_thr_done = false;
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
     hipStream_t post = post_stream(c, c->pass_seq);
     if ((rc = run_pixels(c, sl, K)) != MDH_OK) return poison(c, rc);
@@ -2132,6 +2185,20 @@ extern "C" int mdh_band_pixels_submit(mdh_ctx* c, const int64_t* d_sums_total, d
     // (zero fill only where the export leaves holes: slots of frames that do not exist, rows a short last band does not own)
     if (!(flags & MDH_EXPORT_NOFILL) && ((size_t)nsplit * Kp != (size_t)K || own_rows != rows_stride))
         HIPCHK(hipMemsetAsync(dev_out, 0, out_words * sizeof(u64), post));
+    if (hough) {
+        if (K > hough->Kmax) { set_err("mdh_band_pixels_submit_to: the pass is larger than the Hough context's max_batch"); return poison(c, MDH_E_ARG); }
+        Slot& hs_sl = hough->slot[hough->next_slot];
+        if (!hough->planes_begun) {  // first band of the pass: the counters the bands accumulate into start at zero
+            hipStream_t hpost = post_stream(hough, hough->pass_seq);
+            if (!hough->ev_begin) HIPCHK(hipEventCreateWithFlags(&hough->ev_begin, hipEventDisableTiming));
+            HIPCHK(hipMemsetAsync(hs_sl.d_rowcount, 0, sizeof(int) * ((size_t)hough->Kmax * hough->H + 5 * (size_t)hough->Kmax), hpost));
+            HIPCHK(hipEventRecord(hough->ev_begin, hpost));
+            hough->planes_begun = true;
+        }
+        HIPCHK(hipStreamWaitEvent(post, hough->ev_begin, 0));
+        hipLaunchKernelGGL(k_export_rows_count, dim3((own_rows * c->WW + 255) / 256, K), dim3(256), 0, post, sl.d_dst, (u64*)hs_sl.d_dst, c->H,
+                           c->WW, own_row0, own_rows, hough->H, c->W, full_row0, hs_sl.d_rowcount, hs_sl.d_litcount, hs_sl.d_bbox);
+    } else
     hipLaunchKernelGGL(k_export_rows, dim3((own_rows * c->WW + 255) / 256, K), dim3(256), 0, post, sl.d_dst, dev_out, K, c->H, c->WW,
                        own_row0, own_rows, rows_stride, nsplit, Kp);
     HIPCHK(hipGetLastError());
@@ -2404,11 +2471,15 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
         HIPCHK(hipMemcpyAsync(c->d_xchg, pieces, in_words * sizeof(u64), hipMemcpyHostToDevice, post));
         src = c->d_xchg;
     }
-    HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), post));
+    const bool counted = c->planes_begun;  // mdh_band_pixels_submit_to: the bands have filled the planes AND the counters of this slot
+    c->planes_begun = false;
+    if (!counted) HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), post));
     // pieces == the slot's own plane buffer (mdh_hough_input_planes: the bands exported straight into it, one "band" of H rows):
     // nothing to copy, only the row / frame lit counts and the bounding boxes are taken
     const int inplace = (on_device && (const void*)src == (const void*)sl.d_dst && nbands == 1 && band_rows == c->H) ? 1 : 0;
     if ((const void*)src == (const void*)sl.d_dst && !inplace) { set_err(std::string(who) + ": the context's own plane buffer wants nbands = 1, band_rows = H"); return MDH_E_ARG; }
+    if (counted && !inplace) { set_err(std::string(who) + ": bands exported into this pass with mdh_band_pixels_submit_to: submit the context's own planes"); return MDH_E_STATE; }
+    if (!counted)
     hipLaunchKernelGGL(k_assemble_planes, dim3((unsigned)((c->words + 255) / 256), K), dim3(256), 0, post, src, sl.d_dst, sl.d_rowcount,
                        sl.d_litcount, sl.d_bbox, K, c->H, c->W, c->WW, band_rows, inplace);
     HIPCHK(hipGetLastError());

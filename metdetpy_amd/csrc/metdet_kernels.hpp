@@ -1893,6 +1893,29 @@ __global__ void __launch_bounds__(256) k_export_rows(const u64* __restrict__ dst
 // The other end: frame i of a Hough context is assembled from nbands pieces (piece b = rows [b*band_rows, ...) at
 // ((b * K + i) * band_rows) * WW), together with what the Hough stage wants to know about it: per-row and per-frame lit
 // counts and the bounding box of the lit pixels (as k_dy_sparse leaves them).
+// Row bands of one process, one shared Hough context: the band's owned rows straight into that context's whole-frame planes
+// (plane i, rows full_row0 ...), and the row / frame lit counts and the bounding box of the words that are not zero straight into
+// its counters -- what k_assemble_planes would otherwise take from a second sweep over the assembled planes (2 GB per 500 8K
+// frames, 0.58 ms at the end of every pass, behind the last band's export).
+__global__ void __launch_bounds__(256) k_export_rows_count(const u64* __restrict__ dst_bits, u64* __restrict__ planes, int H, int WW,
+                                                           int row0, int rows, int Hf, int W, int full_row0, int* __restrict__ rowcount,
+                                                           int* __restrict__ litcount, int* __restrict__ bbox) {
+    const int i = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * WW) return;
+    const u64 v = dst_bits[((size_t)i * H + row0) * WW + e];
+    planes[((size_t)i * Hf + full_row0) * WW + e] = v;
+    if (v) {
+        const int y = full_row0 + e / WW, w = e % WW;
+        const int c = __popcll(v);
+        atomicAdd(&rowcount[i * Hf + y], c);
+        atomicAdd(&litcount[i], c);
+        atomicMax(&bbox[4 * i + 0], W - 1 - (w * 64 + __builtin_ctzll(v)));
+        atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(v));
+        atomicMax(&bbox[4 * i + 2], Hf - 1 - y);
+        atomicMax(&bbox[4 * i + 3], y);
+    }
+}
 __global__ void __launch_bounds__(256) k_assemble_planes(const u64* __restrict__ pieces, u64* __restrict__ dst_bits,
                                                          int* __restrict__ rowcount, int* __restrict__ litcount,
                                                          int* __restrict__ bbox, int K, int H, int W, int WW, int band_rows, int inplace) {
