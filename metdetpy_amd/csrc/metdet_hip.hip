@@ -2058,6 +2058,7 @@ extern "C" int mdh_band_pixels(mdh_ctx* c, const int64_t* sums_total, double roi
     c->pass_seq += 1;
     slot_commit(c, sl);
     c->band_slot = nullptr;
+    c->band_thr_done = false;
     HIPCHK(hipEventSynchronize(sl.ev_done));
     spans_collect(c, sl);
     format_cue(c, sl);

@@ -317,4 +317,17 @@ def test_band_api_errors():
         e.pixels(np.zeros(2, np.int64))
     with pytest.raises(_lib.MetDetHipError, match="MDH_ROLE_FULL"):
         e.band.process_batch(np.zeros((2, e.band.H, 64), np.uint8))
+    # the queued entry points of round 4: thresholds ahead of the pixel stages, export into the shared Hough context
+    with pytest.raises(_lib.MetDetHipError, match="mdh_band_submit first"):
+        e.band.band_thresholds_submit(lb.s.plan.roi_px)
+    with pytest.raises(_lib.MetDetHipError, match="not a MDH_ROLE_HOUGH"):
+        e.band.band_pixels_submit_to(lb.s.plan.roi_px, 0, 4, lb.engines[1].band, 0)
+    sub = np.zeros((2, e.band.H, 64), np.uint8)
+    e.band.band_submit(sub)
+    e.band.band_thresholds_submit(lb.s.plan.roi_px)
+    with pytest.raises(_lib.MetDetHipError, match="thresholds already"):
+        e.band.band_thresholds_submit(lb.s.plan.roi_px)
+    with pytest.raises(_lib.MetDetHipError, match="outside the whole frame"):
+        e.band.band_pixels_submit_to(lb.s.plan.roi_px, 0, 4, lb.hough, 62)
+    e.band.band_skip()
     lb.close()
