@@ -2152,6 +2152,7 @@ extern "C" int mdh_band_pixels_submit_to(mdh_ctx* c, const int64_t* d_sums_total
     if (hough->WW != c->WW || hough->W != c->W) { set_err("mdh_band_pixels_submit_to: the two contexts differ in width"); return MDH_E_ARG; }
     if (hough->in_flight >= hough->nslot) { set_err("mdh_band_pixels_submit_to: the Hough context has no free pass slot"); return MDH_E_STATE; }
     if (full_row0 < 0 || own_rows < 1 || full_row0 + own_rows > hough->H) { set_err("mdh_band_pixels_submit_to: rows outside the whole frame"); return MDH_E_ARG; }
+    if (c->band_slot && c->band_slot->K > hough->Kmax) { set_err("mdh_band_pixels_submit_to: the pass is larger than the Hough context's max_batch"); return MDH_E_ARG; }
     CHECK_POISON(hough, "mdh_band_pixels_submit_to");
     return band_pixels_submit_impl(c, d_sums_total, roi_px_total, own_row0, own_rows, hough->H, 1,
                                    (uint64_t*)hough->slot[hough->next_slot].d_dst, MDH_EXPORT_NOFILL, hough, full_row0);
@@ -2187,7 +2188,6 @@ static int band_pixels_submit_impl(mdh_ctx* c, const int64_t* d_sums_total, doub
     if (!(flags & MDH_EXPORT_NOFILL) && ((size_t)nsplit * Kp != (size_t)K || own_rows != rows_stride))
         HIPCHK(hipMemsetAsync(dev_out, 0, out_words * sizeof(u64), post));
     if (hough) {
-        if (K > hough->Kmax) { set_err("mdh_band_pixels_submit_to: the pass is larger than the Hough context's max_batch"); return poison(c, MDH_E_ARG); }
         Slot& hs_sl = hough->slot[hough->next_slot];
         if (!hough->planes_begun) {  // first band of the pass: the counters the bands accumulate into start at zero
             hipStream_t hpost = post_stream(hough, hough->pass_seq);
