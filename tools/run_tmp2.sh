@@ -1,6 +1,5 @@
-O=gpurun_out/r04_34; mkdir -p $O
-A="--cpu-seconds 0 --no-pmc --no-secondary"
-for rep in 1 2; do for sb in 1024 4096 8192; do MDH_TS_SCAN_BATCH=$sb python bench.py --mode timeshard $A > $O/ts_${sb}_$rep.json 2>> $O/err; python -c "
-import json
-d=json.loads(open('$O/ts_${sb}_$rep.json').read().strip().splitlines()[-1]);print('ts SB $sb',int(d['value']),round(d['ms_per_step'],3), (d.get('parity') or {}).get('verdict'), d.get('timeshard',{}).get('first_sweep_s'))"; done; done
-timeout 600 python -m pytest tests/test_gpu_bench_contract.py -m gpu -q -k "time_window" > $O/pytest.log 2>&1; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/pytest.log | tail -2
+O=gpurun_out/r04_35; mkdir -p $O
+C="--no-pmc --cpu-seconds 0 --parity-frames 0 --no-profile --no-secondary --steps 6 --warmup 1"
+for rep in 1 2 3; do for v in "hp3=metdetpy_amd/libmetdet_hip.so" "hp0=metdetpy_amd/libmetdet_hip_hp0.so" "hp1=metdetpy_amd/libmetdet_hip_hp1.so"; do name=${v%%=*}; lib=${v#*=}
+for wl in C1s C3; do MDH_LIB=$PWD/$lib python bench.py --workload $wl $C > $O/${wl}_${name}_$rep.json 2>>$O/err; python -c "
+import json;d=json.loads(open('$O/${wl}_${name}_$rep.json').read().strip().splitlines()[-1]);print('$wl $name $rep', int(d['value']))"; done; done; done
