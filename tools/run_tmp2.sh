@@ -1,5 +1,4 @@
-O=gpurun_out/r04_35; mkdir -p $O
-C="--no-pmc --cpu-seconds 0 --parity-frames 0 --no-profile --no-secondary --steps 6 --warmup 1"
-for rep in 1 2 3; do for v in "hp3=metdetpy_amd/libmetdet_hip.so" "hp0=metdetpy_amd/libmetdet_hip_hp0.so" "hp1=metdetpy_amd/libmetdet_hip_hp1.so"; do name=${v%%=*}; lib=${v#*=}
-for wl in C1s C3; do MDH_LIB=$PWD/$lib python bench.py --workload $wl $C > $O/${wl}_${name}_$rep.json 2>>$O/err; python -c "
-import json;d=json.loads(open('$O/${wl}_${name}_$rep.json').read().strip().splitlines()[-1]);print('$wl $name $rep', int(d['value']))"; done; done; done
+O=gpurun_out/r04_36; mkdir -p $O
+C="--no-pmc --cpu-seconds 0 --parity-frames 0 --no-secondary --gpus 1 --steps 20 --warmup 5"
+for rep in 1 2 3 4 5; do python bench.py $C > $O/d_$rep.json 2>>$O/err; python -c "
+import json;d=json.loads(open('$O/d_$rep.json').read().strip().splitlines()[-1]);r=d['roofline'];print('run $rep', int(d['value']), round(r['launch_ms'],3), round(r['frac'],3), round(r['frac_at_pipeline_pace'],3))"; rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|mclk\|power" | head -4; done
