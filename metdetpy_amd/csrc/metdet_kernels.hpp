@@ -485,6 +485,14 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef LEAN_AUX
 #define LEAN_AUX 0  // cache policy bits of the per-frame window kernel's loads (A/B builds: 1 = sc0, 2 = nt, 16 = sc1, 17 = sc0 sc1)
 #endif
+#ifndef WIDE_AUX
+// Cache policy bits of the batched window kernel's frame loads: nt (non-temporal).  Every frame byte is read once per launch, and
+// with the default policy the CU's vector-memory front end was the limit nobody had looked at: SQ_VMEM_TA_ADDR_FIFO_FULL /
+// _CMD_FIFO_FULL 15 % of the wave cycles, SQ_WAIT_INST_ANY 44 % at a VALU that is half busy (round 4, gpurun_out/r04_39, r04_41).
+// Measured on one box (r04_42, isolated 1080p launch / frames per second): default 1.63-1.65 ms / 2.32-2.36 M; sc0 the same; sc1
+// the same; nt 1.46-1.47 ms / 2.54-2.57 M; sc0 nt and sc1 nt like nt.  (A/B builds: -DWIDE_AUX=0 | 1 sc0 | 2 nt | 3 | 16 sc1 | 18)
+#define WIDE_AUX 2
+#endif
 #ifndef WIDE_MAX3
 #define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
 #endif
@@ -584,17 +592,17 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     auto fetch = [&](int e) -> dvec {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
         if constexpr (PPL == 16) {
-            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : 0));
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         } else {
-            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : 0));
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         }
     };
     auto fetchp = [&](const uint8_t* base) -> dvec {  // the same with the frame's base already in scalar registers
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, frame_bytes, 0x00020000);
         if constexpr (PPL == 16) {
-            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : 0));
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         } else {
-            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : 0));
+            return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         }
     };
     auto unpack = [&](const dvec& d, PK (&p)[RW]) {
