@@ -1181,7 +1181,7 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
             const int nx4 = (r[1] + rw - xa + 3) >> 2;
             // (at most 48 workgroups per due frame; 8 or 16 at 960x540 -- 1000 due frames per pass -- shorten the launch alone, 0.235 -> 0.176 ms,
             // and change nothing at the pipeline's pace)
-            hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->nstream, c->d_ptrtab,
+            hipLaunchKernelGGL(k_noise_sums<0>, dim3(std::min((rh * nx4 + 255) / 256, 48), nj), dim3(256), 0, c->nstream, c->d_ptrtab,
                                c->d_jobs, c->d_sums, g, r[0], r[1], rh, rw);
         } else {
             hipLaunchKernelGGL(k_noise_sums_bytes, dim3((rh * rw + 255) / 256, nj), dim3(256), 0, c->nstream, c->d_ptrtab,
@@ -1241,7 +1241,7 @@ static int run_noise_direct(mdh_ctx* c, Slot& sl) {
     const int xa = r[1] & ~3;
     const int nx4 = (r[1] + rw - xa + 3) >> 2;
     span_begin(c, KK_NOISE_SUMS, c->nstream);
-    hipLaunchKernelGGL(k_noise_sums, dim3(std::min((rh * nx4 + 255) / 256, 48), 1), dim3(256), 0, c->nstream, c->d_ptrtab, c->d_jobs, c->d_sums, g,
+    hipLaunchKernelGGL(k_noise_sums<0>, dim3(std::min((rh * nx4 + 255) / 256, 48), 1), dim3(256), 0, c->nstream, c->d_ptrtab, c->d_jobs, c->d_sums, g,
                        r[0], r[1], rh, rw);
     span_end(c, c->nstream);
     span_begin(c, KK_NOISE_FINAL, c->nstream);

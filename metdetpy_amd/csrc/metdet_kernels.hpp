@@ -58,6 +58,9 @@ struct NoiseJob {
     double one_minus; // 1 - m_cur
 };
 
+// AUX: cache policy bits of the frame loads.  0 everywhere: measured with nt for the batched passes, the window kernel that follows
+// got 3 % slower (1.46 -> 1.51 ms: with the default policy part of the ROI it is about to read is still in the Infinity Cache)
+template <int AUX>
 __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __restrict__ ptrtab, const NoiseJob* __restrict__ jobs,
                                                     long long* __restrict__ sums, PassGeom g, int r0, int c0, int rh, int rw) {
     RAISE_WAVE_PRIORITY();
@@ -82,7 +85,7 @@ __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __rest
             for (int j = 0; j < 8; ++j) {  // 8 independent loads in flight; slots past k read offset "far" -> 0
                 const int e = e_last - min(j0 + j, k - 1);
                 const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
-                v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, j0 + j < k ? off : 0x7FFFFFF0, 0, 0);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, j0 + j < k ? off : 0x7FFFFFF0, 0, AUX);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -916,7 +919,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         }
                         if constexpr (DENSE) {
                             nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0));
-                            if (q == 0 && gw < words) ((u64*)bbits)[(size_t)i * words + gw] = v;
+                            if (q == 0 && gw < words) __builtin_nontemporal_store(v, &((u64*)bbits)[(size_t)i * words + gw]);
                         } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             // (the word index through an opaque move: everything derived from it -- the store's address, the block
@@ -1468,7 +1471,7 @@ __global__ void __launch_bounds__(64) k_morph_close_plain(const u64* __restrict_
         for (int it = 0; it < MORPH_PLAIN_ROWS + 6; ++it) {
             const int yy = y0 - 3 + it;
             const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
-            const u64 brow = live ? src[(size_t)yc * g.WW + wc] : 0ull;
+            const u64 brow = live ? src[(size_t)yc * g.WW + wc] : 0ull;  // (default cache policy: the window kernel has just written these words -- non-temporal loads here cost 6 %)
             unsigned lb, rb;
             edge_bits(brow, lb, rb);
             const unsigned eC = lb | (rb << 1);
@@ -2021,7 +2024,7 @@ __global__ void __launch_bounds__(256) k_classic_diff_tb(const uint8_t* const* _
     };
     auto fetch = [&](int e) -> dvec {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
-        return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, WIDE_AUX));  // (read once per launch: nt, like the M3 window kernel)
     };
     auto unpack = [&](const dvec& d, PK (&p)[RW]) {
 #pragma unroll

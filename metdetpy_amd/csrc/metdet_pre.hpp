@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint8_t* __restrict__ 
 // a touched row crosses the memory system once, in whole cache lines -- and the taps are then read from LDS.  Requires source
 // rows of a multiple of 16 bytes and a 16-byte aligned base (sw % 16 == 0: 3840, 2560, 1920, 1280 ...); other sizes keep the
 // kernel above.  Bytes the launch must move: the source rows the resize touches (2 of every 4 at a 4x reduction) + the output.
+typedef unsigned pre_u4 __attribute__((ext_vector_type(4)));
 #define PRE_SEG 256
 #define PRE_ROWS 4  // output rows per workgroup: eight source-row spans in flight per workgroup before its one barrier
 __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __restrict__ src, int exp_frame, PreGeom g,
@@ -96,8 +97,9 @@ __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __re
                 const uint8_t* r0 = f + (size_t)y0 * row_bytes;
                 const uint8_t* r1 = f + (size_t)y1 * row_bytes;
                 for (int o = t * 16; o < span; o += PRE_SEG * 16) {
-                    *(uint4*)(lds_rows + (size_t)(2 * r) * span_cap + o) = *(const uint4*)(r0 + o);
-                    *(uint4*)(lds_rows + (size_t)(2 * r + 1) * span_cap + o) = *(const uint4*)(r1 + o);
+                    // (source rows are read once: non-temporal, like the window kernel's frame loads)
+                    *(pre_u4*)(lds_rows + (size_t)(2 * r) * span_cap + o) = __builtin_nontemporal_load((const pre_u4*)(r0 + o));
+                    *(pre_u4*)(lds_rows + (size_t)(2 * r + 1) * span_cap + o) = __builtin_nontemporal_load((const pre_u4*)(r1 + o));
                 }
             }
         }
@@ -142,7 +144,8 @@ __global__ void __launch_bounds__(256) k_max_stack(const uint8_t* __restrict__ f
     if (tid < nvec) {
         uint4 acc = ((const uint4*)frames)[tid];
         for (int k = 1; k < K; ++k) {
-            const uint4 v = ((const uint4*)(frames + (size_t)k * bytes))[tid];
+            const pre_u4 vv = __builtin_nontemporal_load(&((const pre_u4*)(frames + (size_t)k * bytes))[tid]);  // (every frame byte once)
+            const uint4 v = make_uint4(vv.x, vv.y, vv.z, vv.w);
             const unsigned a[4] = {acc.x, acc.y, acc.z, acc.w}, b[4] = {v.x, v.y, v.z, v.w};
             unsigned r[4];
 #pragma unroll
