@@ -117,6 +117,10 @@ def run_bands(a, D, wl, mask, cfg):
                        else "device-to-device copies on one GPU (stand-in of the all-to-all), every band and every Hough context on this device",
                        "note": "per band and pass: noise share and pixel stages (blocking), the Hough stage of the assembled planes queued "
                                "and collected one pass later; one host thread per band when all bands share one process"}}
+    try:  # which output format the bands' window kernels ended up in (a band that could not allocate its plain buffer stays sparse)
+        extra["bands"]["dense_format_bands"] = [bool(e.band.dense_now) for e in det.engines] if D.world == 1 else [bool(ctx.dense_now)]
+    except Exception:  # noqa: BLE001
+        pass
     if D.rank == 0 and a.parity_frames > 0 and first[0] is not None:
         cnt = min(a.parity_frames, 16, B)
         extra["parity"] = _parity(_oracle_rows(frames[idx[:cnt]], n, mask, cfg.binary.sensitivity, cnt), first[1], first[0], f"the {nb}-band detector")

@@ -31,6 +31,35 @@ __global__ void __launch_bounds__(256) k_read_frames(const uint4* __restrict__ p
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
+// the same two patterns with NON-TEMPORAL loads (round 4: the window kernel's policy since the nt bit took its launch from 0.635 to 0.71)
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_read_nt(const u4v* __restrict__ p, size_t n, unsigned* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        u4v v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(&p[i + k * stride]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_read_frames_nt(const u4v* __restrict__ p, size_t frame_vec, int frames, int tc, unsigned* out) {
+    const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= frame_vec) return;
+    const int f0 = blockIdx.y * tc, f1 = min(frames, f0 + tc);
+    unsigned acc = 0;
+    for (int f = f0; f + 3 < f1; f += 4) {
+        u4v v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(&p[(size_t)(f + k) * frame_vec + chunk]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
 // the window kernel's traffic without its arithmetic: the same loads (1 KB per wave per frame, 4 frames per burst, chunks of
 // `tc` frames along blockIdx.y) plus its stores (one u64 per 4 lanes per frame = 128 B per wave per frame)
 __global__ void __launch_bounds__(256) k_read_write_frames(const uint4* __restrict__ p, size_t frame_vec, int frames, int tc,
@@ -75,6 +104,20 @@ int main() {
         hipEventElapsedTime(&ms, a, b);
         printf("frame-strided read + bit-plane write, %d chunk(s): %.3f ms/pass  %.2f TB/s read (+ %.0f MB written)\n", chunks, ms / 5,
                bytes / (ms / 5 * 1e-3) / 1e12, frames * (fv / 4) * 8 / 1e6);
+    }
+    for (int blocks : {4096, 16384}) {
+        k_read_nt<<<blocks, 256>>>((const u4v*)d, n, o); hipDeviceSynchronize();
+        hipEventRecord(a); for (int r = 0; r < 5; ++r) k_read_nt<<<blocks, 256>>>((const u4v*)d, n, o); hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("grid-stride read, NON-TEMPORAL loads, %5d blocks: %.3f ms/pass  %.2f TB/s\n", blocks, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
+    }
+    for (int chunks : {1, 3}) {
+        const int tc = (int)((frames + chunks - 1) / chunks);
+        k_read_frames_nt<<<dim3((fv + 255) / 256, chunks), 256>>>((const u4v*)d, fv, (int)frames, tc, o); hipDeviceSynchronize();
+        hipEventRecord(a); for (int r = 0; r < 5; ++r) k_read_frames_nt<<<dim3((fv + 255) / 256, chunks), 256>>>((const u4v*)d, fv, (int)frames, tc, o);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("frame-strided read, NON-TEMPORAL loads, %d chunk(s): %.3f ms/pass  %.2f TB/s\n", chunks, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
     }
     return 0;
 }
