@@ -5,8 +5,8 @@
 
 One "step" = `--passes-per-step` native passes (mdh_submit_batch / mdh_collect_batch, several passes in flight), each over a
 batch of `--batch` consecutive frames of a seeded synthetic night-sky stream that is already resident in HBM: update + detect
-incl. Hough and NMS, results on the host.  A pass of the headline workload lasts 1.7 ms; SURVEY 8d asks for >= 2 s timed, so a
-step is sized (64 passes = 256 000 frames at 1080p, ~0.11 s) such that the driver's `--steps 20` times 2.2 s and the
+incl. Hough and NMS, results on the host.  A pass of the headline workload lasts 1.6 ms; SURVEY 8d asks for >= 2 s timed, so a
+step is sized (64 passes = 256 000 frames at 1080p, ~0.10 s) such that the driver's `--steps 20` times 2.1 s and the
 pipeline's one fill and one drain are < 1 % of the region.  config.frames_per_step / passes_per_step / frames_per_pass say so.
 N > 1: one process per GPU (torchrun), one independent stream per GPU (BASELINE config
 C4), no data-path collective; the collectives are the barrier around the timed region, the max-over-ranks time and the
