@@ -737,9 +737,9 @@ def run_per_frame(a, D, wl, mask):
 
 SECONDARY = [
     # (name, extra arguments): each >= 1 s timed at the rates of profiles/, parity on 64 frames, no CPU baseline, no PMC leg
-    ("C3_4k_n16_mask", ["--workload", "C3", "--steps", "11", "--warmup", "2"]),
-    ("C5_8k_high", ["--workload", "C5", "--unique", "50", "--steps", "12", "--warmup", "2"]),
-    ("C1s_960x540", ["--workload", "C1s", "--steps", "14", "--warmup", "2"]),
+    ("C3_4k_n16_mask", ["--workload", "C3", "--steps", "13", "--warmup", "2"]),
+    ("C5_8k_high", ["--workload", "C5", "--unique", "50", "--steps", "13", "--warmup", "2"]),
+    ("C1s_960x540", ["--workload", "C1s", "--steps", "17", "--warmup", "2"]),
     ("per_frame_pinned", ["--protocol", "per-frame", "--frames", "pinned", "--steps", "12000"]),
     ("per_frame_recycled_ring", ["--protocol", "per-frame", "--frames", "recycled", "--steps", "12000"]),
     ("per_frame_pageable", ["--protocol", "per-frame", "--frames", "pageable", "--steps", "4000"]),
