@@ -8,9 +8,9 @@ batch of `--batch` consecutive frames of a seeded synthetic night-sky stream tha
 incl. Hough and NMS, results on the host.  A pass of the headline workload lasts 1.6 ms; SURVEY 8d asks for >= 2 s timed, so a
 step is sized (64 passes = 256 000 frames at 1080p, ~0.10 s) such that the driver's `--steps 20` times 2.1 s and the
 pipeline's one fill and one drain are < 1 % of the region.  config.frames_per_step / passes_per_step / frames_per_pass say so.
-N > 1: one process per GPU (torchrun), one independent stream per GPU (BASELINE config
-C4), no data-path collective; the collectives are the barrier around the timed region, the max-over-ranks time and the
-final gather of the detection counts.  `value` = frames all ranks processed / max-over-ranks time.
+N > 1: one process per GPU (the driver's launcher exports RANK / WORLD_SIZE / MASTER_*), one independent stream per GPU (BASELINE
+config C4), no data-path collective; the collectives are the barrier around the timed region (rendezvous store), the
+max-over-ranks time and the final gather of the detection counts (RCCL through ctypes: no torch in this script or the package).  `value` = frames all ranks processed / max-over-ranks time.
 
 The JSON line also carries (rank 0):
   roofline      the dominant pixel kernel (stack_threshold), priced PHYSICALLY: the bytes one launch must move (every frame
@@ -334,12 +334,12 @@ def parity_check_per_frame(frames, n, mask, local, count, kind):
         source = lambda k: view[k]
     elif kind == "recycled":
         ring = [np.empty((H, W), np.uint8) for _ in range(8)]
+        det._ctx.set_auto_register(True)  # the loader's opt-in (it owns a fixed ring and outlives the detector)
 
         def source(k):
             np.copyto(ring[k % 8], frames[k])
             return ring[k % 8]
     else:
-        det._ctx.set_auto_register(False)
         source = lambda k: frames[k].copy()
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
     orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY)
@@ -368,57 +368,52 @@ def parity_check_per_frame(frames, n, mask, local, count, kind):
 
 
 class Dist:
-    """The three collectives of the timed harness.  torch.distributed is the launcher's own rendezvous (the driver starts
-    the ranks with torch.distributed.run); "nccl" = RCCL on ROCm.  MDH_BENCH_BACKEND=gloo (CPU tensors) exercises the
-    multi-rank path on a box with fewer GPUs than ranks: the ranks then share devices round-robin."""
+    """The three collectives of the timed harness, without torch: `metdetpy_amd.dist.Group` = the rendezvous store for the
+    control plane (the launcher's RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; barrier, ncclUniqueId) + RCCL through ctypes for
+    the data (max-over-ranks time: ncclAllReduce(max); the final detection gather: ncclAllGather, on a private HIP stream).  RCCL
+    refuses two ranks on one device: on a box with fewer GPUs than ranks the ranks share devices round-robin and those few bytes
+    go through the store instead (`config.collectives` says which; MDH_DIST_BACKEND=store forces it)."""
 
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.d = None
-        self.tdev = None
-        # MDH_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL branch -- init, barrier,
-        # all-reduce, all-gather on device tensors -- on a one-GPU box; launch under torch.distributed.run or set MASTER_ADDR / PORT)
+        self.g = None
+        # MDH_BENCH_FORCE_DIST=1: join a job of ONE rank too (exercises the RCCL branch -- communicator, all-reduce, all-gather
+        # on device memory -- on a one-GPU box)
         if self.world > 1 or os.environ.get("MDH_BENCH_FORCE_DIST") == "1":
-            import torch
-            import torch.distributed as dist
-            backend = os.environ.get("MDH_BENCH_BACKEND", "nccl")
-            self.local = self.local % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(self.local)
-            if backend == "nccl":
-                self.tdev = torch.device("cuda", self.local)
-                dist.init_process_group("nccl", device_id=self.tdev)
-            else:
-                self.tdev = torch.device("cpu")
-                dist.init_process_group(backend)
-            self.d = dist
+            from metdetpy_amd import dist
+            self.g = dist.Group(self.rank, self.local, self.world)
+            self.local = self.g.device
             if os.environ.get("MDH_BENCH_VERBOSE_RANKS") == "1":  # tools/run_8gpu.sh: who sits where
-                print(f"[rank {self.rank}] of {self.world}: HIP device {self.local} of {torch.cuda.device_count()} visible "
-                      f"({torch.cuda.get_device_name(self.local)}), process group backend {backend}", file=sys.stderr, flush=True)
+                print(f"[rank {self.rank}] of {self.world}: {json.dumps(self.g.describe())}", file=sys.stderr, flush=True)
+
+    @property
+    def backend(self):
+        return self.g.backend if self.g is not None else None
 
     def fence(self):
-        # the library has no work in flight between run() calls; the barrier aligns the ranks
-        if self.d is not None:
-            import torch
-            torch.cuda.synchronize()
-            self.d.barrier()
-            torch.cuda.synchronize()
+        # the library has no work in flight between run() calls (every pass is collected); the barrier aligns the ranks
+        if self.g is not None:
+            self.g.barrier()
 
     def max_time_and_sum(self, dt, counts):
-        if self.d is None:
+        self.per_rank = [list(counts)]
+        if self.g is None:
             return dt, list(counts)
-        import torch
-        tmax = torch.tensor([dt], device=self.tdev, dtype=torch.float64)
-        self.d.all_reduce(tmax, op=self.d.ReduceOp.MAX)
-        c = torch.tensor(list(counts), device=self.tdev, dtype=torch.int64)
-        gathered = [torch.zeros_like(c) for _ in range(self.world)]
-        self.d.all_gather(gathered, c)  # the final detection gather (RCCL)
-        return float(tmax.item()), torch.stack(gathered).sum(0).tolist()
+        tmax = self.g.max_f64(dt)
+        self.per_rank = self.g.all_gather_i64(counts)  # the final detection gather (RCCL when every rank has its own GPU)
+        return tmax, [sum(col) for col in zip(*self.per_rank)]
+
+    def all_gather_object(self, obj):
+        return [obj] if self.g is None else self.g.all_gather_object(obj)
+
+    def gather_object(self, obj):
+        return [obj] if self.g is None else self.g.gather_object(obj, 0)
 
     def close(self):
-        if self.d is not None:
-            self.d.destroy_process_group()
+        if self.g is not None:
+            self.g.close()
 
 
 def make_stream_frames(wl, rank, mask, B, unique):
@@ -656,11 +651,11 @@ def run_per_frame(a, D, wl, mask):
       pinned    a pool of mdh_host_alloc (a loader built for this detector): every frame is read in place by the window kernel
       recycled  a ring of 8 ordinary NumPy buffers refilled in turn -- ProcessVideoLoader's shared RawArray ring
                 (videoloader.py:696-701, 746-772).  The refill (one host memcpy per frame, the loader's decode stand-in) happens
-                OUTSIDE the timed calls: only update() + detect() are timed, as for `pinned`.  The library registers each buffer the
-                third time it comes by and reads it in place from then on; no call to host_alloc
-      pageable  a fresh NumPy array per frame (ThreadVideoLoader, videoloader.py:569-618): 64 distinct arrays allocated up front and
-                never repeated within the library's memory of addresses... they ARE repeated every 64 frames, so auto-registration is
-                switched off for this leg: every frame takes the copy path (H2D from pageable memory), as a truly fresh array would
+                OUTSIDE the timed calls: only update() + detect() are timed, as for `pinned`.  The loader opts in to registration
+                (mdh_set_auto_register: off by default): the library registers each buffer the third time it comes by and reads it
+                in place from then on; no call to host_alloc
+      pageable  a fresh NumPy array per frame (ThreadVideoLoader, videoloader.py:569-618): the library's default, nothing is
+                registered, every frame takes the copy path (H2D from pageable memory)
     The per-frame time is also reported split into frames without / with raw Hough segments (a streak costs a serial replay)."""
     from metdetpy_amd import M3Detector
     H, W, n = wl["H"], wl["W"], wl["n"]
@@ -677,13 +672,13 @@ def run_per_frame(a, D, wl, mask):
         source = lambda k: frames[k % len(frames)]
     elif a.frames == "recycled":
         ring = [np.empty((H, W), np.uint8) for _ in range(8)]
+        det._ctx.set_auto_register(True)  # the loader's opt-in: it owns a fixed ring that outlives the detector
 
         def source(k):
             b = ring[k % len(ring)]
             np.copyto(b, host_frames[k % len(host_frames)])  # the loader refills the buffer (untimed: stands for its decode)
             return b
     else:
-        det._ctx.set_auto_register(False)
         fresh = [host_frames[i].copy() for i in range(min(64, len(host_frames)))]
         source = lambda k: fresh[k % len(fresh)]
     tally = [0, 0, 0]
@@ -860,6 +855,12 @@ def main():
                    "parallelism": f"{a.mode} x{D.world}" if a.mode != "streams" else f"streams x{D.world}"},
         "detections": {"raw_segments": r["tot"][0], "nms_segments": r["tot"][1], "lit_pixels": r["tot"][2]},
     }
+    if D.g is not None:
+        out["config"]["collectives"] = (f"{D.backend}: " + ("ncclAllReduce(max) + ncclAllGather on a private HIP stream (librccl through ctypes), "
+                                        "ncclUniqueId and barrier through the rendezvous store" if D.backend == "rccl" else
+                                        "ranks share devices (RCCL refuses two ranks per device): barrier, max and gather through the rendezvous store"))
+        if a.mode == "streams" and getattr(D, "per_rank", None):
+            out["detections"]["per_rank_raw_segments"] = [row[0] for row in D.per_rank]
     out.update(extra)
     if D.rank == 0:
         if r["prof"]:

@@ -57,12 +57,12 @@ def run_bands(a, D, wl, mask, cfg):
     uniq = len(frames)
     idx = np.arange(B) % uniq
     if D.world > 1:
-        det = BandedM3Detector(1, n, mask, 10, cfg, None, rank=D.rank, world=D.world, dist=D.d, device=D.local, max_batch=B)
+        det = BandedM3Detector(1, n, mask, 10, cfg, None, rank=D.rank, world=D.world, group=D.g, device=D.local, max_batch=B)
         plan, ctx = det.plan, det.engine.band
         if os.environ.get("MDH_BENCH_VERBOSE_RANKS") == "1":
             kp = -(-B // D.world)
             print(f"[rank {D.rank}] band rows {plan.bands[D.rank]['own0']}..{plan.bands[D.rank]['own1']} of {H}; "
-                  + (f"RCCL communicator {det.comm.describe()}; " if det.comm is not None else "no RCCL communicator (host buffers over the process group); ")
+                  + (f"RCCL communicator {det.comm.describe()}; " if det.comm is not None else "no RCCL communicator (ranks share a device: host buffers through the rendezvous store); ")
                   + f"per pass: all-reduce of 2 x {B // (2 * n) + 1} int64 noise sums (<= {16 * (B // (2 * n) + 1)} B), all-to-all of "
                     f"{kp * plan.band_rows * plan.WW * 8} B per peer ({kp} frames x {plan.band_rows} rows x {plan.WW} words), gather of the results to rank 0",
                   file=sys.stderr, flush=True)
@@ -194,10 +194,8 @@ def run_timeshard(a, D, wl, mask, cfg):
             mine.update(s.scan())
     t_scan = time.perf_counter() - t0
     if D.world > 1:
-        tables = [None] * D.world
-        D.d.all_gather_object(tables, mine)  # the threshold table: 16 bytes of sums per due frame
         table = {}
-        for part in tables:
+        for part in D.all_gather_object(mine):  # the threshold table: 16 bytes of sums per due frame
             table.update(part)
     else:
         table = mine
@@ -227,11 +225,7 @@ def run_timeshard(a, D, wl, mask, cfg):
         for _ in draining[0]:
             pass
         part.extend(("block",) + b for b in draining[1].blocks)
-    if D.world > 1:
-        gathered = [None] * D.world if D.rank == 0 else None
-        D.d.gather_object(part, gathered, dst=0)  # the final detection gather
-    else:
-        gathered = [part]
+    gathered = D.gather_object(part)  # the final detection gather (rank 0 gets the list, the others None)
     D.fence()
     dt = time.perf_counter() - t0
     dt_all, _ = D.max_time_and_sum(dt, [0, 0, 0])

@@ -52,8 +52,13 @@ extern "C" {
  * mdh_create / mdh_collector_create refuse (NULL, text in mdh_last_error) a struct whose size differs from the library's, so a
  * host compiled against an older header -- or a stale hand-written binding -- fails loudly instead of having fields read from
  * beyond its struct.  mdh_abi_version() is bumped whenever a struct or a prototype changes (2: struct_size fields, round 3;
- * 3: mdh_host_register / mdh_host_unregister / mdh_set_auto_register / mdh_update_stats, round 4). */
-#define MDH_ABI_VERSION 3
+ * 3: mdh_host_register / mdh_host_unregister / mdh_set_auto_register / mdh_update_stats, round 4 -- and, added later in round 4
+ *    without a bump: MDH_E_TIMEOUT, mdh_set_wait_timeout_ms, mdh_share_streams, mdh_band_thresholds_submit,
+ *    mdh_band_pixels_submit_to, mdh_device_reset, mdh_pre_traffic_model, mdh_set_device;
+ * 4: round 5 -- everything listed under 3 is guaranteed present; auto-registration is OFF by default (mdh_set_auto_register);
+ *    mdh_device_count / mdh_stream_create / mdh_stream_destroy / mdh_stream_sync / mdh_dev_malloc / mdh_dev_free / mdh_dev_copy
+ *    (context-free helpers for a host's own collectives); mdh_hough_planes_submit validates before it takes a slot). */
+#define MDH_ABI_VERSION 4
 int mdh_abi_version(void);
 /* The library runs a pass on up to ten HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
  * read once when the runtime initialises.  The library never modifies the process environment: export GPU_MAX_HW_QUEUES=12
@@ -61,6 +66,15 @@ int mdh_abi_version(void);
 int mdh_hw_queues_hint(void);
 /* hipSetDevice(device) for hosts without a HIP binding of their own (the RCCL communicator binds to the current device). */
 int mdh_set_device(int device);
+/* Context-free device helpers, for a host that enqueues collectives of its own (metdetpy_amd/dist.py: the final detection gather
+ * is an ncclAllGather on a private stream over a few bytes of device memory).  No mdh_ctx is involved. */
+int mdh_device_count(void);                                  /* HIP devices visible to this process (0 when there is none) */
+void* mdh_stream_create(int device);                         /* hipStream_t (non-blocking), NULL on failure */
+int mdh_stream_destroy(int device, void* stream);
+int mdh_stream_sync(int device, void* stream, double timeout_ms);   /* timeout_ms <= 0: for ever; else MDH_E_TIMEOUT when it expires */
+void* mdh_dev_malloc(int device, uint64_t bytes);
+int mdh_dev_free(int device, void* ptr);
+int mdh_dev_copy(int device, void* dst, const void* src, uint64_t bytes, int to_device, void* stream);  /* queued on stream, then waited for */
 /* hipDeviceReset(device): releases everything this process holds on the device (every mdh_ctx / mdh_pre on it must have been
  * destroyed first).  For a host that is done with the GPU but stays alive while other processes use it. */
 int mdh_device_reset(int device);
@@ -170,11 +184,13 @@ int mdh_host_free(mdh_ctx* ctx, void* ptr);   /* a pool may be freed through any
  * memory registered here.  The reference's loaders hand over plain NumPy arrays (MetDetPy.py:192; videoloader.py:569-593), and
  * ProcessVideoLoader recycles a fixed ring of them (a shared RawArray, videoloader.py:696-701, 746-772):
  *   mdh_host_register(ctx, ring_base, ring_bytes)   once, by a loader that knows its ring;  mdh_host_unregister before freeing it
- *   mdh_set_auto_register(ctx, 1)  (the default; MDH_AUTO_REGISTER=0 in the environment switches it off): the third time
- *       mdh_update is handed the same pageable address the library registers that frame buffer itself (at most 64 buffers per
- *       context, unregistered by mdh_destroy).  A caller that frees such a buffer while the context lives should call
- *       mdh_host_unregister on it first.
- * Frames at addresses seen for the first time are copied (H2D from pageable memory) as before; results are identical. */
+ *   mdh_set_auto_register(ctx, 1)  (OFF by default since ABI 4; MDH_AUTO_REGISTER=1 in the environment switches it on): the
+ *       third time mdh_update is handed the same pageable address the library registers that frame buffer itself (at most 64
+ *       buffers per context, unregistered by mdh_destroy).  Opt-in because it pins memory the CALLER owns: a caller that switches
+ *       it on promises to call mdh_host_unregister before it frees (or unmaps) such a buffer while the context lives -- a loader
+ *       that hands over a fresh array per frame gets the same malloc address back again and again and cannot keep that promise,
+ *       so it must not be enrolled behind its back (a stale registration reads freed pages).
+ * Frames in memory no kernel can reach are copied (H2D from pageable memory); results are identical. */
 int mdh_host_register(mdh_ctx* ctx, void* ptr, uint64_t bytes);
 int mdh_host_unregister(mdh_ctx* ctx, void* ptr);
 int mdh_set_auto_register(mdh_ctx* ctx, int on);

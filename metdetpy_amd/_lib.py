@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MDH_LIB") or os.path.join(_HERE, "libmetdet_hip.so") 
 MDH_MAX_LINES = 512
 MDH_MAX_WINDOW = 255
 MDH_NUM_KERNELS = 8
-MDH_ABI_VERSION = 3
+MDH_ABI_VERSION = 4
 MDH_HOUGH_EXACT, MDH_HOUGH_ACCUMULATOR = 0, 1
 MDH_DET_M3, MDH_DET_CLASSIC = 0, 1
 MDH_ROLE_FULL, MDH_ROLE_BAND, MDH_ROLE_HOUGH = 0, 1, 2
@@ -80,7 +80,8 @@ EXPORTS = [
     "mdh_stream_handle", "mdh_band_submit", "mdh_band_sums_device", "mdh_band_pixels_submit", "mdh_band_collect", "mdh_chain",
     "mdh_device_copy_on", "mdh_bands_allreduce_local", "mdh_hough_input_planes",
     "mdh_host_register", "mdh_host_unregister", "mdh_set_auto_register", "mdh_update_stats", "mdh_set_device",
-    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset", "mdh_share_streams", "mdh_band_thresholds_submit", "mdh_band_pixels_submit_to"
+    "mdh_set_wait_timeout_ms", "mdh_pre_traffic_model", "mdh_device_reset", "mdh_share_streams", "mdh_band_thresholds_submit", "mdh_band_pixels_submit_to",
+    "mdh_device_count", "mdh_stream_create", "mdh_stream_destroy", "mdh_stream_sync", "mdh_dev_malloc", "mdh_dev_free", "mdh_dev_copy",
 ]
 
 _lib = None
@@ -152,6 +153,15 @@ def load():
     L.mdh_host_free.argtypes = [vp, vp]
     L.mdh_share_streams.argtypes = [vp, vp]
     L.mdh_set_device.argtypes = [i32]
+    L.mdh_device_count.argtypes = []
+    L.mdh_stream_create.argtypes = [i32]
+    L.mdh_stream_create.restype = vp
+    L.mdh_stream_destroy.argtypes = [i32, vp]
+    L.mdh_stream_sync.argtypes = [i32, vp, dbl]
+    L.mdh_dev_malloc.argtypes = [i32, u64]
+    L.mdh_dev_malloc.restype = vp
+    L.mdh_dev_free.argtypes = [i32, vp]
+    L.mdh_dev_copy.argtypes = [i32, vp, vp, u64, i32, vp]
     L.mdh_device_reset.argtypes = [i32]
     L.mdh_set_wait_timeout_ms.argtypes = [vp, dbl]
     L.mdh_host_register.argtypes = [vp, vp, u64]

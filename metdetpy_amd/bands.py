@@ -14,10 +14,12 @@ artificial borders spoil at most the halo rows, which are thrown away.  What is 
     (Detector.py:342-344) are computed there from the assembled plane, so they need no collective of their own,
   * the results: gathered to rank 0, which owns the MeteorCollector.
 
-Collectives go through torch.distributed ("nccl" = RCCL over xGMI on the GPU box: the band kernels write straight
-into the send buffer in HBM and the Hough context reads the receive buffer in place; "gloo" with host buffers in the
-CPU tests).  torch is plumbing here: rendezvous, buffers for RCCL, collectives.  `LocalBands` runs all bands of a
-frame in one process on one GPU (same code path minus the collectives) for single-GPU parity tests.
+Collectives: RCCL over xGMI, enqueued through ctypes on the detector library's own streams (rccl.py) -- the band kernels
+write straight into the send buffer in HBM and the Hough context reads the receive buffer in place; nothing of torch is
+involved.  Ranks that have no communicator (several ranks sharing one device on a one-GPU box, or an engine substituted by
+the CPU tests) exchange host buffers through the `group` object instead (dist.Group over the rendezvous store; the tests also
+plug a gloo-backed group of their own in: tests/gloo_group.py).  `LocalBands` runs all bands of a frame in one process on one
+GPU (same code path minus the collectives) for single-GPU parity tests.
 """
 from __future__ import annotations
 
@@ -196,9 +198,11 @@ class LocalBands:
         if self.shared:
             self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device, with_hough=False) for b in range(p.nbands)]
             self.hough = self.engines[0].shared_hough_context(max_batch)
-            # MDH_BANDS_SHARE_STREAMS=1: the bands of one process queue their stages on band 0's streams (mdh_share_streams).  Off
-            # by default: measured slower on one MI355X (8 bands of an 8K stream: 30 k frames/s shared against 52 k with a set of
-            # streams per band at 4 hardware queues, 50 k / 47 k at 8 / 12 queues; profiles/EXPERIMENTS.md, round 4)
+            # MDH_BANDS_SHARE_STREAMS (default 1): the bands of one process queue their stages on band 0's streams
+            # (mdh_share_streams).  On by default since round 4: with every band's scalar chain queued before the first band's
+            # window kernel (mdh_band_thresholds_submit) 8 bands of an 8K stream run at 61-73 k frames/s shared against 51-59 k with
+            # a set of streams per band (sharing ALONE, without that reordering, had been slower: 30 k against 52 k;
+            # profiles/EXPERIMENTS.md, round 4).  0 = a set of streams per band, for A/B.
             if os.environ.get("MDH_BANDS_SHARE_STREAMS", "1") != "0":
                 for e in self.engines[1:]:
                     e.band.share_streams_of(self.engines[0].band)
@@ -392,33 +396,34 @@ class BandedM3Detector:
     `detect_batch(sub_frames)` takes this rank's rows of K consecutive frames (`plan.crop(frames, rank)`) and returns
     on rank 0 what `M3Detector.detect_batch` returns for the whole frames; other ranks get (None, info)."""
 
-    def __init__(self, window_sec, fps, mask, num_cls, cfg, logger=None, *, rank: int, world: int, dist=None, device: int = 0,
+    def __init__(self, window_sec, fps, mask, num_cls, cfg, logger=None, *, rank: int, world: int, group=None, device: int = 0,
                  max_batch: int = 64, engine=HipBandEngine, comm=None):
-        """comm: an `rccl.Communicator` of this rank (one rank per GPU).  With it -- or with an "nccl" process group, from which
-        one is made -- the data-path collectives are RCCL calls enqueued on the detector library's own streams and a pass is
-        queued without a host round trip; `dist` then only carries the unique id and the final gather of the results (control
-        plane).  Without it (gloo, the CPU tests) the blocking steps and host buffers of round 2 are used."""
+        """group: this rank's `dist.Group` (or anything with its rank / world / all_reduce_sum_i64 / all_to_all_u64 /
+        gather_object -- the CPU tests plug a gloo-backed one in).  comm: an `rccl.Communicator` of this rank (one rank per GPU).
+        With it -- or with a group that holds one, from whose control plane a second communicator is made for the library's
+        streams -- the data-path collectives are RCCL calls enqueued on the detector library's own streams and a pass is queued
+        without a host round trip; the group then only carries the unique id and the final gather of the results.  Without a
+        communicator (ranks sharing a device, substitute engines) the blocking steps and host buffers of round 2 are used."""
         self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, world)
-        self.rank, self.world, self.dist = int(rank), int(world), dist
-        if world > 1 and dist is None:
-            raise ValueError("world > 1 needs an initialised torch.distributed module (metdetpy_amd.dist.init_from_env)")
+        self.rank, self.world, self.group = int(rank), int(world), group
+        if world > 1 and group is None:
+            raise ValueError("world > 1 needs a group (metdetpy_amd.dist.init_from_env)")
         self.plan = self.s.plan
         self.engine = engine(self.plan, self.rank, self.s.n, cfg, self.s.mask_area, max_batch, device)
         self.max_batch = int(max_batch)
-        self._on_gpu = dist is not None and dist.get_backend() == "nccl"
         self.comm = comm
-        if self.comm is None and self._on_gpu and engine is HipBandEngine:
+        self._own_comm = False
+        t = float(os.environ.get("MDH_RCCL_TIMEOUT", "120"))
+        if self.comm is None and engine is HipBandEngine and getattr(group, "comm", None) is not None:
             from . import rccl
             # (MDH_RCCL_TIMEOUT seconds, default 120: a rank whose peers never arrive raises instead of hanging in ncclCommInitRank)
-            self.comm = rccl.Communicator.from_torch_dist(dist, self.rank, self.world, device=device,
-                                                          timeout_s=float(os.environ.get("MDH_RCCL_TIMEOUT", "120")))
+            self.comm = rccl.Communicator.from_group(group.cp, device=device, timeout_s=t)
+            self._own_comm = True
         if self.comm is not None and engine is HipBandEngine:
             # a pass that waits on a dead peer's send must not hang collect(): the library gives up after the same time,
             # collect() then aborts the communicator (which releases the stuck kernels) and raises
-            t = float(os.environ.get("MDH_RCCL_TIMEOUT", "120"))
             self.engine.band.set_wait_timeout(t)
             self.engine.hough.set_wait_timeout(t)
-        self._send = self._recv = None
         self._xbuf = None
         self._pending, self._seq = [], 0
 
@@ -449,36 +454,10 @@ class BandedM3Detector:
         self._pending.append((K, kp, mine, None, None, None))
         self._seq += 1
 
-    # ---- collectives ---------------------------------------------------------------------------
-    def _allreduce_sums(self, sums: np.ndarray) -> np.ndarray:
-        if self.dist is None or len(sums) == 0:
-            return sums
-        import torch
-        t = torch.from_numpy(sums.copy())
-        if self._on_gpu:
-            t = t.cuda()
-        self.dist.all_reduce(t)  # SUM; int64, exact
-        return t.cpu().numpy()
-
-    def _exchange_buffers(self, kp, which):
-        """Send / receive buffers of the all-to-all, (world, kp_max, band_rows, WW) int64 (bit patterns of u64); two receive
-        buffers used alternately, so that the pass queued behind a pass whose Hough stage is still reading has its own."""
-        import torch
-        p = self.plan
-        if self._send is None:
-            shape = (self.world, -(-self.max_batch // self.world), p.band_rows, p.WW)
-            dev = torch.device("cuda", torch.cuda.current_device()) if self._on_gpu else torch.device("cpu")
-            self._send = torch.zeros(shape, dtype=torch.int64, device=dev)
-            self._recv = [torch.zeros(shape, dtype=torch.int64, device=dev) for _ in range(2)]
-        recv = self._recv[which]
-        return self._send[:, :kp].contiguous() if kp != self._send.shape[1] else self._send, \
-            recv[:, :kp].contiguous() if kp != recv.shape[1] else recv
-
     def submit(self, sub_frames, K=None, on_device=False):
         """Queue a pass: noise sums -> all-reduce -> pixel stages -> all-to-all of the bit planes -> this rank's share of the
         Hough stage, which is only QUEUED (mdh_hough_planes_submit): it runs under the band stages of the next pass.  At most two
         passes may be queued; collect() returns the oldest one's results."""
-        import torch
         p, N, r = self.plan, self.world, self.rank
         K = len(sub_frames) if not on_device else int(K)
         if K > self.max_batch:
@@ -487,33 +466,21 @@ class BandedM3Detector:
             raise RuntimeError("two passes are already queued: collect() one first")
         if self.comm is not None:
             return self._submit_queued(sub_frames, K, on_device)
+        # no communicator: blocking steps, host buffers through the group (ranks sharing a device; substitute engines)
         kp = -(-K // N)
         part = self.engine.noise(sub_frames, K=K, on_device=True) if on_device else self.engine.noise(sub_frames)
-        total = self._allreduce_sums(part)
-        keep = None
-        if self.dist is None:
-            sent, thr_info = self.engine.pixels(total)
-            recv, on_dev = sent, False  # world == 1: the send layout of one band IS the receive layout
-        elif self._on_gpu:
-            send, recv_t = self._exchange_buffers(kp, self._seq % 2)
-            _, thr_info = self.engine.pixels(total, out=send.data_ptr())  # kernels write the send buffer in HBM
-            self.dist.all_to_all_single(recv_t, send)                     # RCCL over xGMI
-            torch.cuda.current_stream().synchronize()
-            recv, on_dev, keep = recv_t.data_ptr(), True, recv_t
-        else:
-            sent, thr_info = self.engine.pixels(total)
-            send = torch.from_numpy(sent.view(np.int64))
-            recv_t = torch.empty_like(send)
-            self.dist.all_to_all_single(recv_t, send)
-            recv, on_dev = recv_t.numpy().view(np.uint64), False
+        total = part if self.group is None or len(part) == 0 else self.group.all_reduce_sum_i64(part)  # SUM; int64, exact
+        sent, thr_info = self.engine.pixels(total)
+        # world == 1: the send layout of one band IS the receive layout
+        recv = sent if self.group is None else self.group.all_to_all_u64(sent)
         mine = len(range(r, K, N))
         done = None
         if mine:
             if hasattr(self.engine, "hough_submit"):
-                self.engine.hough_submit(recv, kp, on_device=on_dev)
+                self.engine.hough_submit(recv, kp, on_device=False)
             else:  # a substitute engine (CPU tests of the exchange logic) runs its Hough stage at once
-                done = self.engine.hough_stage(recv, kp, on_device=on_dev)
-        self._pending.append((K, kp, mine, thr_info, done, keep))
+                done = self.engine.hough_stage(recv, kp, on_device=False)
+        self._pending.append((K, kp, mine, thr_info, done, None))
         self._seq += 1
 
     def collect(self):
@@ -536,11 +503,7 @@ class BandedM3Detector:
             for j in range(mine):
                 part.append((j * N + r, hi[j].copy(), raw[j, :min(int(hi[j]["n_raw"]), _lib.MDH_MAX_LINES)].copy(),
                              nms[j, :int(hi[j]["n_nms"])].copy(), prob[j, :int(hi[j]["n_nms"])].copy()))
-        if self.dist is None:
-            gathered = [part]
-        else:
-            gathered = [None] * N if r == 0 else None
-            self.dist.gather_object(part, gathered, dst=0)  # the final detection gather
+        gathered = [part] if self.group is None else self.group.gather_object(part, 0)  # the final detection gather
         if r != 0:
             return None, thr_info
         info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
@@ -561,7 +524,7 @@ class BandedM3Detector:
             for ptr in [q for pair in self._xbuf for q in pair]:
                 self.engine.band.device_free(ptr)
             self._xbuf = None
-        if self.comm is not None:
+        if self.comm is not None and self._own_comm:
             self.comm.close()
-            self.comm = None
+        self.comm = None
         self.engine.close()

@@ -20,6 +20,7 @@
 #include "../../include/metdet_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -232,8 +233,9 @@ struct mdh_ctx {
     // buffers in pageable memory seen lately (address, hand-overs): a repeated address is a recycled buffer and gets registered
     struct { uintptr_t addr; int hits; } reg_seen[AUTO_REG_SEEN] = {};
     int reg_seen_next = 0;
-    int auto_registered = 0;               // buffers this context registered itself (unregistered by mdh_destroy)
-    bool auto_register_on = true;          // MDH_AUTO_REGISTER=0 / mdh_set_auto_register(ctx, 0)
+    std::atomic<int> auto_registered{0};   // buffers this context registered itself (unregistered by mdh_destroy; another context's
+                                           //   mdh_host_unregister may count one down: atomic)
+    bool auto_register_on = false;         // opt-in: MDH_AUTO_REGISTER=1 / mdh_set_auto_register(ctx, 1) (the caller then owes mdh_host_unregister before a free)
     int64_t direct_frames = 0, copied_frames = 0;  // mdh_update: frames read in place by the window kernel / copied first
     int64_t mail_hits = 0, mail_misses = 0;  // frames that found the waiting kernel alive / launches cancelled or expired
     double t_detect_ret = 0;               // host time mdh_detect last returned at; the gap to the next mdh_update decides whether the
@@ -258,6 +260,7 @@ struct mdh_ctx {
     bool poisoned = false;
     double wait_timeout_ms = 0;  // mdh_set_wait_timeout_ms: how long a collect waits for its pass (0 = for ever)
     bool planes_begun = false;      // MDH_ROLE_HOUGH: the next slot's counters are zeroed and being filled by mdh_band_pixels_submit_to
+    int planes_K = 0;               //   ... with this many frames per band (every band of the pass, and the submit, must agree)
     hipEvent_t ev_begin = nullptr;  //   ... that zeroing, for the bands' post streams to wait on
     bool band_thr_done = false;     // mdh_band_thresholds_submit ran for the pass staged by mdh_band_submit
     bool streams_borrowed = false;  // mdh_share_streams: the main / noise / post / copy streams belong to another context
@@ -301,6 +304,71 @@ extern "C" int mdh_hw_queues_hint(void) {
 // hipSetDevice for host code that has no HIP binding of its own (metdetpy_amd/rccl.py selects the device before ncclCommInitRank)
 extern "C" int mdh_set_device(int device) {
     HIPCHK(hipSetDevice(device));
+    return MDH_OK;
+}
+// Context-free device helpers for a host's own collectives (metdetpy_amd/dist.py: the final detection gather is an ncclAllGather on a
+// stream of the host's, staged through a few bytes of device memory -- no mdh_ctx involved, no torch tensor either).
+extern "C" int mdh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+extern "C" void* mdh_stream_create(int device) {
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        set_err("mdh_stream_create: hipStreamCreateWithFlags failed");
+        return nullptr;
+    }
+    return (void*)s;
+}
+extern "C" int mdh_stream_destroy(int device, void* stream) {
+    if (!stream) return MDH_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return MDH_OK;
+}
+// waits for everything queued on `stream`; timeout_ms > 0: gives up with MDH_E_TIMEOUT (a collective whose peer never arrived)
+extern "C" int mdh_stream_sync(int device, void* stream, double timeout_ms) {
+    HIPCHK(hipSetDevice(device));
+    if (timeout_ms <= 0) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        return MDH_OK;
+    }
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) return MDH_OK;
+        if (e != hipErrorNotReady) { set_err(std::string("mdh_stream_sync: ") + hipGetErrorString(e)); return MDH_E_HIP; }
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > timeout_ms) {
+            set_err("mdh_stream_sync: the stream's work did not complete in time");
+            return MDH_E_TIMEOUT;
+        }
+        timespec nap = {0, 50000};
+        nanosleep(&nap, nullptr);
+    }
+}
+extern "C" void* mdh_dev_malloc(int device, uint64_t bytes) {
+    void* p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+        set_err("mdh_dev_malloc: hipMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+extern "C" int mdh_dev_free(int device, void* p) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(p));
+    return MDH_OK;
+}
+// to_device = 1: host -> device, 0: device -> host; queued on `stream` and waited for (small control buffers)
+extern "C" int mdh_dev_copy(int device, void* dst, const void* src, uint64_t bytes, int to_device, void* stream) {
+    if (!dst || !src) return MDH_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return MDH_OK;
 }
 extern "C" const char* mdh_kernel_name(int k) { return (k >= 0 && k < MDH_NUM_KERNELS) ? kKernelNames[k] : ""; }
@@ -2153,6 +2221,7 @@ extern "C" int mdh_band_pixels_submit_to(mdh_ctx* c, const int64_t* d_sums_total
     if (hough->in_flight >= hough->nslot) { set_err("mdh_band_pixels_submit_to: the Hough context has no free pass slot"); return MDH_E_STATE; }
     if (full_row0 < 0 || own_rows < 1 || full_row0 + own_rows > hough->H) { set_err("mdh_band_pixels_submit_to: rows outside the whole frame"); return MDH_E_ARG; }
     if (c->band_slot && c->band_slot->K > hough->Kmax) { set_err("mdh_band_pixels_submit_to: the pass is larger than the Hough context's max_batch"); return MDH_E_ARG; }
+    if (c->band_slot && hough->planes_begun && c->band_slot->K != hough->planes_K) { set_err("mdh_band_pixels_submit_to: the bands of one pass must export the same number of frames"); return MDH_E_ARG; }
     CHECK_POISON(hough, "mdh_band_pixels_submit_to");
     return band_pixels_submit_impl(c, d_sums_total, roi_px_total, own_row0, own_rows, hough->H, 1,
                                    (uint64_t*)hough->slot[hough->next_slot].d_dst, MDH_EXPORT_NOFILL, hough, full_row0);
@@ -2195,6 +2264,7 @@ static int band_pixels_submit_impl(mdh_ctx* c, const int64_t* d_sums_total, doub
             HIPCHK(hipMemsetAsync(hs_sl.d_rowcount, 0, sizeof(int) * ((size_t)hough->Kmax * hough->H + 5 * (size_t)hough->Kmax), hpost));
             HIPCHK(hipEventRecord(hough->ev_begin, hpost));
             hough->planes_begun = true;
+            hough->planes_K = K;
         }
         HIPCHK(hipStreamWaitEvent(post, hough->ev_begin, 0));
         hipLaunchKernelGGL(k_export_rows_count, dim3((own_rows * c->WW + 255) / 256, K), dim3(256), 0, post, sl.d_dst, (u64*)hs_sl.d_dst, c->H,
@@ -2459,6 +2529,21 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
         return MDH_E_ARG;
     }
     CHECK_POISON(c, "mdh_hough_planes_submit");
+    if (K < 1 || K > c->Kmax) { set_err(std::string(who) + ": pass size must be 1..max_batch"); return MDH_E_ARG; }
+    if (c->in_flight >= c->nslot) { set_err(std::string(who) + ": the maximum number of passes is already in flight: collect one first"); return MDH_E_STATE; }
+    // Every argument / state check comes BEFORE the slot is taken and before the "bands already counted into this slot" state is
+    // consumed: an error return leaves the context exactly as it was (the caller may correct the call and repeat it).
+    const bool counted = c->planes_begun;  // mdh_band_pixels_submit_to: the bands have filled the planes AND the counters of this slot
+    const void* own_planes = (const void*)c->slot[c->next_slot].d_dst;  // (the slot slot_begin hands out next)
+    // pieces == the slot's own plane buffer (mdh_hough_input_planes: the bands exported straight into it, one "band" of H rows):
+    // nothing to copy, only the row / frame lit counts and the bounding boxes are taken
+    const int inplace = (on_device && (const void*)pieces == own_planes && nbands == 1 && band_rows == c->H) ? 1 : 0;
+    if (on_device && (const void*)pieces == own_planes && !inplace) { set_err(std::string(who) + ": the context's own plane buffer wants nbands = 1, band_rows = H"); return MDH_E_ARG; }
+    if (counted && !inplace) { set_err(std::string(who) + ": bands exported into this pass with mdh_band_pixels_submit_to: submit the context's own planes"); return MDH_E_STATE; }
+    if (counted && K != c->planes_K) {
+        set_err(std::string(who) + ": the bands exported " + std::to_string(c->planes_K) + " frames into this pass, " + std::to_string(K) + " submitted");
+        return MDH_E_ARG;
+    }
     HIPCHK(hipSetDevice(c->device));
     Slot* slp = nullptr;
     int rc;
@@ -2472,14 +2557,8 @@ static int hough_planes_submit(mdh_ctx* c, const uint64_t* pieces, int K, int on
         HIPCHK(hipMemcpyAsync(c->d_xchg, pieces, in_words * sizeof(u64), hipMemcpyHostToDevice, post));
         src = c->d_xchg;
     }
-    const bool counted = c->planes_begun;  // mdh_band_pixels_submit_to: the bands have filled the planes AND the counters of this slot
     c->planes_begun = false;
     if (!counted) HIPCHK(hipMemsetAsync(sl.d_rowcount, 0, sizeof(int) * ((size_t)c->Kmax * c->H + 5 * (size_t)c->Kmax), post));
-    // pieces == the slot's own plane buffer (mdh_hough_input_planes: the bands exported straight into it, one "band" of H rows):
-    // nothing to copy, only the row / frame lit counts and the bounding boxes are taken
-    const int inplace = (on_device && (const void*)src == (const void*)sl.d_dst && nbands == 1 && band_rows == c->H) ? 1 : 0;
-    if ((const void*)src == (const void*)sl.d_dst && !inplace) { set_err(std::string(who) + ": the context's own plane buffer wants nbands = 1, band_rows = H"); return MDH_E_ARG; }
-    if (counted && !inplace) { set_err(std::string(who) + ": bands exported into this pass with mdh_band_pixels_submit_to: submit the context's own planes"); return MDH_E_STATE; }
     if (!counted)
     hipLaunchKernelGGL(k_assemble_planes, dim3((unsigned)((c->words + 255) / 256), K), dim3(256), 0, post, src, sl.d_dst, sl.d_rowcount,
                        sl.d_litcount, sl.d_bbox, K, c->H, c->W, c->WW, band_rows, inplace);

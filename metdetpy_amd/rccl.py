@@ -2,9 +2,9 @@
 (`Context.stream_handle`), so that a pass is queued without a host round trip -- no torch tensor, no `torch.cuda` stream, no
 synchronisation between the band kernels, the exchange and the Hough stage (include/metdet_hip.h, "WITHOUT host round trips").
 
-Only what the band path needs: a communicator (the 128-byte unique id travels through whatever control plane the launcher has:
-`torch.distributed.broadcast_object_list` under torchrun), an in-place all-reduce of int64 sums, and an equal-split all-to-all of
-u64 bit-plane pieces as one group of ncclSend / ncclRecv.  xGMI is point to point: the all-to-all is exactly one send and one
+Only what the sharded modes need: a communicator (the 128-byte unique id travels through the control plane of rendezvous.py: a
+key/value store rank 0 serves), an in-place all-reduce of int64 sums, an equal-split all-to-all of u64 bit-plane pieces as one
+group of ncclSend / ncclRecv, and an all-gather of bytes for the final detection gather.  xGMI is point to point: the all-to-all is exactly one send and one
 receive per peer, `piece` words each (8 GPUs, 8K, 256 frames per pass: 32 frames x 540 rows x 120 words x 8 B = 16.6 MB per peer).
 
 RCCL refuses two ranks on one device, so on a one-GPU box this module can only be exercised with a communicator of ONE rank (the
@@ -17,19 +17,12 @@ import ctypes as C
 import os
 
 NCCL_UNIQUE_ID_BYTES = 128
-ncclSum, ncclInt64, ncclUint64 = 0, 4, 5
+ncclSum, ncclMax = 0, 2
+ncclInt8, ncclUint8, ncclInt64, ncclUint64, ncclFloat64 = 0, 1, 4, 5, 8
 
 
 class UniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
-
-
-class Config(C.Structure):
-    """ncclConfig_t (nccl.h, 2.27): size / magic / version header, then the fields; NCCL_CONFIG_INITIALIZER's values."""
-    _fields_ = [("size", C.c_size_t), ("magic", C.c_uint), ("version", C.c_uint), ("blocking", C.c_int), ("cgaClusterSize", C.c_int),
-                ("minCTAs", C.c_int), ("maxCTAs", C.c_int), ("netName", C.c_char_p), ("splitShare", C.c_int), ("trafficClass", C.c_int),
-                ("commName", C.c_char_p), ("collnetEnable", C.c_int), ("CTAPolicy", C.c_int), ("shrinkShare", C.c_int),
-                ("nvlsCTAs", C.c_int), ("pad", C.c_int * 8)]
 
 
 class RcclError(RuntimeError):
@@ -66,7 +59,7 @@ def load():
     L.ncclCommCuDevice.argtypes = [vp, C.POINTER(i32)]
     L.ncclCommGetAsyncError.argtypes = [vp, C.POINTER(i32)]
     L.ncclCommAbort.argtypes = [vp]
-    L.ncclCommInitRankConfig.argtypes = [C.POINTER(vp), i32, UniqueId, i32, C.POINTER(Config)]
+    L.ncclAllGather.argtypes = [vp, vp, sz, i32, vp, vp]
     _lib = L
     return L
 
@@ -86,43 +79,52 @@ class Communicator:
     """One rank of an RCCL communicator on HIP device `device` (selected here, before ncclCommInitRank binds to "the current
     device": the caller may sit on another thread or another torch.cuda device than the detector context).
 
-    `timeout_s`: ncclCommInitRank blocks until every rank has arrived; with a timeout the communicator is created in RCCL's
-    non-blocking mode and polled, and a rank whose peers never turn up aborts with RcclTimeout instead of hanging.  After
-    creation the communicator's own size / rank / device are checked against what the launcher said."""
+    `timeout_s`: ncclCommInitRank blocks until every rank has arrived.  The communicator stays a BLOCKING one (every later
+    ncclAllReduce / ncclSend / ncclRecv / ncclGroupEnd returns ncclSuccess or a real error, never ncclInProgress: round 4 created
+    it with blocking = 0 to be able to poll, and every data-path call on such a communicator may then return ncclInProgress);
+    the bound on the wait comes from running the init call on a helper thread and joining it with a timeout -- a rank whose
+    peers never turn up raises RcclTimeout instead of hanging (the helper thread stays parked in RCCL; the process is expected to
+    exit).  After creation the communicator's own size / rank / device are checked against what the launcher said."""
 
     def __init__(self, rank: int, world: int, unique_id: bytes, device: int | None = None, timeout_s: float | None = None):
         if len(unique_id) != NCCL_UNIQUE_ID_BYTES:
             raise ValueError("unique_id must be the 128 bytes of ncclGetUniqueId")
         self.L = load()
         self.rank, self.world, self.device = int(rank), int(world), device
-        if device is not None:
-            from . import _lib
-            _lib.set_device(int(device))
         uid = UniqueId()
         C.memmove(C.addressof(uid), unique_id, NCCL_UNIQUE_ID_BYTES)
         self.comm = C.c_void_p()
+
+        def init():
+            if device is not None:  # (the HIP device is per thread: selected on the thread that calls ncclCommInitRank)
+                from . import _lib
+                _lib.set_device(int(device))
+            return self.L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+
         if timeout_s is None:
-            _check(self.L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+            _check(init(), "ncclCommInitRank")
         else:
-            import time
-            INT_MIN = -2147483648
-            cfg = Config(C.sizeof(Config) - 8 * C.sizeof(C.c_int), 0xcafebeef, 22707, 0, INT_MIN, INT_MIN, INT_MIN, None, INT_MIN, INT_MIN, None,
-                         INT_MIN, INT_MIN, INT_MIN, INT_MIN)
-            rc = self.L.ncclCommInitRankConfig(C.byref(self.comm), self.world, uid, self.rank, C.byref(cfg))
-            if rc not in (0, 7):  # ncclSuccess, ncclInProgress
-                _check(rc, "ncclCommInitRankConfig")
-            t0, state = time.monotonic(), C.c_int(7)
-            while True:
-                _check(self.L.ncclCommGetAsyncError(self.comm, C.byref(state)), "ncclCommGetAsyncError")
-                if state.value == 0:
-                    break
-                if state.value != 7:
-                    self.abort()
-                    _check(state.value, "ncclCommInitRankConfig (async)")
-                if time.monotonic() - t0 > timeout_s:
-                    self.abort()
-                    raise RcclTimeout(f"rank {rank}: the communicator of {world} ranks did not form within {timeout_s} s (a peer is missing)")
-                time.sleep(0.01)
+            import threading
+            box = {}
+
+            def run():
+                try:
+                    box["rc"] = init()
+                except BaseException as e:  # noqa: BLE001
+                    box["exc"] = e
+
+            th = threading.Thread(target=run, name="mdh-rccl-init", daemon=True)
+            th.start()
+            th.join(float(timeout_s))
+            if th.is_alive():
+                self.comm = C.c_void_p()  # (still being written by the parked thread: never handed to RCCL again)
+                raise RcclTimeout(f"rank {rank}: the communicator of {world} ranks did not form within {timeout_s} s (a peer is missing)")
+            if "exc" in box:
+                raise box["exc"]
+            _check(box["rc"], "ncclCommInitRank")
+        if device is not None:
+            from . import _lib
+            _lib.set_device(int(device))
         n, r = C.c_int(-1), C.c_int(-1)
         _check(self.L.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
         _check(self.L.ncclCommUserRank(self.comm, C.byref(r)), "ncclCommUserRank")
@@ -153,12 +155,11 @@ class Communicator:
             self.comm = C.c_void_p()
 
     @classmethod
-    def from_torch_dist(cls, dist, rank: int, world: int, device: int | None = None, timeout_s: float | None = None):
-        """The id is made on rank 0 and broadcast through the process group the launcher set up (control plane only)."""
-        box = [new_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=0)
-        return cls(rank, world, box[0], device=device, timeout_s=timeout_s)
+    def from_group(cls, group, device: int | None = None, timeout_s: float | None = None):
+        """The id is made on rank 0 and broadcast through the control plane (`rendezvous.Group`, or anything with its
+        rank / world / broadcast_bytes)."""
+        uid = group.broadcast_bytes(new_unique_id() if group.rank == 0 else None, 0)
+        return cls(group.rank, group.world, uid, device=device, timeout_s=timeout_s)
 
     def all_reduce_sum_i64(self, ptr: int, count: int, stream: int):
         """In place, on `stream` (a hipStream_t as an integer)."""
@@ -177,6 +178,13 @@ class Communicator:
             self.L.ncclGroupEnd()  # (close the group, but the send / receive error is the one to report)
             raise
         _check(self.L.ncclGroupEnd(), "ncclGroupEnd")
+
+    def all_gather_bytes(self, send: int, recv: int, nbytes: int, stream: int):
+        """`nbytes` from every rank, rank order, into `recv` (world * nbytes); device pointers, on `stream`."""
+        _check(self.L.ncclAllGather(send, recv, nbytes, ncclUint8, self.comm, stream), "ncclAllGather")
+
+    def all_reduce_max_f64(self, ptr: int, count: int, stream: int):
+        _check(self.L.ncclAllReduce(ptr, ptr, count, ncclFloat64, ncclMax, self.comm, stream), "ncclAllReduce")
 
     def close(self):
         if self.comm:

@@ -357,30 +357,24 @@ def unpack_block(block, num_cls):
     return out
 
 
-def run_time_sharded(window_sec, fps, mask, num_cls, cfg, total_frames, read, *, dist=None, rank=0, world=1, device=0,
+def run_time_sharded(window_sec, fps, mask, num_cls, cfg, total_frames, read, *, group=None, rank=0, world=1, device=0,
                      max_batch=64, engine=HipBandEngine):
     """All of it for one rank: scan, all-gather of the sums table, finish, gather of the results to rank 0.
-    Returns (results, info) on rank 0 -- results[i] = (lines, cls_pred) as M3Detector.detect gives them -- else None."""
-    if world > 1 and dist is None:
-        raise ValueError("world > 1 needs an initialised torch.distributed module")
+    Returns (results, info) on rank 0 -- results[i] = (lines, cls_pred) as M3Detector.detect gives them -- else None.
+    group: `dist.Group` (RCCL all-gather when every rank has its own device, the rendezvous store otherwise) or anything with
+    its all_gather_object / gather_object."""
+    if world > 1 and group is None:
+        raise ValueError("world > 1 needs a group (metdetpy_amd.dist.init_from_env)")
     shard = TimeShard(window_sec, fps, mask, num_cls, cfg, total_frames, read, rank=rank, world=world, device=device,
                       max_batch=max_batch, engine=engine)
     mine = shard.scan()
-    if dist is None:
-        tables = [mine]
-    else:
-        tables = [None] * world
-        dist.all_gather_object(tables, mine)  # the threshold table: 16 bytes of sums per due frame
+    tables = [mine] if group is None else group.all_gather_object(mine)  # the threshold table: 16 bytes of sums per due frame
     table = {}
     for part in tables:
         table.update(part)
     part = shard.finish(table)
     shard.close()
-    if dist is None:
-        gathered = [part]
-    else:
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(part, gathered, dst=0)  # the final detection gather
+    gathered = [part] if group is None else group.gather_object(part, 0)  # the final detection gather
     if rank != 0:
         return None
     info = np.zeros(total_frames, _lib.FRAME_INFO_DTYPE)

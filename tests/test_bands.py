@@ -1,7 +1,8 @@
 """Row-band tiling of one stream (metdetpy_amd/bands.py; SURVEY 8e "spatial row-bands", BASELINE config 5).
 
-CPU part: the tiling logic with an engine made of the oracle's functions, in-process (LocalBands) and across two real
-processes with gloo collectives (BandedM3Detector), against the whole-frame oracle -- bit-exact.
+CPU part: the tiling logic with an engine made of the oracle's functions, in-process (LocalBands) and across two and eight real
+processes (BandedM3Detector; collectives over the product's rendezvous store and over gloo), against the whole-frame oracle --
+bit-exact.
 GPU part (-m gpu): the HIP band / Hough contexts through the C-ABI, against the whole-frame HIP detector and the oracle."""
 import json
 import os
@@ -17,6 +18,7 @@ from oracle import c_oracle as co
 from oracle import m3_oracle as mo
 from tests.band_oracle_engine import OracleBandEngine, pack_rows, unpack_rows
 from tests.helpers import binary_cfg, busy_frames, oracle_kwargs
+from tests.mp import run_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -89,21 +91,22 @@ def test_local_bands_equal_whole_frame_oracle(kind, H, W, n, nbands, K):
         check_against(res, info, want, p0)
 
 
-GLOO_BAND_WORKER = r"""
+BAND_WORKER = r"""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, sys.argv[1])
-from metdetpy_amd import dist as md
 from metdetpy_amd.bands import BandedM3Detector
 from tests.band_oracle_engine import OracleBandEngine
+from tests.gloo_group import make_group
 from tests.test_bands import make_case
-use_hip = sys.argv[2] == "hip"
-rank, local, world, dist = md.init_from_env("gloo")
-H, W, n, K = (135, 192, 6, 9) if not use_hip else (270, 448, 8, 16)
+use_hip, kind = sys.argv[2] == "hip", sys.argv[3]
+H, W, n, K = [int(v) for v in sys.argv[4:8]]
+group = make_group(kind)
+rank, world = group.rank, group.world
 mask = np.ones((H, W), np.uint8)
 frames, cfg = make_case("sky", H, W, n, 3 * K, 77)
 kw = {} if use_hip else dict(engine=OracleBandEngine)
-det = BandedM3Detector(n / 10, 10, mask, 10, cfg, None, rank=rank, world=world, dist=dist, device=0, max_batch=K, **kw)
+det = BandedM3Detector(n / 10, 10, mask, 10, cfg, None, rank=rank, world=world, group=group, device=0, max_batch=K, **kw)
 out = []
 for p0 in range(0, len(frames), K):
     res, info = det.detect_batch(det.plan.crop(frames[p0:p0 + K], rank))
@@ -116,25 +119,12 @@ for p0 in range(0, len(frames), K):
 det.close()
 if rank == 0:
     print(json.dumps(out))
-dist.barrier()
-dist.destroy_process_group()
+group.close()
 """
 
 
-def run_two_ranks(tmp_path, mode):
-    script = tmp_path / "band_worker.py"
-    script.write_text(GLOO_BAND_WORKER)
-    port = 31000 + (os.getpid() % 2000)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.PIPE))
-    outs = [p.communicate(timeout=600) for p in procs]
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e.decode()[-3000:]
-    return json.loads(outs[0][0].decode().strip().splitlines()[-1])
+def run_band_ranks(tmp_path, mode, kind, world, H, W, n, K):
+    return run_ranks(tmp_path, "band_worker", BAND_WORKER, world, args=(mode, kind, H, W, n, K))
 
 
 def compare_worker_output(got, H, W, n, K):
@@ -148,9 +138,23 @@ def compare_worker_output(got, H, W, n, K):
         assert np.array_equal(np.array(g["pred"]).reshape(-1, 10), w["pred"]), i
 
 
-def test_two_process_gloo_bands_equal_whole_frame_oracle(tmp_path):
-    """world_size 2 over gloo: all-reduce of the noise sums, all-to-all of the bit planes, gather of the results."""
-    compare_worker_output(run_two_ranks(tmp_path, "oracle"), 135, 192, 6, 9)
+@pytest.mark.parametrize("kind", ["store", "gloo"])
+def test_two_process_bands_equal_whole_frame_oracle(tmp_path, kind):
+    """world_size 2: all-reduce of the noise sums, all-to-all of the bit planes, gather of the results -- over the product's own
+    group (rendezvous store) and over torch's gloo backend (tests/gloo_group.py)."""
+    compare_worker_output(run_band_ranks(tmp_path, "oracle", kind, 2, 135, 192, 6, 9), 135, 192, 6, 9)
+
+
+@pytest.mark.parametrize("kind", ["store", "gloo"])
+def test_eight_process_bands_of_an_8k_shaped_plan(tmp_path, kind):
+    """world_size 8, the structure BASELINE config 5 runs with (7680x4320 over 8 GPUs: 540-row bands + 4-row halos, frames r, r + 8,
+    ... replayed on rank r) at 1/16 of the linear size: 8 bands of 34 rows (the last one 32) + halos, 12 frames per pass -- so some
+    ranks replay two frames of a pass and some one -- three passes, against the whole-frame oracle."""
+    H, W, n, K = 270, 480, 6, 12
+    from metdetpy_amd.bands import BandPlan
+    plan = BandPlan(H, W, 8, (100, 160, 180, 320))
+    assert plan.band_rows == 34 and plan.bands[7]["own1"] - plan.bands[7]["own0"] == 32 and plan.bands[3]["sub0"] == 3 * 34 - 4
+    compare_worker_output(run_band_ranks(tmp_path, "oracle", kind, 8, H, W, n, K), H, W, n, K)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -273,7 +277,9 @@ def test_rccl_collectives_on_the_library_streams_one_rank():
     frames = SkyStream(H, W, 20220417, speed=8, streak_period=16).take(4 * K)
     want = whole_frame_oracle(frames, n, mask, cfg)
     assert sum(w["n_raw"] for w in want) > 0
-    comm = rccl.Communicator(0, 1, rccl.new_unique_id())
+    # timeout_s set: the communicator is made on a helper thread and must still be a BLOCKING one (a non-blocking
+    # communicator answers ncclInProgress to the data-path calls below)
+    comm = rccl.Communicator(0, 1, rccl.new_unique_id(), device=0, timeout_s=60)
     det = BandedM3Detector(n / 10, 10, mask, 10, cfg, None, rank=0, world=1, max_batch=K, comm=comm)
     band = det.engine.band
     ptrs, queued = [], []
@@ -294,12 +300,22 @@ def test_rccl_collectives_on_the_library_streams_one_rank():
     for ptr in ptrs:
         band.device_free(ptr)
     det.close()
+    comm.close()
 
 
 @pytest.mark.gpu
-def test_two_process_gloo_hip_bands(tmp_path):
-    """Two ranks, each with its own band + Hough contexts on GPU 0, host-staged gloo collectives."""
-    compare_worker_output(run_two_ranks(tmp_path, "hip"), 270, 448, 8, 16)
+@pytest.mark.parametrize("kind", ["store", "gloo"])
+def test_two_process_hip_bands(tmp_path, kind):
+    """Two ranks, each with its own band + Hough contexts on GPU 0 (RCCL refuses two ranks on one device: host-staged collectives
+    through the group)."""
+    compare_worker_output(run_band_ranks(tmp_path, "hip", kind, 2, 270, 448, 8, 16), 270, 448, 8, 16)
+
+
+@pytest.mark.gpu
+def test_eight_process_hip_bands_on_one_gpu(tmp_path):
+    """The 8-rank structure of BASELINE config 5 on the HIP path: eight processes, each with its band + Hough contexts, sharing
+    the box's one GPU; 8 bands of a 544-row frame, 24 frames per pass (three replayed per rank), three passes."""
+    compare_worker_output(run_band_ranks(tmp_path, "hip", "store", 8, 544, 960, 8, 24), 544, 960, 8, 24)
 
 
 @pytest.mark.gpu

@@ -4,7 +4,7 @@
   config 5   7680x4320, m3det_high thresholds: whole frame on one GPU, and tiled into 8 row bands (on one device here;
              one band per GPU in production) against the whole-frame detector
   config 4   `bench.py --gpus 2` launched the way the driver launches it (torch.distributed.run, one rank per GPU; two
-             ranks share the one GPU of the test box over gloo)
+             ranks share the one GPU of the test box: their final gather goes through the rendezvous store)
 
 Bar: bit-exact thresholds, lit counts, raw Hough segments in discovery order, lineset_nms output and probabilities.
 """
@@ -121,17 +121,31 @@ def _free_port():
 def test_config4_bench_two_ranks_as_the_driver_launches_it():
     """`bench.py --gpus 2` under torch.distributed.run: barrier + max-over-ranks timing, the final gather of the
     detection counts, ONE JSON line from rank 0 with n_gpus = 2 and the whole-job rate."""
-    env = dict(os.environ, MDH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--batch", "128", "--passes-per-step", "2", "--unique", "64"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _bench_ranks(2)
+    assert d["config"]["collectives"].startswith("store"), d["config"]["collectives"]  # (two ranks, one device: no RCCL communicator)
+
+
+def _bench_ranks(N, extra=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(N), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--steps", "6", "--warmup", "2",
+           "--batch", "128", "--passes-per-step", "2", "--unique", "64", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == N and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["frames_per_step"] == 256 and d["config"]["passes_per_step"] == 2
-    assert abs(d["value"] - 2 * 6 * 256 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
+    assert abs(d["value"] - N * 6 * 256 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d, "the CPU baseline is timed at N = 1 only"
-    assert d["detections"]["raw_segments"] > 0 and d["config"]["parallelism"] == "streams x2"
+    assert d["detections"]["raw_segments"] > 0 and d["config"]["parallelism"] == f"streams x{N}"
+    return d
+
+
+def test_config4_bench_eight_ranks_as_the_driver_launches_it():
+    """The command the driver runs for the 8-GPU point of the scaling curve, on this box's ONE device: eight ranks, eight
+    independent streams (seeds 20220413 + rank), barrier / max-over-ranks / final gather through the store."""
+    d = _bench_ranks(8)
+    # eight different streams: the gathered counts are the sum over the ranks, not eight times rank 0's
+    assert d["detections"]["per_rank_raw_segments"] and len(set(d["detections"]["per_rank_raw_segments"])) > 1

@@ -112,9 +112,10 @@ def test_bench_config1_end_to_end_workload():
 
 
 def test_bench_rccl_branch_with_one_rank():
-    """The "nccl" (= RCCL) branch of the timed harness -- process-group init on the device, barrier, max-reduce of the time,
-    all-gather of the detection counts on device tensors -- with a world of one rank launched the way the driver launches N
-    (a one-GPU box cannot hold two RCCL ranks; the two-rank run of this suite goes over gloo)."""
+    """The RCCL branch of the timed harness -- communicator from an id that travelled through the rendezvous store, barrier,
+    ncclAllReduce(max) of the time, ncclAllGather of the detection counts on device memory and a private HIP stream (librccl
+    through ctypes, no torch) -- with a world of one rank launched the way the driver launches N (a one-GPU box cannot hold two
+    RCCL ranks; the two- and eight-rank runs of this suite share the device and gather through the store)."""
     env = dict(os.environ, MDH_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "128", "--steps", "6", "--warmup", "2",
@@ -125,6 +126,7 @@ def test_bench_rccl_branch_with_one_rank():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0 and d["detections"]["lit_pixels"] > 0
+    assert d["config"]["collectives"].startswith("rccl"), d["config"]["collectives"]
 
 
 def test_bench_classic_and_accumulator_entries():

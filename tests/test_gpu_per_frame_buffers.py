@@ -3,7 +3,8 @@
 The reference's loop pops plain NumPy arrays from its loaders (MetDetPy.py:192; videoloader.py:569-593), and ProcessVideoLoader
 recycles a fixed ring of them (a shared RawArray, videoloader.py:696-701, 746-772).  mdh_update reads a frame in place when a
 kernel can reach it: a pool of mdh_host_alloc, a range registered with mdh_host_register, or a pageable buffer whose address
-came by three times (the library registers it itself).  Every path must give the oracle's results, bit for bit.
+came by three times once the loader has opted in (mdh_set_auto_register: the library then registers it itself).  Every path must
+give the oracle's results, bit for bit.
 """
 import ctypes
 import mmap
@@ -61,6 +62,7 @@ def test_recycled_pageable_ring_gets_registered(shape, n, ring):
     frames = stream(shape, n, 5 * n + 40, 11 + n)
     want = oracle_series(frames, n, mask, cfg)
     det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    det._ctx.set_auto_register(True)  # (the loader says it recycles its buffers and will unregister before freeing one)
     bufs = [np.empty(shape, np.uint8) for _ in range(ring)]
     total = 0
     for t, f in enumerate(frames):
@@ -79,14 +81,15 @@ def test_recycled_pageable_ring_gets_registered(shape, n, ring):
     det.close()
 
 
-def test_auto_register_off_copies_every_frame():
+def test_auto_register_is_opt_in_pageable_frames_are_copied():
+    """The default: a buffer that comes by again and again is NOT pinned behind the caller's back (it may be a fresh array per frame
+    that malloc keeps handing the same address for -- ADVICE round 4); every frame is copied."""
     shape, n = (72, 192), 4
     mask = np.ones(shape, np.uint8)
     cfg = binary_cfg("normal")
     frames = stream(shape, n, 40, 5)
     want = oracle_series(frames, n, mask, cfg)
     det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
-    det._ctx.set_auto_register(False)
     buf = np.empty(shape, np.uint8)
     for t, f in enumerate(frames):
         buf[...] = f
@@ -124,7 +127,7 @@ def test_explicitly_registered_ring_and_fresh_arrays():
     det._ctx.host_unregister(ring)
     with pytest.raises(_lib.MetDetHipError, match="not a range registered"):
         det._ctx.host_unregister(ring)
-    # unregistered: the same buffers are ordinary memory again (and, recycled, get registered one by one)
+    # unregistered: the same buffers are ordinary memory again
     for t in range(3):
         ring[0][...] = frames[t]
         det.update(ring[0])
@@ -142,6 +145,7 @@ def test_registered_buffer_unmapped_and_mapped_again():
     frames = stream(shape, n, 60, 41)
     want = oracle_series(frames, n, mask, cfg)
     det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    det._ctx.set_auto_register(True)
     nbytes = shape[0] * shape[1]
     mm = mmap.mmap(-1, nbytes)
     view = np.frombuffer(mm, np.uint8).reshape(shape)

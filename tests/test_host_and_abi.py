@@ -1,5 +1,5 @@
 """CPU-side tests: the C-ABI library loads and exports every symbol the header declares (no compute calls),
-host logic against the reference's golden vectors, config parsing, and the 2-process (gloo) gather path."""
+host logic against the reference's golden vectors, config parsing, and the multi-process gather path (2 and 8 ranks)."""
 import json
 import os
 import re
@@ -114,6 +114,20 @@ def test_product_does_not_import_oracle():
             assert "oracle" not in src.replace("# oracle", ""), f"{name} mentions the oracle"
 
 
+def test_product_and_bench_import_no_torch():
+    """north_star: "no PyTorch".  The package, bench.py and bench_modes.py do not import torch; the launcher the driver uses
+    (`python -m torch.distributed.run`) only exports RANK / WORLD_SIZE / MASTER_*, which rendezvous.py reads."""
+    files = [os.path.join(ROOT, "metdetpy_amd", f) for f in os.listdir(os.path.join(ROOT, "metdetpy_amd")) if f.endswith(".py")]
+    files += [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "bench_modes.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for path in files:
+        src = open(path).read()
+        assert not re.search(r"^\s*(import torch|from torch)", src, re.M), f"{path} imports torch"
+    probe = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, sys.argv[1]); import metdetpy_amd, metdetpy_amd.dist, "
+                            "metdetpy_amd.bands, metdetpy_amd.timeshard, metdetpy_amd.rccl, metdetpy_amd.rendezvous, bench, bench_modes; "
+                            "assert 'torch' not in sys.modules", ROOT], capture_output=True, text=True)
+    assert probe.returncode == 0, probe.stderr[-1500:]
+
+
 def test_g3_std_roi_host(golden_dir):
     for c in json.load(open(os.path.join(golden_dir, "g3_std_roi.json"))):
         h, w, kind = c["h"], c["w"], c["kind"]
@@ -168,40 +182,77 @@ def test_stream_sharding():
             assert seen == list(range(n))
 
 
-GLOO_WORKER = r"""
+GATHER_WORKER = r"""
 import os, sys, json
 sys.path.insert(0, sys.argv[1])
 from metdetpy_amd import dist as md
-rank, local, world, dist = md.init_from_env("gloo")
-streams = md.shard_streams(5, rank, world)
+from tests.gloo_group import make_group
+group = make_group(sys.argv[2])
+rank, world = group.rank, group.world
+streams = md.shard_streams(int(sys.argv[3]), rank, world)
 local_recs = {s: [{"stream": s, "rank": rank, "pt1": [s, rank], "score": 0.5 + s}] * (s % 3) for s in streams}
-merged = md.gather_records(local_recs, dist)
-tmax = md.max_over_ranks(1.0 + rank, dist)
+merged = md.gather_records(local_recs, group)
+tmax = md.max_over_ranks(1.0 + rank, group)
+counts = group.all_gather_i64([rank, 10 * rank, -rank])
+assert counts == [[r, 10 * r, -r] for r in range(world)], counts
 if rank == 0:
-    print(json.dumps({"merged": {str(k): v for k, v in merged.items()}, "tmax": tmax}))
+    print(json.dumps({"merged": {str(k): v for k, v in merged.items()}, "tmax": tmax, "backend": group.backend}))
 else:
     assert merged is None
-dist.barrier()
-dist.destroy_process_group()
+group.close()
 """
 
 
-def test_two_process_gloo_gather(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(GLOO_WORKER)
-    port = 29500 + (os.getpid() % 2000)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
-    outs = [p.communicate(timeout=180) for p in procs]
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e.decode()[-2000:]
-    res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
-    assert res["tmax"] == 2.0
-    assert sorted(int(k) for k in res["merged"]) == [0, 1, 2, 3, 4]
+@pytest.mark.parametrize("kind,world,streams", [("store", 2, 5), ("gloo", 2, 5), ("store", 8, 8), ("store", 8, 19)])
+def test_multi_process_final_gather(tmp_path, kind, world, streams):
+    """Independent streams, one (or more) per rank: the final gather of the detection records to rank 0, the max-over-ranks time and
+    the all-gather of the counts -- over the product's store-backed group (no GPU here: the RCCL branch of the same calls runs in
+    tests/test_gpu_bench_contract.py) and over gloo."""
+    from tests.mp import run_ranks
+    res = run_ranks(tmp_path, "gather_worker", GATHER_WORKER, world, args=(kind, streams), timeout=300)
+    assert res["tmax"] == float(world) and res["backend"] == kind
+    assert sorted(int(k) for k in res["merged"]) == list(range(streams))
     for k, v in res["merged"].items():
-        assert len(v) == int(k) % 3 and all(r["stream"] == int(k) and r["rank"] == int(k) % 2 for r in v)
+        assert len(v) == int(k) % 3 and all(r["stream"] == int(k) and r["rank"] == int(k) % world for r in v)
+
+
+def test_rendezvous_store_survives_a_stale_port_file(tmp_path, monkeypatch):
+    """A crashed run leaves its port file behind: a new job on the same MASTER_PORT must not trust it (handshake nonce)."""
+    import struct
+    import threading
+    from metdetpy_amd import rendezvous as rv
+    from tests.mp import free_port
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    tempfile.tempdir = None  # (re-read TMPDIR)
+    try:
+        port = free_port()
+        dead = free_port()
+        with open(rv._port_file("127.0.0.1", port), "wb") as f:
+            f.write(struct.pack("<I", dead) + b"x" * 16)  # nobody listens there
+        box = {}
+
+        def rank1():
+            g = rv.Group(1, 2, "127.0.0.1", port, timeout_s=20)
+            box["got"] = g.broadcast_bytes(None, 0)
+            box["ag"] = g.all_gather_bytes(b"one")
+            g.close()
+
+        th = threading.Thread(target=rank1)
+        th.start()
+        import time
+        time.sleep(0.3)  # rank 1 is already retrying against the stale file
+        g0 = rv.Group(0, 2, "127.0.0.1", port, timeout_s=20)
+        g0.broadcast_bytes(b"uid", 0)
+        assert g0.all_gather_bytes(b"zero") == [b"zero", b"one"]
+        g0.close()
+        th.join(30)
+        assert box == {"got": b"uid", "ag": [b"zero", b"one"]}
+        assert not g0.store.server.data, "the store kept keys of finished collectives"
+        with pytest.raises(rv.RendezvousError):
+            rv.Group(1, 2, "127.0.0.1", free_port(), timeout_s=0.5)  # no rank 0 anywhere
+    finally:
+        tempfile.tempdir = None
 
 
 def test_every_environment_switch_is_documented():

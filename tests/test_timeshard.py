@@ -16,6 +16,7 @@ from metdetpy_amd.utils import select_std_roi
 from oracle import m3_oracle as mo
 from tests.band_oracle_engine import OracleBandEngine
 from tests.helpers import binary_cfg, frames_normal
+from tests.mp import run_ranks
 from tests.test_bands import check_against, make_case, whole_frame_oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -97,17 +98,18 @@ TS_WORKER = r"""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, sys.argv[1])
-from metdetpy_amd import dist as md
 from metdetpy_amd.timeshard import run_time_sharded
 from tests.band_oracle_engine import OracleBandEngine
+from tests.gloo_group import make_group
 from tests.test_bands import make_case
-use_hip = sys.argv[2] == "hip"
-rank, local, world, dist = md.init_from_env("gloo")
-H, W, n, total, B = (96, 160, 5, 70, 12) if not use_hip else (270, 448, 8, 150, 32)
+use_hip, kind = sys.argv[2] == "hip", sys.argv[3]
+H, W, n, total, B = [int(v) for v in sys.argv[4:9]]
+group = make_group(kind)
+rank, world = group.rank, group.world
 mask = np.ones((H, W), np.uint8)
 frames, cfg = make_case("sky", H, W, n, total, 31)
 kw = {} if use_hip else dict(engine=OracleBandEngine)
-res = run_time_sharded(n / 10, 10, mask, 10, cfg, total, lambda lo, hi: frames[lo:hi], dist=dist, rank=rank, world=world,
+res = run_time_sharded(n / 10, 10, mask, 10, cfg, total, lambda lo, hi: frames[lo:hi], group=group, rank=rank, world=world,
                        max_batch=B, **kw)
 if rank == 0:
     results, info = res
@@ -115,25 +117,12 @@ if rank == 0:
                            lit=int(fi["lit_count"]), n_raw=int(fi["n_raw"])) for (l, p), fi in zip(results, info)]))
 else:
     assert res is None
-dist.barrier()
-dist.destroy_process_group()
+group.close()
 """
 
 
-def run_two_ranks(tmp_path, mode):
-    script = tmp_path / "ts_worker.py"
-    script.write_text(TS_WORKER)
-    port = 33000 + (os.getpid() % 2000)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.PIPE))
-    outs = [p.communicate(timeout=600) for p in procs]
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e.decode()[-3000:]
-    return json.loads(outs[0][0].decode().strip().splitlines()[-1])
+def run_ts_ranks(tmp_path, mode, kind, world, H, W, n, total, B):
+    return run_ranks(tmp_path, "ts_worker", TS_WORKER, world, args=(mode, kind, H, W, n, total, B))
 
 
 def compare(got, H, W, n, total):
@@ -147,8 +136,18 @@ def compare(got, H, W, n, total):
         assert np.array_equal(np.array(g["pred"]).reshape(-1, 10), w["pred"]), i
 
 
-def test_two_process_gloo_time_shards_equal_whole_stream_oracle(tmp_path):
-    compare(run_two_ranks(tmp_path, "oracle"), 96, 160, 5, 70)
+@pytest.mark.parametrize("kind", ["store", "gloo"])
+def test_two_process_time_shards_equal_whole_stream_oracle(tmp_path, kind):
+    compare(run_ts_ranks(tmp_path, "oracle", kind, 2, 96, 160, 5, 70, 12), 96, 160, 5, 70)
+
+
+@pytest.mark.parametrize("kind", ["store", "gloo"])
+def test_eight_process_time_windows_with_the_all_gathered_table(tmp_path, kind):
+    """north_star's sharding at its world size: 8 windows of one stream, the (S1, S2) table of the due frames all-gathered, every
+    rank replaying the scalar chain up to its own start, results gathered to rank 0 -- against ONE oracle over the whole stream.
+    136 frames over 8 ranks = 17 per window: shorter than the 2(n-1) = 10-frame warm-up plus a pass, so windows reach into their
+    predecessors' frames, and the due frames (every 2n = 12) fall into different windows."""
+    compare(run_ts_ranks(tmp_path, "oracle", kind, 8, 96, 160, 6, 136, 7), 96, 160, 6, 136)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -175,8 +174,15 @@ def test_hip_time_shards_equal_whole_stream(kind, world, H, W, n, total, B):
 
 
 @pytest.mark.gpu
-def test_two_process_gloo_hip_time_shards(tmp_path):
-    compare(run_two_ranks(tmp_path, "hip"), 270, 448, 8, 150)
+@pytest.mark.parametrize("kind", ["store", "gloo"])
+def test_two_process_hip_time_shards(tmp_path, kind):
+    compare(run_ts_ranks(tmp_path, "hip", kind, 2, 270, 448, 8, 150, 32), 270, 448, 8, 150)
+
+
+@pytest.mark.gpu
+def test_eight_process_hip_time_windows_on_one_gpu(tmp_path):
+    """8 windows, eight processes sharing the box's one GPU (the pipelined detector of every window on its own context)."""
+    compare(run_ts_ranks(tmp_path, "hip", "store", 8, 270, 448, 8, 400, 32), 270, 448, 8, 400)
 
 
 @pytest.mark.gpu

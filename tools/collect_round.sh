@@ -33,7 +33,7 @@ python bench.py --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C2_houg
 python bench.py --workload C3 --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C3_hough_accumulator.json 2>> $O/err_acc
 python bench.py --workload C5 --unique 50 --batch 125 --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C5_hough_accumulator.json 2>> $O/err_acc
 python bench.py --workload C1e --cpu-seconds 0 > $O/${TAG}_bench_C1e_end_to_end.json 2> $O/err_c1e
-MDH_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 1 --cpu-seconds 0 2> $O/err_2r | grep '^{' > $O/${TAG}_bench_2ranks_gloo_one_gpu.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 1 --cpu-seconds 0 2> $O/err_2r | grep '^{' > $O/${TAG}_bench_2ranks_one_gpu.json
 for wl in C2 C3 C5; do WL=$wl python tools/hough_frame_times.py > $O/${TAG}_hough_frame_times_$wl.txt 2>&1; done
 ./tools/lds_atomic_rate > $O/${TAG}_lds_atomic_rate.txt 2>&1
 python tools/bench_pre_batch.py > $O/${TAG}_preprocess_batch.json 2> $O/err_pre

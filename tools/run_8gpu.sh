@@ -3,13 +3,20 @@
 # driver launches `--gpus N` (torch.distributed.run, rendezvous on 127.0.0.1).  NOT run on the build's one-GPU boxes: no scaling
 # number in this repository comes from here until a node with N GPUs has run it.
 #
-#   bash tools/run_8gpu.sh [N] [out_dir]
+#   bash tools/run_8gpu.sh [--dry-run] [N] [out_dir]
+#
+# --dry-run: the SAME three commands with N ranks on however many devices the box has (one is enough): the ranks share devices
+# round-robin, no RCCL communicator can form (RCCL refuses two ranks per device), so barrier / max / gathers go through the
+# rendezvous store and the band path exchanges host buffers.  Small passes; proves the structural path the driver launches at
+# N = 8 end to end (launcher -> rendezvous -> every mode's sharding -> gather -> one JSON line with parity), not the scaling.
 #
 # Every rank prints, before its first pass: the HIP device it sits on, what the RCCL communicator of the band path says about
 # itself (ranks, rank, device), and the message sizes of its collectives.  It fails loudly -- non-zero exit, text on stderr --
 # when fewer GPUs are visible than ranks, when the communicator does not form within MDH_RCCL_TIMEOUT seconds, when it holds
 # another number of ranks than WORLD_SIZE (ncclCommCount), or when a pass that waits on a peer does not complete in that time.
 set -u
+DRY=0
+if [ "${1:-}" = "--dry-run" ]; then DRY=1; shift; fi
 N=${1:-8}
 OUT=${2:-gpurun_out/run_${N}gpu}
 cd "$(dirname "$0")/.."
@@ -25,7 +32,10 @@ except OSError:
     print(0)
 PY
 )
-if [ "$have" -lt "$N" ]; then
+if [ "$DRY" = 1 ]; then
+    [ "$have" -ge 1 ] || { echo "run_8gpu.sh --dry-run: no HIP device visible" >&2; exit 2; }
+    export MDH_DIST_BACKEND=store
+elif [ "$have" -lt "$N" ]; then
     echo "run_8gpu.sh: $N ranks asked for, $have HIP device(s) visible -- RCCL refuses two ranks on one device; nothing was run" >&2
     exit 2
 fi
@@ -49,6 +59,12 @@ print(f"   {d['value']:.0f} {d['unit']} on {d['n_gpus']} GPUs, {d['ms_per_step']
 PY
 }
 fail=0
+if [ "$DRY" = 1 ]; then
+    launch streams 29611 --steps 4 --warmup 1 --batch 128 --passes-per-step 2 --unique 64 || fail=1
+    launch bands_C5 29612 --mode bands --workload C5 --unique 16 --batch 16 --steps 3 --warmup 1 --cpu-seconds 0 --parity-frames 8 || fail=1
+    launch timeshard_C2 29613 --mode timeshard --batch 64 --steps 16 --unique 64 --cpu-seconds 0 || fail=1
+    exit $fail
+fi
 # BASELINE config 4: N independent 1080p streams, no data-path collective (the driver's scaling curve runs exactly this)
 launch streams 29611 --steps 20 --warmup 5 || fail=1
 # BASELINE config 5: ONE 7680x4320 stream tiled into N row bands: all-reduce of the noise sums + all-to-all of the bit planes (RCCL on the library's streams)
