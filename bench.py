@@ -14,9 +14,10 @@ max-over-ranks time and the final gather of the detection counts (RCCL through c
 
 The JSON line also carries (rank 0):
   roofline      the dominant pixel kernel (stack_threshold), priced PHYSICALLY: the bytes one launch must move (every frame
-                byte once + the window carried into the launch + what it stores) over the launch durations measured live
-                with HIP events on the library's own stream -- inside the pipelined timed region (`frac`, what rocprofv3
-                --kernel-trace sees too) and with one pass in flight and nothing overlapping (`frac_standalone`).  SURVEY 8d's
+                byte once + the window carried into the launch + what it stores) over (a) the time the timed region spent per
+                pass -- `frac`, tied to ms_per_step, the number the driver's own clock checks -- and (b) the launch's own
+                duration measured live with HIP events on the library's stream with one pass in flight and nothing overlapping
+                (`frac_isolated`; rocprofv3 --kernel-trace of `--depth 1` averages the same launches).  SURVEY 8d's
                 "(n+1) reads per pixel" model is kept as `algorithmic_frac`: the kernel is time-blocked (each byte is fetched
                 once per launch, not n times), so that figure exceeds 1 by design and is not a bandwidth.
   cpu_baseline  the CPU oracle timed on this box's host cores over a bounded sample of the same stream (N = 1 only): the
@@ -44,8 +45,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the library's streams want their own hardware queues (the HIP default is 4); read when the HIP runtime starts
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+# (GPU_MAX_HW_QUEUES: not set here -- the binding asks for what its mode wants before the HIP runtime loads, metdetpy_amd/_lib.py)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s is what a streaming copy reaches)
 
@@ -255,10 +255,19 @@ def cpu_baseline(frames, n, mask, seconds):
                                                       "OpenCV-side ops and PPHT from the C port)"})
 
 
-def parity_check(frames, n, mask, local, count):
+def parity_check(frames, n, mask, local, count, timed=None):
     """Detection parity vs the CPU reference restatement (the metric's second half): a fresh GPU detector and the C
     port of the oracle see the first `count` frames of the stream; thresholds, lit counts, raw Hough segments (in
-    discovery order) and NMS output must be identical, and so must the records the collector makes of them."""
+    discovery order) and NMS output must be identical, and so must the records the collector makes of them.
+
+    timed = {"tally": [raw segments, NMS segments, lit pixels] summed over the TIMED region, "frames": its frame count,
+    "per_pass_equal": every timed pass gave the same tallies}: the timed region processes the stream's period over and over in
+    its steady state (the threshold has settled, every window is full), so its tallies must be the oracle's tallies of one
+    steady-state period times the number of periods -- checked here against the LAST whole period the oracle saw (count is
+    raised to three periods: the first two still carry the warm-up of the window and of the threshold's EMA)."""
+    period = len(frames)
+    if timed is not None and timed["frames"] % period == 0 and count > 0:
+        count = max(count, 3 * period)
     from metdetpy_amd import M3Detector
     from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
@@ -269,11 +278,13 @@ def parity_check(frames, n, mask, local, count):
     det.close()
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
     orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY)
-    bad, segs, o_results = [], 0, []
+    bad, segs, o_results, o_lines_num, o_lit = [], 0, [], [], []
     for i in range(count):
         orc.update(frames[i])
         o_raw = orc.detect()
         o_results.append((np.zeros((0, 4), np.int32), np.zeros(0)))
+        o_lines_num.append(int(orc.lines_num))
+        o_lit.append(int(orc.lit_count))
         thr = orc.state()[0]
         ok = (int(info[i]["bi_threshold"]) == thr and int(info[i]["lit_count"]) == orc.lit_count
               and int(info[i]["n_raw"]) == orc.lines_num
@@ -308,10 +319,29 @@ def parity_check(frames, n, mask, local, count):
     ocol.clear()
     g_rec, o_rec = [r.to_dict() for r in gcol.met_exporter.meteor_list], [r.to_dict() for r in ocol.met_exporter.meteor_list]
     rec_ok = g_rec == o_rec
-    return {"frames_checked": count, "raw_segments_checked": segs, "mismatching_frames": bad, "records": len(o_rec),
-            "records_identical": rec_ok, "verdict": "identical" if not bad and rec_ok else "MISMATCH",
-            "checked": "bi_threshold, lit_count, raw Hough segments (order included), lineset_nms output, collector records "
-                       "vs oracle/metdet_oracle.c"}
+    out = {"frames_checked": count, "raw_segments_checked": segs, "mismatching_frames": bad, "records": len(o_rec),
+           "records_identical": rec_ok, "verdict": "identical" if not bad and rec_ok else "MISMATCH",
+           "checked": "bi_threshold, lit_count, raw Hough segments (order included), lineset_nms output, collector records "
+                      "vs oracle/metdet_oracle.c"}
+    if timed is not None:
+        if timed["frames"] % period or count < 3 * period:
+            out["timed_region"] = {"verdict": "not checked", "why": "the timed region is not a whole number of stream periods"}
+        else:
+            lo = (count // period - 1) * period  # the last whole period the oracle saw
+            per = [sum(o_lines_num[lo:lo + period]), sum(len(o_results[i][0]) for i in range(lo, lo + period)), sum(o_lit[lo:lo + period])]
+            prev = [sum(o_lines_num[lo - period:lo]), sum(len(o_results[i][0]) for i in range(lo - period, lo)), sum(o_lit[lo - period:lo])]
+            periods = timed["frames"] // period
+            want = [v * periods for v in per]
+            ok = want == list(timed["tally"]) and timed.get("per_pass_equal", True) and per == prev
+            out["timed_region"] = {"periods": periods, "frames": timed["frames"], "oracle_tally_per_period": per,
+                                   "oracle_steady": per == prev, "expected_tally": want, "gpu_tally": list(timed["tally"]),
+                                   "gpu_every_pass_equal": bool(timed.get("per_pass_equal", True)),
+                                   "verdict": "identical" if ok else "MISMATCH",
+                                   "checked": "[raw segments, NMS segments, lit pixels] summed over every frame of the timed region == "
+                                              "the oracle's tallies of one steady-state period x the number of periods"}
+            if not ok:
+                out["verdict"] = "MISMATCH"
+    return out
 
 
 def parity_check_per_frame(frames, n, mask, local, count, kind):
@@ -527,19 +557,24 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=Fal
         "in_pipeline_note": "mean span of the kernel's launches in the timed region (HIP events on the library's main streams, every "
                             "4th pass): consecutive launches overlap on the two main streams (MDH_MAIN_STREAMS=1 serialises them: "
                             "shorter spans, ~10 % fewer frames/s) next to the other stages of the neighbouring passes",
+        # THE figures of the line: the kernel's bytes over the time the timed region spent per pass -- tied to
+        # ms_per_step, the one number the driver's clock checks.  The non-overlapped launch is kept as `frac_isolated`.
+        "achieved": compulsory / (ms_per_pass * 1e-3) / 1e9, "frac": frac_of(ms_per_pass),
         "frac_at_pipeline_pace": frac_of(ms_per_pass),
+        "frac_note": "frac = bytes_per_launch / ms_per_pass / peak: priced on the pipelined timed region itself (ms_per_pass = ms_per_step / "
+                     "passes_per_step); frac_isolated = the same bytes over the launch's own duration with one pass in flight (launch_ms)",
         "algorithmic_bytes_per_launch": (n + 1) * frame * B,
         "algorithmic_note": "SURVEY 8d's (n+1) reads per pixel per frame; the kernel keeps the window in registers and reads "
                             "each byte once per launch, so the figure priced on these bytes exceeds 1 by design and is not a bandwidth",
     })
     if prof_alone and prof_alone.get(kern, (0, 0))[1]:
         a_ms = prof_alone[kern][0] / prof_alone[kern][1]
-        out.update({"launch_ms": a_ms, "launches": prof_alone[kern][1], "achieved": compulsory / (a_ms * 1e-3) / 1e9, "frac": frac_of(a_ms),
+        out.update({"launch_ms": a_ms, "launches": prof_alone[kern][1], "achieved_isolated": compulsory / (a_ms * 1e-3) / 1e9, "frac_isolated": frac_of(a_ms),
                     "launch_ms_note": "mean duration of the kernel's launches with ONE pass in flight (nothing overlaps), HIP events on "
                                       "the library's main stream, measured after the timed region of this run",
                     "algorithmic_frac": (n + 1) * frame * B / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     else:  # --standalone-passes 0 (or --depth 1, where the timed region itself is non-overlapped)
-        out.update({"launch_ms": avg_ms, "launches": launches, "achieved": compulsory / (avg_ms * 1e-3) / 1e9, "frac": frac_of(avg_ms),
+        out.update({"launch_ms": avg_ms, "launches": launches, "achieved_isolated": compulsory / (avg_ms * 1e-3) / 1e9, "frac_isolated": frac_of(avg_ms),
                     "launch_ms_note": "mean span of the kernel's launches in the timed region (no stand-alone leg in this run)",
                     "algorithmic_frac": (n + 1) * frame * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     traffic, src = None, None
@@ -587,12 +622,14 @@ def run_streams(a, D, wl, mask):
     nms = np.zeros((B, _lib.MDH_MAX_LINES, 4), np.int32)
     prob = np.zeros((B, _lib.MDH_MAX_LINES), np.float64)
     tally = [0, 0, 0]
+    passes_seen = {}  # distinct per-pass tallies -> how many passes gave them (the timed region: ONE entry in steady state)
 
     def collect():
         ctx.collect_into(info, raw, nms, prob)
-        tally[0] += int(info["n_raw"].sum())
-        tally[1] += int(info["n_nms"].sum())
-        tally[2] += int(info["lit_count"].sum())
+        one = (int(info["n_raw"].sum()), int(info["n_nms"].sum()), int(info["lit_count"].sum()))
+        passes_seen[one] = passes_seen.get(one, 0) + 1
+        for k_ in range(3):
+            tally[k_] += one[k_]
 
     P = a.passes_per_step
 
@@ -612,12 +649,14 @@ def run_streams(a, D, wl, mask):
         run(a.warmup * P)
     steps = a.steps if a.steps is not None else 20
     tally[:] = [0, 0, 0]
+    passes_seen.clear()
     D.fence()
     t0 = time.perf_counter()
     run(steps * P)  # the timed region carries no timing events: they cost the pipeline a few per cent
     D.fence()
     segs, kept, lit = tally
     dt = time.perf_counter() - t0
+    timed = {"tally": [segs, kept, lit], "frames": steps * P * B, "per_pass_equal": len(passes_seen) == 1}
     prof = {}
     if not a.no_profile and D.rank == 0:
         # the kernels' spans INSIDE the pipeline (overlapping each other, queueing included): the same pipelined passes again,
@@ -637,7 +676,7 @@ def run_streams(a, D, wl, mask):
         ctx.profile_enable(False)
     dt_all, tot = D.max_time_and_sum(dt, [segs, kept, lit])
     res = dict(frames=steps * P * B * D.world, dt=dt_all, steps=steps, tot=tot, prof=prof, prof_alone=prof_alone, frames_sample=frames,
-               B=B, P=P, uniq=uniq, dense=bool(DETECTOR == "m3" and ctx.dense_now))
+               B=B, P=P, uniq=uniq, dense=bool(DETECTOR == "m3" and ctx.dense_now), timed=timed)
     (ctx.host_free if a.host_input else ctx.device_free)(pool)
     det.close()
     return res
@@ -754,7 +793,7 @@ def run_secondary(a):
                "--standalone-passes", "6"] + extra
         t0 = time.perf_counter()
         try:
-            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=480)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not line:
                 out[name] = {"error": f"rc {p.returncode}: {p.stderr.strip()[-300:]}"}
@@ -770,6 +809,7 @@ def run_secondary(a):
              "frames_per_step": d["config"]["frames_per_step"], "passes_per_step": d["config"].get("passes_per_step"),
              "frac": rf.get("frac"), "frac_at_pipeline_pace": rf.get("frac_at_pipeline_pace"),
              "parity": (d.get("parity") or {}).get("verdict"), "parity_frames": (d.get("parity") or {}).get("frames_checked"),
+             "timed_region_tallies": ((d.get("parity") or {}).get("timed_region") or {}).get("verdict"),
              "wall_s": round(time.perf_counter() - t0, 1), "command": "python bench.py " + " ".join(cmd[2:])}
         if "per_frame" in d:
             e["per_frame"] = {k: d["per_frame"][k] for k in ("frames", "update_stats", "us_per_frame", "frames_by_kind", "frames_per_s_by_kind")}
@@ -798,11 +838,7 @@ def main():
         a.passes_per_step = 1
     if a.protocol == "per-frame" and a.warmup == 2:
         a.warmup = 6
-    if a.mode == "bands" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "MDH_BENCH_KEEP_QUEUES" not in os.environ:
-        # N band contexts + a Hough context in ONE process on one device: ~30 active streams.  The HIP runtime's hardware queues
-        # (read at its first call, which is still ahead) are few on purpose here: measured 54 k frames/s with 3-5 queues, 38-42 k with
-        # 6-12, 5 k with 32 (the command processor time-slices oversubscribed queues)
-        os.environ["GPU_MAX_HW_QUEUES"] = "4"
+    # (--mode bands with all bands in one process: LocalBands asks the binding for 4 hardware queues itself, _lib.prefer_hw_queues)
     mask = np.ones((H, W), np.uint8)
     if a.workload in ("C3", "C1e"):
         m = load_mask(H, W)
@@ -887,7 +923,7 @@ def main():
             elif HOUGH_MODE == "accumulator":
                 out["parity"] = parity_check_accumulator(frames, n, mask, D.local, a.parity_frames)
             else:
-                out["parity"] = parity_check(frames, n, mask, D.local, a.parity_frames)
+                out["parity"] = parity_check(frames, n, mask, D.local, a.parity_frames, timed=r.get("timed") if a.warmup > 0 else None)
         if (D.world == 1 and not a.no_secondary and plain_streams and a.workload == "C2" and DETECTOR == "m3" and HOUGH_MODE == "exact"
                 and not a.host_input and a.depth == 0 and a.sensitivity is None):
             from metdetpy_amd import _lib

@@ -85,6 +85,21 @@ EXPORTS = [
 ]
 
 _lib = None
+_hw_queues = 12
+
+
+def prefer_hw_queues(n: int) -> bool:
+    """How many hardware queues the HIP runtime should map the library's streams onto (GPU_MAX_HW_QUEUES; HIP's default is 4).
+    The runtime reads it ONCE, when it initialises, so this only has an effect before the library is loaded; a value the host
+    exported itself always wins.  The binding asks for 12 (one detector: ~10 active streams, full overlap); a process that runs
+    MANY contexts on one device (LocalBands: 8 bands + a Hough context) asks for 4 -- the command processor time-slices
+    oversubscribed queues, measured 54 k frames/s with 3-5 queues against 5 k with 32.  Returns whether the
+    request can still take effect.  Results never depend on it."""
+    global _hw_queues
+    if _lib is not None:
+        return False
+    _hw_queues = int(n)
+    return "GPU_MAX_HW_QUEUES" not in os.environ
 
 
 class MetDetHipError(RuntimeError):
@@ -125,8 +140,9 @@ def load():
         raise MetDetHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "or `make -C metdetpy_amd/csrc` (there is no CPU fallback)")
     # host side of the boundary: the library's streams want their own hardware queues (HIP's default is 4; read once when the
-    # runtime initialises, i.e. at the process's first HIP call).  The library itself never touches the environment.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    # runtime initialises, i.e. at the process's first HIP call).  The C library itself never touches the environment; this
+    # binding does, once, here, and only when the host has not decided: an unchanged MetDetPy.py gets the tuned value.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(_hw_queues))
     L = C.CDLL(LIB_PATH)
     if not hasattr(L, "mdh_create") and hasattr(L, "mdh_collector_create"):
         L = _HostOnlyLibrary(L)

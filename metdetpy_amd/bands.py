@@ -194,6 +194,8 @@ class LocalBands:
         multi-GPU structure, kept for the tests of the exchange logic: shared_hough=False)."""
         self.s = _BandSetup(window_sec, fps, mask, num_cls, cfg, nbands)
         p = self.s.plan
+        if engine is HipBandEngine and nbands > 2:
+            _lib.prefer_hw_queues(4)  # many contexts on one device: few hardware queues (no effect once the runtime is up)
         self.shared = (engine is HipBandEngine) if shared_hough is None else bool(shared_hough)
         if self.shared:
             self.engines = [engine(p, b, self.s.n, cfg, self.s.mask_area, max_batch, device, with_hough=False) for b in range(p.nbands)]

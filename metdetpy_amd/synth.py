@@ -76,3 +76,72 @@ class SkyStream:
 
     def take(self, k: int) -> np.ndarray:
         return np.stack([self.next() for _ in range(k)], axis=0)
+
+
+class Config1Clip:
+    """Stand-in for BASELINE config 1's video (test/20220413Red.mp4: a Git-LFS blob the reference tree does not hold), built from
+    what the reference DOES hold about it: test/20220413_annotation.json (one meteor, 00:00:02.4 -> 00:00:04.4, pt1 [433, 147] ->
+    pt2 [374, 222] at anno_size [1168, 655]) and test/clip_test.json (the same meteor at [1412, 496] -> [1232, 728], i.e. a
+    3840x2160 source; its times are multiples of 0.04 s: 25 frames per second).  tests/golden/config1_truth.json carries those
+    numbers as data.
+
+    A 3840x2160 BGR clip at 25 fps: a night sky at the runtime resolution (noise, stars) blown up 4x with a fixed full-resolution
+    dither on top and slightly different channel gains (so that BGR2GRAY and the 4:1 INTER_LINEAR resize have real work), and ONE
+    meteor drawn at full resolution: its head travels pt1 -> pt2 (scaled from anno_size to the frame) at constant speed between
+    start_time and end_time, dragging a trail of `trail_s` seconds that runs out after the head has stopped.  NumPy only, seeded.
+    """
+
+    def __init__(self, truth: dict, *, size_hw=(2160, 3840), fps: float = 25.0, duration_s: float = 6.0, seed: int = 20220413,
+                 gain: float = 70.0, trail_s: float = 0.32, width_px: float = 6.0):
+        self.H, self.W = size_hw
+        self.fps, self.total = float(fps), int(round(duration_s * fps))
+        ax, ay = truth["anno_size"]
+        m = truth["meteors"][0]
+        sx, sy = self.W / ax, self.H / ay
+        self.p1 = np.array([m["pt1"][0] * sx, m["pt1"][1] * sy])
+        self.p2 = np.array([m["pt2"][0] * sx, m["pt2"][1] * sy])
+        self.t0, self.t1 = _clock_s(m["start_time"]), _clock_s(m["end_time"])
+        self.gain, self.trail_s, self.width = float(gain), float(trail_s), float(width_px)
+        self.small = SkyStream(self.H // 4, self.W // 4, seed, streak_period=10 ** 9)  # (no streaks of its own)
+        rng = np.random.default_rng(seed + 7)
+        self.dither = rng.integers(-3, 4, (self.H, self.W, 3), dtype=np.int16)
+        self.chan_gain = np.array([0.92, 1.0, 1.06], np.float32)
+        self.k = 0
+
+    def _head(self, t: float) -> np.ndarray:
+        u = min(max((t - self.t0) / (self.t1 - self.t0), 0.0), 1.0)
+        return self.p1 + (self.p2 - self.p1) * u
+
+    def next(self) -> np.ndarray:
+        """The next source frame, (H, W, 3) uint8 BGR: clip(rint(sky * channel gain) + dither), sky = the small frame blown up 4x
+        (+ the meteor where it is).  The gains are applied at the small resolution (the same values, a sixteenth of the work)."""
+        t = self.k / self.fps
+        base = self.small.next().astype(np.float32)
+        small3 = np.rint(base[..., None] * self.chan_gain).astype(np.int16)
+        img = np.repeat(np.repeat(small3, 4, 0), 4, 1)
+        img += self.dither
+        if self.t0 <= t < self.t1 + self.trail_s:
+            a, b = self._head(t - self.trail_s), self._head(t)
+            if t - self.trail_s < self.t0:
+                a = self.p1
+            pad = self.width + 2
+            lo = np.floor(np.minimum(a, b) - pad).astype(int)
+            hi = np.ceil(np.maximum(a, b) + pad).astype(int)
+            x_lo, y_lo, x_hi, y_hi = max(lo[0], 0), max(lo[1], 0), min(hi[0], self.W - 1), min(hi[1], self.H - 1)
+            yy, xx = np.mgrid[y_lo:y_hi + 1, x_lo:x_hi + 1]
+            d = b - a
+            dd = float(d @ d)
+            tt = np.clip(((xx - a[0]) * d[0] + (yy - a[1]) * d[1]) / dd, 0, 1) if dd > 0 else np.zeros(xx.shape)
+            dist = np.hypot(xx - (a[0] + tt * d[0]), yy - (a[1] + tt * d[1]))
+            # brightest at the head, fading along the trail
+            add = (self.gain * (0.45 + 0.55 * tt) * np.clip(self.width / 2 + 1 - dist, 0, 1)).astype(np.float32)
+            sky = base[yy // 4, xx // 4] + add
+            img[y_lo:y_hi + 1, x_lo:x_hi + 1] = (np.rint(sky[..., None] * self.chan_gain).astype(np.int16)
+                                                 + self.dither[y_lo:y_hi + 1, x_lo:x_hi + 1])
+        self.k += 1
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _clock_s(text: str) -> float:
+    h, m, s = text.split(":")
+    return int(h) * 3600 + int(m) * 60 + float(s)
