@@ -60,6 +60,16 @@ WORKLOADS = {
                      "restatement on the GPU) -> detector -> native collector"),
 }
 STREAK_PERIOD = 50  # SkyStream default: one streak per 50 frames
+# --stream: SkyStream arguments, the stream's period (the resident pool holds whole periods) and the detector preset it runs under
+STREAMS = {
+    "sky": dict(kw={}, period=50),
+    "noisy": dict(kw=dict(sigma=6.0), period=50, sensitivity="low"),
+    "hot": dict(kw=dict(hot_frac=0.01), period=50),
+    "cloud": dict(kw=dict(cloud_period=50), period=50),
+    "sparse": dict(kw=dict(streak_period=400), period=400),
+    "dense": dict(kw=dict(streak_period=24), period=24),
+}
+STREAM = "sky"
 
 
 def parse():
@@ -81,6 +91,9 @@ def parse():
                     "passes (4000 / 2000 / 1000 / 500 frames) are whole multiples of it, so a resubmitted pass CONTINUES the "
                     "stream (frame 249 -> frame 0 is seamless) instead of starting on a scene cut")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--stream", default="sky", choices=sorted(STREAMS), help="the synthetic stream's weather: sky = SURVEY 8d's friendly one "
+                    "(N(30, 2.5), one streak per 50 frames); noisy = sigma 6 under m3det_low (Hough 10 / 15 / 8); hot = 1 %% hot pixels; cloud = a "
+                    "cloud-edge frame every 50 frames (> 8192 lit pixels for n frames); sparse / dense = a streak in ~5 %% / ~80 %% of the frames")
     ap.add_argument("--mode", default="streams", choices=["streams", "bands", "timeshard"])
     ap.add_argument("--protocol", default="batch", choices=["batch", "per-frame"])
     ap.add_argument("--detector", default="m3", choices=["m3", "classic"], help="classic: the reference's second line detector "
@@ -118,8 +131,18 @@ def make_cfg():
     from metdetpy_amd import BinaryCfg, BinaryCoreCfg, DynamicCfg, HoughLineCfg
     if DETECTOR == "classic":  # fixed threshold (the oracle's ClassicOracle restates the detect() half of the class)
         return BinaryCfg(BinaryCoreCfg(False, CLASSIC_THRESHOLD, SENSITIVITY, 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
-    # config/m3det_normal.json (or m3det_high.json) detector block
-    return BinaryCfg(BinaryCoreCfg(True, 7, SENSITIVITY, 0.1, 2), HoughLineCfg(10, 10, 10), DynamicCfg(True, 5))
+    # config/m3det_normal.json (or m3det_high.json / m3det_low.json: the low preset's Hough block is 10 / 15 / 8) detector block
+    hough = HoughLineCfg(10, 15, 8) if SENSITIVITY == "low" else HoughLineCfg(10, 10, 10)
+    return BinaryCfg(BinaryCoreCfg(True, 7, SENSITIVITY, 0.1, 2), hough, DynamicCfg(True, 5))
+
+
+def oracle_detector(n, mask):
+    """The C port of the oracle under the same preset as make_cfg()."""
+    from metdetpy_amd.utils import select_std_roi
+    from oracle import c_oracle as co
+    c = make_cfg()
+    return co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY, hough_threshold=c.hough_line.threshold,
+                  hough_min_len=c.hough_line.min_len, hough_max_gap=c.hough_line.max_gap)
 
 
 def make_detector(n, mask, device, max_batch):
@@ -228,7 +251,7 @@ def cpu_baseline(frames, n, mask, seconds):
     by_threads = {}
     for th in teams:
         co.lib().om3_set_threads(th)
-        det = co.CM3(n, mask, roi, sensitivity=SENSITIVITY)
+        det = oracle_detector(n, mask)
 
         def step(f, det=det):
             det.update(f)
@@ -238,7 +261,9 @@ def cpu_baseline(frames, n, mask, seconds):
 
         done, dt = _time_detector(step, frames, warm, share, 4 * len(frames))
         by_threads[int(co.lib().om3_num_threads())] = dict(value=done / dt, frames=done)
-    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, sensitivity=SENSITIVITY)
+    c = make_cfg()
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, sensitivity=SENSITIVITY, hough_threshold=c.hough_line.threshold,
+                      hough_min_len=c.hough_line.min_len, hough_max_gap=c.hough_line.max_gap)
 
     def np_step(f):
         orc.update(f)
@@ -264,37 +289,75 @@ def parity_check(frames, n, mask, local, count, timed=None):
     "per_pass_equal": every timed pass gave the same tallies}: the timed region processes the stream's period over and over in
     its steady state (the threshold has settled, every window is full), so its tallies must be the oracle's tallies of one
     steady-state period times the number of periods -- checked here against the LAST whole period the oracle saw (count is
-    raised to three periods: the first two still carry the warm-up of the window and of the threshold's EMA)."""
-    period = len(frames)
-    if timed is not None and timed["frames"] % period == 0 and count > 0:
-        count = max(count, 3 * period)
+    raised to at least three periods -- the first two still carry the warm-up of the window and of the threshold's EMA -- and
+    then, a period at a time, until two consecutive periods of the oracle agree)."""
     from metdetpy_amd import M3Detector
     from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
-    if count > len(frames):  # (the resident period is shorter -- C5's 50 frames: the stream wraps seamlessly, and so does the check)
-        frames = frames[np.arange(count) % len(frames)]
-    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=count)
-    info, raw, nms, prob = det._ctx.process_batch(np.ascontiguousarray(frames[:count]))
-    det.close()
+    period = len(frames)
+    want_steady = timed is not None and timed["frames"] % period == 0 and count > 0
+    if want_steady:
+        count = max(count, 3 * period) // period * period
+    src = frames
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
-    orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY)
-    bad, segs, o_results, o_lines_num, o_lit = [], 0, [], [], []
-    for i in range(count):
-        orc.update(frames[i])
+    orc = oracle_detector(n, mask)
+    o_rows, o_results, o_lines_num, o_lit = [], [], [], []
+
+    def period_tally(k):  # oracle tallies of period k
+        lo = k * period
+        return [sum(o_lines_num[lo:lo + period]), sum(len(o_results[i][0]) for i in range(lo, lo + period)), sum(o_lit[lo:lo + period])]
+
+    i = 0
+    while i < count:
+        orc.update(src[i % period])
         o_raw = orc.detect()
+        o_rows.append((orc.state()[0], o_raw))
         o_results.append((np.zeros((0, 4), np.int32), np.zeros(0)))
         o_lines_num.append(int(orc.lines_num))
         o_lit.append(int(orc.lit_count))
-        thr = orc.state()[0]
-        ok = (int(info[i]["bi_threshold"]) == thr and int(info[i]["lit_count"]) == orc.lit_count
-              and int(info[i]["n_raw"]) == orc.lines_num
-              and np.array_equal(raw[i][:min(orc.lines_num, 512)], o_raw[:512]))
         if 0 < orc.lines_num <= 500:
-            o_nms, o_prob = co.lineset_nms(o_raw)
-            o_results[i] = (o_nms, o_prob)
+            o_results[i] = co.lineset_nms(o_raw)
+        i += 1
+        # the threshold's EMA takes a few hundred frames to settle (longer at n = 16: one update per 2n frames): the oracle goes
+        # on, a period at a time, until two consecutive periods agree -- the state the timed region runs in
+        if want_steady and i == count and count < 12 * period and period_tally(count // period - 1) != period_tally(count // period - 2):
+            count += period
+    # the parity detector also records what every frame's Hough replay cost (MDH_HOUGH_DEBUG: cycle stamps per frame of its one
+    # pass -- the instrumented instantiations are slower, which is why the timed detector never runs them)
+    had_dbg = os.environ.get("MDH_HOUGH_DEBUG")
+    os.environ["MDH_HOUGH_DEBUG"] = "1"
+    det = M3Detector(1, n, mask, 10, make_cfg(), None, device=local, max_batch=count)
+    if had_dbg is None:
+        del os.environ["MDH_HOUGH_DEBUG"]
+    info, raw, nms, prob = det._ctx.process_batch(np.ascontiguousarray(src[np.arange(count) % period]))
+    hough_cost = None
+    try:
+        import ctypes as C
+        dbg2 = np.zeros((2, count, 8), np.int64)
+        if det._ctx.L.mdh_debug_hough(C.c_void_p(det._ctx.handle), dbg2.ctypes.data_as(C.POINTER(C.c_longlong)), count) == 0:
+            pts, tier, us = dbg2[0][:, 0], dbg2[0][:, 1] & 0xFF, dbg2[0][:, 3] / 100.0
+            act = pts > 0
+            if act.any():
+                w = int(np.argmax(np.where(act, us, -1)))
+                hough_cost = {"frames_with_points": int(act.sum()), "replay_us_median": float(np.median(us[act])), "replay_us_p99": float(np.percentile(us[act], 99)),
+                              "slowest_frame": {"frame": w, "replay_us": float(us[w]), "points": int(pts[w]), "tier": int(tier[w]), "segments": int(info[w]["n_raw"])},
+                              "frames_by_tier": {str(int(k)): int((tier[act] == k).sum()) for k in np.unique(tier[act])},
+                              "max_points": int(pts.max()), "note": "per-frame replay time of the Hough stage from the kernels' own cycle stamps (MDH_HOUGH_DEBUG, "
+                              "100 MHz wall clock), over the parity leg's frames; tiers: 0 small LDS, 1 large LDS, 2 hybrid, 3 one wave (> 8192 points), 4 tiny"}
+    except Exception as e:  # noqa: BLE001
+        hough_cost = {"error": f"{type(e).__name__}: {e}"[:200]}
+    det.close()
+    bad, segs = [], 0
+    for i in range(count):
+        thr, o_raw = o_rows[i]
+        ok = (int(info[i]["bi_threshold"]) == thr and int(info[i]["lit_count"]) == o_lit[i]
+              and int(info[i]["n_raw"]) == o_lines_num[i]
+              and np.array_equal(raw[i][:min(o_lines_num[i], 512)], o_raw[:512]))
+        if 0 < o_lines_num[i] <= 500:
+            o_nms, o_prob = o_results[i]
             k = int(info[i]["n_nms"])
             ok = ok and k == len(o_nms) and np.array_equal(nms[i][:k], o_nms) and np.array_equal(prob[i][:k], o_prob)
-        segs += orc.lines_num
+        segs += o_lines_num[i]
         if not ok:
             bad.append(i)
     # the records a collector makes of them (config/m3det_normal.json's meteor_cfg, re-check off): GPU results through the
@@ -323,6 +386,8 @@ def parity_check(frames, n, mask, local, count, timed=None):
            "records_identical": rec_ok, "verdict": "identical" if not bad and rec_ok else "MISMATCH",
            "checked": "bi_threshold, lit_count, raw Hough segments (order included), lineset_nms output, collector records "
                       "vs oracle/metdet_oracle.c"}
+    if hough_cost is not None:
+        out["hough_frame_cost"] = hough_cost
     if timed is not None:
         if timed["frames"] % period or count < 3 * period:
             out["timed_region"] = {"verdict": "not checked", "why": "the timed region is not a whole number of stream periods"}
@@ -372,7 +437,7 @@ def parity_check_per_frame(frames, n, mask, local, count, kind):
     else:
         source = lambda k: frames[k].copy()
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
-    orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=SENSITIVITY)
+    orc = oracle_detector(n, mask)
     bad, segs = [], 0
     for i in range(count):
         det.update(source(i))
@@ -451,10 +516,11 @@ def make_stream_frames(wl, rank, mask, B, unique):
     number of streak periods, so that the stream is seamless where the resident batch repeats them."""
     from metdetpy_amd.synth import SkyStream
     H, W, n = wl["H"], wl["W"], wl["n"]
-    stream = SkyStream(H, W, wl["seed"] + rank, mask01=None if mask.all() else mask)
+    st = STREAMS[STREAM]
+    stream = SkyStream(H, W, wl["seed"] + rank, mask01=None if mask.all() else mask, **st["kw"])
     uniq = B if unique <= 0 else min(B, max(unique, 2 * n))
     if uniq < B:
-        uniq = max(STREAK_PERIOD, uniq // STREAK_PERIOD * STREAK_PERIOD)
+        uniq = max(st["period"], uniq // st["period"] * st["period"])
     return stream.take(uniq)
 
 
@@ -473,7 +539,7 @@ def pmc_traffic_live(a, dense, kern=None):
     if exe is None:
         return None, "rocprofv3 is not on PATH"
     kern = kern or ("k_classic_diff" if DETECTOR == "classic" else "k_stack_threshold")
-    base = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--batch", str(a.batch), "--unique", str(a.unique),
+    base = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--stream", a.stream, "--batch", str(a.batch), "--unique", str(a.unique),
             "--steps", "3", "--warmup", "1", "--passes-per-step", "1", "--no-secondary", "--depth", "1", "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0",
             "--no-profile", "--no-pmc", "--detector", a.detector, "--hough-mode", a.hough_mode]
     if a.sensitivity:
@@ -774,6 +840,14 @@ SECONDARY = [
     ("C3_4k_n16_mask", ["--workload", "C3", "--steps", "13", "--warmup", "2"]),
     ("C5_8k_high", ["--workload", "C5", "--unique", "50", "--steps", "13", "--warmup", "2"]),
     ("C1s_960x540", ["--workload", "C1s", "--steps", "17", "--warmup", "2"]),
+    # the unfriendly skies: 1080p, a 100-frame period (sparse: 400, dense: 96), parity + worst-frame replay time each
+    ("C2_noisy_sky_m3det_low", ["--stream", "noisy", "--unique", "100", "--steps", "6", "--warmup", "1"]),
+    ("C2_hot_pixels_1pct", ["--stream", "hot", "--unique", "100", "--steps", "6", "--warmup", "1"]),
+    ("C2_cloud_edge_every_50", ["--stream", "cloud", "--unique", "100", "--steps", "3", "--warmup", "1", "--passes-per-step", "16"]),
+    ("C2_streak_share_5pct", ["--stream", "sparse", "--unique", "400", "--steps", "6", "--warmup", "1"]),
+    ("C2_streak_share_80pct", ["--stream", "dense", "--unique", "96", "--batch", "3840", "--steps", "6", "--warmup", "1"]),
+    # BASELINE config 5 the way it is sharded (8 row bands), all bands on this one device: prices the tiling's bookkeeping
+    ("C5_8k_as_8_row_bands_one_gpu", ["--mode", "bands", "--workload", "C5", "--unique", "50", "--batch", "500", "--steps", "12", "--warmup", "3"]),
     ("per_frame_pinned", ["--protocol", "per-frame", "--frames", "pinned", "--steps", "12000"]),
     ("per_frame_recycled_ring", ["--protocol", "per-frame", "--frames", "recycled", "--steps", "12000"]),
     ("per_frame_pageable", ["--protocol", "per-frame", "--frames", "pageable", "--steps", "4000"]),
@@ -810,6 +884,7 @@ def run_secondary(a):
              "frac": rf.get("frac"), "frac_at_pipeline_pace": rf.get("frac_at_pipeline_pace"),
              "parity": (d.get("parity") or {}).get("verdict"), "parity_frames": (d.get("parity") or {}).get("frames_checked"),
              "timed_region_tallies": ((d.get("parity") or {}).get("timed_region") or {}).get("verdict"),
+             "hough_frame_cost": (d.get("parity") or {}).get("hough_frame_cost"),
              "wall_s": round(time.perf_counter() - t0, 1), "command": "python bench.py " + " ".join(cmd[2:])}
         if "per_frame" in d:
             e["per_frame"] = {k: d["per_frame"][k] for k in ("frames", "update_stats", "us_per_frame", "frames_by_kind", "frames_per_s_by_kind")}
@@ -823,8 +898,9 @@ def main():
     D = Dist()
     wl = WORKLOADS[a.workload]
     H, W, n = wl["H"], wl["W"], wl["n"]
-    global SENSITIVITY, DETECTOR, HOUGH_MODE
-    SENSITIVITY = a.sensitivity or wl.get("sensitivity", "normal")
+    global SENSITIVITY, DETECTOR, HOUGH_MODE, STREAM
+    STREAM = a.stream
+    SENSITIVITY = a.sensitivity or STREAMS[STREAM].get("sensitivity") or wl.get("sensitivity", "normal")
     DETECTOR = a.detector
     HOUGH_MODE = a.hough_mode
     if DETECTOR == "classic":
@@ -866,6 +942,8 @@ def main():
     if a.protocol == "per-frame":
         shape = f"update(frame) / detect() per frame from host memory (the reference's loop; frames: {a.frames}), one frame per step"
     desc = wl["desc"]
+    if STREAM != "sky":
+        desc += f", --stream {STREAM} ({json.dumps(STREAMS[STREAM]['kw'])})"
     if a.mode == "bands":  # (the workload's own text says "whole frame on one GPU (no row-band tiling)": not this run)
         desc = desc.replace(", whole frame on one GPU (no row-band tiling)", "")
     out = {

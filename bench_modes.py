@@ -21,10 +21,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 def _oracle_rows(frames, n, mask, sensitivity, count):
     """[(thr, lit, n_raw, raw)] of the first `count` frames from the C port of the oracle."""
-    from metdetpy_amd.utils import select_std_roi
+    import bench
     from oracle import c_oracle as co
     co.lib().om3_set_threads(min(32, len(os.sched_getaffinity(0))))
-    orc = co.CM3(n, mask, select_std_roi(mask, 0.1), sensitivity=sensitivity)
+    orc = bench.oracle_detector(n, mask)
     rows = []
     for f in frames[:count]:
         orc.update(f)
@@ -98,12 +98,14 @@ def run_bands(a, D, wl, mask, cfg):
     t0 = time.perf_counter()
     # two passes in flight: the Hough stage of pass p (queued, mdh_hough_planes_submit) runs under the band stages of pass p + 1
     queued = 0
+    collect_at = []  # wall time of every collect: a rate that ramps (allocations, clocks) shows here, a uniform one does not
     for s_ in range(steps + 1):
         if s_ < steps:
             submit()
             queued += 1
         if queued == 2 or (s_ == steps and queued):
             res, info = det.collect(arrays=True) if local_shared else det.collect()
+            collect_at.append(time.perf_counter() - t0)
             queued -= 1
             if info is not None and (res is not None or local_shared):
                 tally[0] += int(info["n_raw"].sum())
@@ -117,6 +119,9 @@ def run_bands(a, D, wl, mask, cfg):
                        else "device-to-device copies on one GPU (stand-in of the all-to-all), every band and every Hough context on this device",
                        "note": "per band and pass: noise share and pixel stages (blocking), the Hough stage of the assembled planes queued "
                                "and collected one pass later; one host thread per band when all bands share one process"}}
+    gaps = np.diff([0.0] + collect_at) * 1e3
+    extra["bands"]["ms_between_collects"] = {"first": float(gaps[0]), "median": float(np.median(gaps)), "max": float(gaps.max()),
+                                             "slowest_at_pass": int(np.argmax(gaps))}
     try:  # which output format the bands' window kernels ended up in (a band that could not allocate its plain buffer stays sparse)
         extra["bands"]["dense_format_bands"] = [bool(e.band.dense_now) for e in det.engines] if D.world == 1 else [bool(ctx.dense_now)]
     except Exception:  # noqa: BLE001

@@ -1667,10 +1667,22 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     sl.t_base = c->t;
     sl.dense = false;
     if (c->dense_now && c->cfg.detector == MDH_DET_M3 && c->role != MDH_ROLE_HOUGH && K > 1) {
-        if (!sl.d_bplain) {  // first dense pass on this slot (an allocation synchronises the device: once per slot)
-            if (hipMalloc((void**)&sl.d_bplain, sizeof(u64) * (size_t)c->Kmax * c->words) != hipSuccess) {
-                (void)hipGetLastError();
-                sl.d_bplain = nullptr;  // no memory for the second format: stay with the sparse one
+        if (!sl.d_bplain) {
+            // First dense pass of the context: the plain buffers of ALL its slots at once.  Round 4 allocated one per slot as the
+            // passes came by -- six allocations, each synchronising the device, spread over the first six dense passes (a timed
+            // region behind three warm-up passes still paid three of them, times eight contexts in the row-band bench); and on a
+            // box whose VRAM has not been handed out before, an allocation of gigabytes is slow (the driver wipes the pages it
+            // hands out; a later process gets pages the driver wiped in the background when the earlier one exited) -- the
+            // "first process on a fresh box runs the band bench at a quarter of the rate" of round 4.
+            for (int k = 0; k < c->nslot; ++k) {
+                Slot& o = c->slot[k];
+                if (o.d_bplain) continue;
+                if (hipMalloc((void**)&o.d_bplain, sizeof(u64) * (size_t)c->Kmax * c->words) != hipSuccess) {
+                    (void)hipGetLastError();
+                    o.d_bplain = nullptr;
+                }
+            }
+            if (!sl.d_bplain) {  // no memory for the second format: stay with the sparse one
                 c->dense_now = false;
                 c->dense_cfg = 0;
             }

@@ -16,7 +16,13 @@ class SkyStream:
 
     def __init__(self, H: int, W: int, seed: int, *, mu: float = 30.0, sigma: float = 2.5, n_stars: int = 200,
                  streak_period: int = 50, streak_life: int = 12, speed: float | None = None, streak_gain: float = 60.0,
-                 mask01: np.ndarray | None = None):
+                 mask01: np.ndarray | None = None, hot_frac: float = 0.0, cloud_period: int = 0, cloud_gain: float = 25.0,
+                 cloud_width: int | None = None):
+        """The unfriendly variants (bench.py --stream): `sigma` = 6 for a noisy sky; `hot_frac` of the pixels are hot (a fixed
+        offset of +40 .. +160 and three times the noise: they flicker over the threshold on their own); every `cloud_period`-th
+        frame carries a "cloud edge": a wavy strip `cloud_width` pixels wide across the whole frame, +`cloud_gain` for that one
+        frame -- more than 8192 lit pixels in the binaries of the n frames whose windows hold it.  All drawn after the stars and
+        before the streak, from the same generator, so the default stream (none of them) is unchanged."""
         self.H, self.W = H, W
         self.rng = np.random.default_rng(seed)
         self.mu, self.sigma = mu, sigma
@@ -33,6 +39,12 @@ class SkyStream:
             stars[y - 1:y + 2, x - 1:x + 2] += a * np.array([[.3, .6, .3], [.6, 1, .6], [.3, .6, .3]], np.float32)
         self.stars = stars
         self._streak = None
+        self.hot = None
+        if hot_frac > 0:
+            m = self.rng.random((H, W)) < hot_frac
+            self.hot = (m, self.rng.uniform(40, 160, int(m.sum())).astype(np.float32))
+        self.cloud_period, self.cloud_gain = int(cloud_period), float(cloud_gain)
+        self.cloud_width = int(cloud_width) if cloud_width else max(3, -(-11520 // W))  # (> 8192 lit pixels whatever the width)
 
     def _new_streak(self):
         ang = self.rng.uniform(0, 2 * np.pi)
@@ -62,6 +74,16 @@ class SkyStream:
     def next(self) -> np.ndarray:
         img = self.rng.standard_normal((self.H, self.W), dtype=np.float32) * np.float32(self.sigma) + np.float32(self.mu)
         img += self.stars
+        if self.hot is not None:
+            m, off = self.hot
+            img[m] += off + self.rng.standard_normal(len(off), dtype=np.float32) * np.float32(2 * self.sigma)
+        if self.cloud_period and self.t % self.cloud_period == self.cloud_period // 2:
+            xs = np.arange(self.W)
+            y0 = self.rng.uniform(0.25, 0.75) * self.H
+            ys = np.rint(y0 + 0.08 * self.H * np.sin(xs / self.W * 2 * np.pi * self.rng.uniform(1, 3) + self.rng.uniform(0, 6))).astype(int)
+            for d in range(self.cloud_width):
+                yy = np.clip(ys + d, 0, self.H - 1)
+                img[yy, xs] += np.float32(self.cloud_gain)
         if self.t % self.period == self.period // 5:
             self._new_streak()
         if self._streak is not None:

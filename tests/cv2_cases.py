@@ -7,6 +7,8 @@ Every OpenCV call site of the hot path is covered (a
     cv2.absdiff           Detector.py:266-284    cv2.HoughLinesP        Detector.py:347-353, 289-293
     cv2.cvtColor          imgproc.py:87-88       cv2.resize             imgproc.py:82-85, fileio.py:250-292
 """
+import functools
+
 import numpy as np
 
 STENCIL_SHAPES = [(1, 1), (1, 7), (7, 1), (2, 2), (5, 9), (37, 53), (64, 64), (135, 241)]
@@ -35,7 +37,11 @@ def _draw_line(img, x0, y0, x1, y1, width=1):
         img[ys[ok] + d, xs[ok]] = 255
 
 
-HOUGH_PARAMS = [(10, 10, 10.0), (10, 15, 8.0), (10, 10, 0.0), (25, 30, 3.0), (1, 0, 0.0), (10, 10, 4.37)]  # threshold, minLineLength, maxLineGap
+# threshold, minLineLength, maxLineGap.  2.5 / 3.5 / 0.5: HoughLinesP takes cvRound(maxLineGap), which rounds halves to EVEN
+# (2, 4, 0) -- and M3Detector hands it a float (Detector.py:343-353: max(0, 1 - dst_sum / 0.05) * max_gap), so the tie rule is
+# live on the hot path; the "dashes_halves" image below has dashes 2, 3 and 4 pixels apart, so each rounding gives other segments
+HOUGH_PARAMS = [(10, 10, 10.0), (10, 15, 8.0), (10, 10, 0.0), (25, 30, 3.0), (1, 0, 0.0), (10, 10, 4.37), (10, 10, 2.5), (10, 10, 3.5),
+                (10, 10, 0.5)]
 
 
 def hough_inputs():
@@ -66,6 +72,13 @@ def hough_inputs():
     img = new(270, 480)
     img[rng.random(img.shape) < 0.01] = 255
     out.append(("noise", img))
+    img = new(80, 360)
+    for row, gap in ((10, 1), (25, 2), (40, 3), (55, 4), (70, 5)):
+        x = 3
+        while x + 7 < 360:
+            img[row, x:x + 7] = 255
+            x += 7 + gap
+    out.append(("dashes_halves", img))
     img = new(120, 200)
     img[rng.random(img.shape) < 0.12] = 255
     out.append(("dense", img))
@@ -99,26 +112,59 @@ def hough_inputs():
     return out
 
 
-COLOR_SHAPES = [(2, 2), (67, 131), (270, 480), (216, 384), (540, 960)]
+COLOR_SHAPES = [(2, 2), (67, 131), (270, 480), (216, 384), (540, 960), (4, 4096), (432, 768)]
 RESIZES = {  # src (h, w) -> dsizes (w, h)
     (67, 131): [(131, 67), (65, 33), (40, 21), (262, 134), (100, 100)],
     (270, 480): [(240, 135), (120, 68), (96, 54), (480, 270), (333, 187)],
     (216, 384): [(96, 54), (192, 108), (384, 216)],
     (540, 960): [(480, 270), (240, 135), (958, 539)],
     (2, 2): [(1, 1), (4, 4), (3, 5)],
+    (4, 4096): [(1024, 1)],      # the contested triples through a 4:1 reduction as well
+    (432, 768): [(192, 108)],    # 4:1 in both directions, the reduction of config 1 (3840x2160 -> resize 960)
 }
+
+
+@functools.lru_cache(maxsize=1)
+def contested_gray_triples():
+    """All (b, g, r) with b a multiple of 2 for which the two candidate coefficient sets of cv2.cvtColor(BGR2GRAY) on u8 disagree:
+    15-bit (3735, 19235, 9798; + 2^14 >> 15 -- OpenCV 4.x's RGB2Gray<uchar>, what oracle/m3_oracle.py and the HIP kernel use) vs
+    14-bit (1868, 9617, 4899; + 2^13 >> 14 -- OpenCV 2.x / 3.x, and what SURVEY App. A.12 recalled).  A pinned answer on these
+    pixels says which one a given OpenCV build runs; an image of random pixels could agree with both by accident."""
+    v = np.arange(0, 256, dtype=np.int32)
+    b, g, r = np.meshgrid(v[::2], v, v, indexing="ij")
+    g15 = (b * 3735 + g * 19235 + r * 9798 + 16384) >> 15
+    g14 = (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14
+    sel = np.flatnonzero((g15 != g14).ravel())
+    tri = np.stack([b.ravel()[sel], g.ravel()[sel], r.ravel()[sel]], axis=1).astype(np.uint8)
+    return tri
 
 
 def color_inputs():
     rng = np.random.default_rng(9003)
     out = []
     for (h, w) in COLOR_SHAPES:
+        if (h, w) == (4, 4096):  # every pixel is one on which the 15-bit and the 14-bit gray coefficients disagree
+            tri = contested_gray_triples()
+            assert len(tri) >= h * w, len(tri)
+            out.append((f"bgr_{h}x{w}", np.ascontiguousarray(tri[:h * w].reshape(h, w, 3))))
+            continue
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         if h >= 60:  # some smooth structure as well, so that the bilinear taps matter
             yy, xx = np.mgrid[:h, :w]
             img[..., 1] = ((np.sin(xx / 7.0) + np.cos(yy / 5.0) + 2) * 60).astype(np.uint8)
         out.append((f"bgr_{h}x{w}", img))
     return out
+
+
+CLASSIC = dict(H=135, W=240, frames=12, seed=9004, thresholds=[12, 20], hough=(10, 10, 10))
+
+
+def classic_frames():
+    """A small sky with a fast streak for the ClassicDetector chain (Detector.py:257-296: four frames, absdiff / threshold / dilate /
+    255 - x / bitwise_and / HoughLinesP)."""
+    from metdetpy_amd.synth import SkyStream
+    C = CLASSIC
+    return SkyStream(C["H"], C["W"], C["seed"], speed=9, streak_period=6, streak_life=5, n_stars=30).take(C["frames"])
 
 
 M3_STREAM = dict(H=270, W=480, n=8, seed=20220413, frames=70, speed=10, streak_period=30, sensitivities=["normal", "high", "low"])

@@ -79,6 +79,29 @@ def check_color(z, gray_fn, resize_fn):
             assert np.array_equal(gray_fn(r), z[f"{name}/gray_of_resize_{w}x{h}"]), (name, w, h)
 
 
+def check_classic(z, detect):
+    """detect(frames[t-3 .. t], T) -> (dst u8, lines) for every four-frame window of the seeded frames."""
+    frames = cases.classic_frames()
+    n = 0
+    for T in cases.CLASSIC["thresholds"]:
+        for t in range(3, len(frames)):
+            dst, lines = detect(frames[t - 3:t + 1], T)
+            assert np.array_equal(np.packbits(dst > 0, axis=1), z[f"T{T}/{t}/dst"]), (T, t, "dst")
+            assert np.array_equal(np.asarray(lines, np.int32).reshape(-1, 4), z[f"T{T}/{t}/lines"]), (T, t, "lines")
+            n += len(z[f"T{T}/{t}/lines"])
+    return n
+
+
+def oracle_classic(window, T):
+    thr_h, min_len, gap = cases.CLASSIC["hough"]
+    orc = mo.ClassicOracle(np.ones(window[0].shape, np.uint8), threshold=T, hough_threshold=thr_h, hough_min_len=min_len,
+                           hough_max_gap=gap, hough_fn=co.hough_lines_p)
+    for f in window:
+        orc.update(f)
+    lines, _ = orc.detect()
+    return orc.dst, lines
+
+
 def m3_series(z, tag, sens, step):
     """Drive `step(frame) -> (lines, cls_pred, bi_threshold, lines_num, dst_sum, dst or None)` over the seeded stream."""
     from metdetpy_amd.synth import SkyStream
@@ -114,6 +137,32 @@ def test_oracle_cvtcolor_and_resize_equal_cv2():
     check_color(pinned("color"), mo.bgr_to_gray, mo.resize_linear)
 
 
+def test_oracle_classic_chain_equals_cv2():
+    assert check_classic(pinned("classic"), oracle_classic) > 0
+
+
+def test_contested_gray_triples_really_separate_the_two_coefficient_sets():
+    """(No fixture needed.)  The pinned colour case "bgr_4x4096" consists of pixels on which OpenCV 4.x's 15-bit BGR2GRAY and the
+    14-bit set of 2.x / 3.x (what SURVEY App. A.12 recalled) give DIFFERENT grays: whichever cv2 runs tools/pin_cv2.py settles it."""
+    tri = cases.contested_gray_triples()
+    assert len(tri) >= 4 * 4096
+    b, g, r = (tri[:, k].astype(np.int64) for k in range(3))
+    g14 = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    assert not np.any(mo.bgr_to_gray(tri[None])[0] == g14)
+    name, img = [c for c in cases.color_inputs() if c[0] == "bgr_4x4096"][0]
+    assert img.shape == (4, 4096, 3) and np.array_equal(img.reshape(-1, 3), tri[:4 * 4096])
+
+
+def test_half_gaps_change_the_segments():
+    """(No fixture needed.)  The fractional maxLineGap cases are live: cvRound(2.5) = 2 and cvRound(3.5) = 4 (halves to even) give
+    other segments on "dashes_halves" than rounding halves up (3, 4) would -- so a pinned answer tells the two rules apart."""
+    img = dict(cases.hough_inputs())["dashes_halves"]
+    assert (mo.cv_round(2.5), mo.cv_round(3.5), mo.cv_round(0.5), mo.cv_round(4.37)) == (2, 4, 0, 4)
+    seg = {g: co.hough_lines_p(img, 1, np.pi / 180.0, 10, 10, g) for g in (2.0, 2.5, 3.0, 3.5, 4.0)}
+    assert np.array_equal(seg[2.5], seg[2.0]) and not np.array_equal(seg[2.5], seg[3.0])
+    assert np.array_equal(seg[3.5], seg[4.0]) and not np.array_equal(seg[3.5], seg[3.0])
+
+
 @pytest.mark.parametrize("sens", cases.M3_STREAM["sensitivities"])
 def test_oracle_m3_detector_equals_reference(sens):
     z = pinned("m3")
@@ -142,6 +191,7 @@ def oracle_backed_cv2():
     m.erode = lambda img, k: co.erode3(img)
     m.dilate = lambda img, k: co.dilate3(img)
     m.absdiff = mo.absdiff
+    m.bitwise_and = np.bitwise_and
     m.cvtColor = lambda img, code: mo.bgr_to_gray(img)
     m.resize = lambda img, dsize, interpolation=None: mo.resize_linear(img, dsize)
 
@@ -156,7 +206,8 @@ def oracle_backed_cv2():
 def test_pin_script_round_trip(tmp_path):
     import pin_cv2
     written = pin_cv2.generate(str(tmp_path), oracle_backed_cv2())
-    assert written == ["g9_cv2_stencil.npz", "g9_cv2_hough.npz", "g9_cv2_color.npz"]
+    assert written == ["g9_cv2_stencil.npz", "g9_cv2_hough.npz", "g9_cv2_color.npz", "g9_cv2_classic.npz"]
+    assert check_classic(pinned("classic", str(tmp_path)), oracle_classic) > 0
     assert check_stencil(pinned("stencil", str(tmp_path)), mo.median_blur3, mo.morph_close3, mo.erode3, mo.dilate3) == len(cases.stencil_inputs())
     assert check_hough(pinned("hough", str(tmp_path)), lambda im, thr, ml, gap: co.hough_lines_p(im, 1, np.pi / 180.0, thr, ml, gap)) == \
         len(cases.hough_inputs()) * len(cases.HOUGH_PARAMS)
@@ -204,6 +255,23 @@ def test_hip_preprocessing_equals_cv2():
             p.close()
 
 
+def hip_classic(window, T):
+    from metdetpy_amd import ClassicDetector
+    thr_h, min_len, gap = cases.CLASSIC["hough"]
+    det = ClassicDetector(1, 4.0, np.ones(window[0].shape, np.uint8), 10, binary_cfg(adaptive=False, init_value=T, hough=(thr_h, min_len, gap)), None)
+    for f in window:
+        det.update(f)
+        lines, _ = det.detect()
+    dst = det.dst
+    det.close()
+    return dst, lines
+
+
+@pytest.mark.gpu
+def test_hip_classic_chain_equals_cv2():
+    assert check_classic(pinned("classic"), hip_classic) > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sens", cases.M3_STREAM["sensitivities"])
 def test_hip_m3_detector_equals_reference(sens):
@@ -229,7 +297,13 @@ def test_hip_round_trip_through_the_stand_in(tmp_path):
     from metdetpy_amd.imgproc import Preprocessor
     pin_cv2.generate(str(tmp_path), oracle_backed_cv2())
     assert check_hough(pinned("hough", str(tmp_path)), hip_hough, names={"fan", "dashed", "streaks", "segments", "single", "empty"}) > 0
+    assert check_classic(pinned("classic", str(tmp_path)), hip_classic) > 0
     z = pinned("color", str(tmp_path))
+    for name, img in [c for c in cases.color_inputs() if c[0] in ("bgr_4x4096", "bgr_432x768")]:  # the two contested spots
+        for (w, h) in cases.RESIZES[img.shape[:2]]:
+            p = Preprocessor(img.shape[:2], (w, h))
+            assert np.array_equal(p(img), z[f"{name}/gray_of_resize_{w}x{h}"]), (name, w, h)
+            p.close()
     name, img = cases.color_inputs()[2]
     for (w, h) in cases.RESIZES[img.shape[:2]]:
         p = Preprocessor(img.shape[:2], (w, h))

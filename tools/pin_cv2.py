@@ -5,13 +5,16 @@ reference's requirement; never needed on the GPU box):
     python tools/pin_cv2.py                                  # the cv2 operators on the seeded inputs of tests/cv2_cases.py
     python tools/pin_cv2.py --reference /path/to/MetDetPy    # ... and the reference's own M3Detector / ClassicDetector
 
-It writes tests/golden/g9_cv2_{stencil,hough,color,m3}.npz + g9_cv2_meta.json (inputs are regenerated from seeds by the tests,
+It writes tests/golden/g9_cv2_{stencil,hough,color,classic,m3}.npz + g9_cv2_meta.json (inputs are regenerated from seeds by the tests,
 only what cv2 / the reference RETURNED is stored).  With those files present, tests/test_cv2_pinned.py stops skipping with
 "PARITY UNPINNED" and checks the CPU oracle -- and, under -m gpu, the HIP path -- against them bit for bit:
 
     cv2.medianBlur / threshold / morphologyEx(MORPH_CLOSE) / erode / dilate / absdiff      Detector.py:184, 241, 266-288, 329-335
     cv2.HoughLinesP(img, 1, pi/180, thr, minLineLength, maxLineGap)                        Detector.py:289-293, 347-353
     cv2.cvtColor(BGR2GRAY), cv2.resize(INTER_LINEAR)                                       imgproc.py:82-88, fileio.py:250-292
+    ClassicDetector.detect's cv2 call sequence on four-frame windows (dst, lines)           Detector.py:257-296
+    the two contested spots: BGR2GRAY on pixels where the 15-bit and the 14-bit coefficient sets differ; 4:1 INTER_LINEAR
+    HoughLinesP with maxLineGap at .5 (cvRound: half to even)                               Detector.py:343-353
     M3Detector.update / detect series (threshold, dst, lines, cls_pred)                     Detector.py:302-392
 
 `generate(outdir, cv2)` takes the module as an argument so that the file formats can be exercised without OpenCV (the tests feed
@@ -69,6 +72,27 @@ def pin_color(cv2):
     return out
 
 
+def pin_classic(cv2):
+    """ClassicDetector.detect's own sequence of cv2 calls (Detector.py:257-296), frame by frame on the seeded frames: the
+    reference's class is not needed for it, only cv2."""
+    out = {}
+    k3 = cv2.getStructuringElement(cv2.MORPH_RECT, (3, 3))
+    frames = cases.classic_frames()
+    thr_h, min_len, gap = cases.CLASSIC["hough"]
+    for T in cases.CLASSIC["thresholds"]:
+        for t in range(3, len(frames)):
+            f0, f1, f2, f3 = frames[t], frames[t - 1], frames[t - 2], frames[t - 3]  # f0 newest
+            _, d = cv2.threshold(cv2.absdiff(f1, f0), T, 255, cv2.THRESH_BINARY)
+            d = 255 - cv2.dilate(d, k3)
+            a, b = cv2.bitwise_and(d, f3), cv2.bitwise_and(d, f2)
+            _, dst = cv2.threshold(cv2.absdiff(a, b), T, 255, cv2.THRESH_BINARY)
+            dst = cv2.dilate(dst, k3)
+            res = cv2.HoughLinesP(dst, 1, np.pi / 180.0, thr_h, minLineLength=min_len, maxLineGap=gap)
+            out[f"T{T}/{t}/dst"] = np.packbits(dst > 0, axis=1)
+            out[f"T{T}/{t}/lines"] = np.zeros((0, 4), np.int32) if res is None else np.asarray(res, np.int32).reshape(-1, 4)
+    return out
+
+
 def pin_m3(reference):
     """The reference's own detectors on the seeded synthetic sky (needs the reference's full environment)."""
     sys.path.insert(0, reference)
@@ -100,7 +124,7 @@ def pin_m3(reference):
 def generate(outdir, cv2, reference=None):
     os.makedirs(outdir, exist_ok=True)
     written = []
-    for tag, fn in (("stencil", pin_stencil), ("hough", pin_hough), ("color", pin_color)):
+    for tag, fn in (("stencil", pin_stencil), ("hough", pin_hough), ("color", pin_color), ("classic", pin_classic)):
         np.savez_compressed(os.path.join(outdir, f"g9_cv2_{tag}.npz"), **fn(cv2))
         written.append(f"g9_cv2_{tag}.npz")
     if reference:
