@@ -289,8 +289,8 @@ def parity_check(frames, n, mask, local, count, timed=None):
     "per_pass_equal": every timed pass gave the same tallies}: the timed region processes the stream's period over and over in
     its steady state (the threshold has settled, every window is full), so its tallies must be the oracle's tallies of one
     steady-state period times the number of periods -- checked here against the LAST whole period the oracle saw (count is
-    raised to at least three periods -- the first two still carry the warm-up of the window and of the threshold's EMA -- and
-    then, a period at a time, until two consecutive periods of the oracle agree)."""
+    raised to at least three periods -- the first two still carry the warm-up of the window and of the threshold's EMA; see
+    below for how the oracle gets from there to the timed region)."""
     from metdetpy_amd import M3Detector
     from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
@@ -298,6 +298,7 @@ def parity_check(frames, n, mask, local, count, timed=None):
     want_steady = timed is not None and timed["frames"] % period == 0 and count > 0
     if want_steady:
         count = max(count, 3 * period) // period * period
+        want_steady = timed["warm_frames"] >= count  # (the timed region must lie beyond what the oracle runs through frame by frame)
     src = frames
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))
     orc = oracle_detector(n, mask)
@@ -318,10 +319,38 @@ def parity_check(frames, n, mask, local, count, timed=None):
         if 0 < orc.lines_num <= 500:
             o_results[i] = co.lineset_nms(o_raw)
         i += 1
-        # the threshold's EMA takes a few hundred frames to settle (longer at n = 16: one update per 2n frames): the oracle goes
-        # on, a period at a time, until two consecutive periods agree -- the state the timed region runs in
-        if want_steady and i == count and count < 12 * period and period_tally(count // period - 1) != period_tally(count // period - 2):
-            count += period
+    steady = None
+    if want_steady:
+        # Where does the threshold stand in the TIMED region, millions of frames into the stream?  Its EMA keeps creeping for
+        # thousands of frames (4K, n = 16: T = 10 from frame 500 to frame 1500, 11 later), so the oracle's third period is not
+        # "the steady state".  The stream is periodic, so the oracle's own scalar chain can be carried on without pixels: the
+        # sigma of a due frame depends on t mod period only (oracle/m3_oracle.py: threshold_far_into_a_periodic_stream, bit-identical
+        # to running the detector through every frame -- tests/test_oracle_golden.py).  The pixel oracle then runs two more periods
+        # at that threshold (fixed-threshold mode: the second one is tallied) unless its last period was already there.
+        from oracle import m3_oracle as mo
+        c_ = make_cfg()
+        t_first, t_last = timed["warm_frames"] + 1, timed["warm_frames"] + timed["frames"]
+        thr_set, snr_end = mo.threshold_far_into_a_periodic_stream(src, n, select_std_roi(mask, 0.1), c_.binary.interval, SENSITIVITY, count,
+                                                                   orc.state()[2], t_first, t_last)
+        steady = {"thresholds_in_timed_region": thr_set, "oracle_snr_at_its_end": snr_end}
+        last = range(count - period, count)
+        if len(thr_set) == 1 and all(o_rows[i][0] == thr_set[0] for i in last):
+            steady["tally"] = period_tally(count // period - 1)
+            steady["from"] = "the oracle's last whole period (already at that threshold)"
+        elif len(thr_set) == 1:
+            fx = co.CM3(n, mask, select_std_roi(mask, 0.1), adaptive=False, init_value=thr_set[0], hough_threshold=c_.hough_line.threshold,
+                        hough_min_len=c_.hough_line.min_len, hough_max_gap=c_.hough_line.max_gap)
+            tl = [0, 0, 0]
+            for i2 in range(2 * period):
+                fx.update(src[i2 % period])
+                r2 = fx.detect()
+                if i2 >= period:
+                    tl[0] += int(fx.lines_num)
+                    tl[2] += int(fx.lit_count)
+                    if 0 < fx.lines_num <= 500:
+                        tl[1] += len(co.lineset_nms(r2)[0])
+            steady["tally"] = tl
+            steady["from"] = f"a second oracle detector held at T = {thr_set[0]} (fixed-threshold mode), its second period"
     # the parity detector also records what every frame's Hough replay cost (MDH_HOUGH_DEBUG: cycle stamps per frame of its one
     # pass -- the instrumented instantiations are slower, which is why the timed detector never runs them)
     had_dbg = os.environ.get("MDH_HOUGH_DEBUG")
@@ -389,21 +418,21 @@ def parity_check(frames, n, mask, local, count, timed=None):
     if hough_cost is not None:
         out["hough_frame_cost"] = hough_cost
     if timed is not None:
-        if timed["frames"] % period or count < 3 * period:
+        if steady is None:
             out["timed_region"] = {"verdict": "not checked", "why": "the timed region is not a whole number of stream periods"}
+        elif "tally" not in steady:
+            out["timed_region"] = {"verdict": "not checked", "why": "the oracle's threshold changes inside the timed region", **steady}
         else:
-            lo = (count // period - 1) * period  # the last whole period the oracle saw
-            per = [sum(o_lines_num[lo:lo + period]), sum(len(o_results[i][0]) for i in range(lo, lo + period)), sum(o_lit[lo:lo + period])]
-            prev = [sum(o_lines_num[lo - period:lo]), sum(len(o_results[i][0]) for i in range(lo - period, lo)), sum(o_lit[lo - period:lo])]
             periods = timed["frames"] // period
-            want = [v * periods for v in per]
-            ok = want == list(timed["tally"]) and timed.get("per_pass_equal", True) and per == prev
-            out["timed_region"] = {"periods": periods, "frames": timed["frames"], "oracle_tally_per_period": per,
-                                   "oracle_steady": per == prev, "expected_tally": want, "gpu_tally": list(timed["tally"]),
+            want = [v * periods for v in steady["tally"]]
+            ok = want == list(timed["tally"]) and timed.get("per_pass_equal", True)
+            out["timed_region"] = {"periods": periods, "frames": timed["frames"], "first_frame": timed["warm_frames"] + 1,
+                                   "oracle_threshold": steady["thresholds_in_timed_region"][0], "oracle_tally_per_period": steady["tally"],
+                                   "oracle_tally_from": steady["from"], "expected_tally": want, "gpu_tally": list(timed["tally"]),
                                    "gpu_every_pass_equal": bool(timed.get("per_pass_equal", True)),
                                    "verdict": "identical" if ok else "MISMATCH",
-                                   "checked": "[raw segments, NMS segments, lit pixels] summed over every frame of the timed region == "
-                                              "the oracle's tallies of one steady-state period x the number of periods"}
+                                   "checked": "[raw segments, NMS segments, lit pixels] summed over every frame of the timed region == the "
+                                              "oracle's tallies of one period at the threshold ITS OWN scalar chain reaches there x the number of periods"}
             if not ok:
                 out["verdict"] = "MISMATCH"
     return out
@@ -722,7 +751,7 @@ def run_streams(a, D, wl, mask):
     D.fence()
     segs, kept, lit = tally
     dt = time.perf_counter() - t0
-    timed = {"tally": [segs, kept, lit], "frames": steps * P * B, "per_pass_equal": len(passes_seen) == 1}
+    timed = {"tally": [segs, kept, lit], "frames": steps * P * B, "per_pass_equal": len(passes_seen) == 1, "warm_frames": a.warmup * P * B}
     prof = {}
     if not a.no_profile and D.rank == 0:
         # the kernels' spans INSIDE the pipeline (overlapping each other, queueing included): the same pipelined passes again,
@@ -837,7 +866,7 @@ def run_per_frame(a, D, wl, mask):
 
 SECONDARY = [
     # (name, extra arguments): each >= 1 s timed at the rates of profiles/, parity on 64 frames, no CPU baseline, no PMC leg
-    ("C3_4k_n16_mask", ["--workload", "C3", "--steps", "13", "--warmup", "2"]),
+    ("C3_4k_n16_mask", ["--workload", "C3", "--unique", "100", "--steps", "13", "--warmup", "2"]),
     ("C5_8k_high", ["--workload", "C5", "--unique", "50", "--steps", "13", "--warmup", "2"]),
     ("C1s_960x540", ["--workload", "C1s", "--steps", "17", "--warmup", "2"]),
     # the unfriendly skies: 1080p, a 100-frame period (sparse: 400, dense: 96), parity + worst-frame replay time each

@@ -297,3 +297,29 @@ def test_bgr2gray_and_resize_kat():
     want = (img.reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(2, 2, 4).astype(int).sum(-1) + 2) >> 2
     assert np.array_equal(half, want)
     assert np.array_equal(mo.resize_linear(img, (4, 4)), img)
+
+
+def test_threshold_far_into_a_periodic_stream_equals_running_every_frame():
+    """bench.py checks the tallies of its timed region -- millions of frames into a periodic stream -- against the oracle; the
+    threshold in force there comes from the oracle's scalar chain carried on WITHOUT pixels (the sigma of a due frame depends on
+    t mod period only).  That shortcut must be the detector itself: same snr bit for bit, same thresholds, as the C port run
+    through every frame."""
+    from metdetpy_amd.synth import SkyStream
+    from metdetpy_amd.utils import select_std_roi
+    H, W, n, P = 108, 192, 8, 50
+    frames = SkyStream(H, W, 5, speed=4).take(P)
+    mask = np.ones((H, W), np.uint8)
+    roi = select_std_roi(mask, 0.1)
+    for sens in ("normal", "high"):
+        orc = co.CM3(n, mask, roi, sensitivity=sens)
+        snap, thr_in = {}, {}
+        for t in range(1, 16 * P + 1):
+            orc.update(frames[(t - 1) % P])
+            st = orc.state()
+            thr_in.setdefault((t - 1) // P, set()).add(st[0])
+            if t % P == 0:
+                snap[t] = st
+        for t_from, a, b in ((3 * P, 3 * P + 1, 4 * P), (3 * P, 9 * P + 1, 12 * P), (5 * P, 12 * P + 1, 16 * P)):
+            got, v = mo.threshold_far_into_a_periodic_stream(frames, n, roi, 2, sens, t_from, snap[t_from][2], a, b)
+            want = sorted(set().union(*[thr_in[k] for k in range((a - 1) // P, (b - 1) // P + 1)]))
+            assert got == want and v == snap[b][2], (sens, t_from, a, b, got, want, v, snap[b][2])
