@@ -923,6 +923,7 @@ def run_secondary(a):
 
 
 def main():
+    sys.modules.setdefault("bench", sys.modules[__name__])  # (bench_modes does `import bench`: the module this script runs as, not a second copy)
     a = parse()
     D = Dist()
     wl = WORKLOADS[a.workload]

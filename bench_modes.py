@@ -19,12 +19,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def _oracle_rows(frames, n, mask, sensitivity, count):
-    """[(thr, lit, n_raw, raw)] of the first `count` frames from the C port of the oracle."""
-    import bench
+def _oracle_rows(frames, n, mask, cfg, count):
+    """[(thr, lit, n_raw, raw)] of the first `count` frames from the C port of the oracle under the detector preset `cfg`."""
+    from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
     co.lib().om3_set_threads(min(32, len(os.sched_getaffinity(0))))
-    orc = bench.oracle_detector(n, mask)
+    # (the preset travels as an argument: `import bench` here is a second copy of the module the script runs as __main__,
+    # whose globals -- SENSITIVITY -- were never set)
+    orc = co.CM3(n, mask, select_std_roi(mask, cfg.binary.area), sensitivity=cfg.binary.sensitivity, interval=cfg.binary.interval,
+                 hough_threshold=cfg.hough_line.threshold, hough_min_len=cfg.hough_line.min_len, hough_max_gap=cfg.hough_line.max_gap)
     rows = []
     for f in frames[:count]:
         orc.update(f)
@@ -128,7 +131,7 @@ def run_bands(a, D, wl, mask, cfg):
         pass
     if D.rank == 0 and a.parity_frames > 0 and first[0] is not None:
         cnt = min(a.parity_frames, 16, B)
-        extra["parity"] = _parity(_oracle_rows(frames[idx[:cnt]], n, mask, cfg.binary.sensitivity, cnt), first[1], first[0], f"the {nb}-band detector")
+        extra["parity"] = _parity(_oracle_rows(frames[idx[:cnt]], n, mask, cfg, cnt), first[1], first[0], f"the {nb}-band detector")
     det.close()
     return dict(frames=steps * B, dt=dt_all, steps=steps, tot=tally, prof={}, prof_alone={}, frames_sample=None, B=B, uniq=uniq, extra=extra)
 
@@ -270,7 +273,7 @@ def run_timeshard(a, D, wl, mask, cfg):
         tally = [int(info["n_raw"].sum()), int(info["n_nms"].sum()), int(info["lit_count"].sum())]
         if a.parity_frames > 0:
             cnt = min(a.parity_frames, 64, total)
-            extra["parity"] = _parity(_oracle_rows(first, n, mask, cfg.binary.sensitivity, cnt), info, results, "the time-sharded detector")
+            extra["parity"] = _parity(_oracle_rows(first, n, mask, cfg, cnt), info, results, "the time-sharded detector")
     return dict(frames=total, dt=dt_all, steps=steps, tot=tally, prof={}, prof_alone={}, frames_sample=None, B=B, uniq=uniq, extra=extra)
 
 
@@ -370,7 +373,7 @@ def run_c1e(a, D, wl, mask, cfg):
         from oracle import m3_oracle as mo
         cnt = min(a.parity_frames, 24, uniq)
         gray = np.stack([mo.preprocess_frame(clip[k], (W, H), mask) for k in range(cnt)])
-        extra["parity"] = _parity(_oracle_rows(gray, n, mask, cfg.binary.sensitivity, cnt), first["info"],
+        extra["parity"] = _parity(_oracle_rows(gray, n, mask, cfg, cnt), first["info"],
                                   [(first["nms"][i][:int(first["info"][i]["n_nms"])],
                                     np.concatenate([np.zeros((int(first["info"][i]["n_nms"]), 9)), first["prob"][i][:int(first["info"][i]["n_nms"]), None]], 1))
                                    for i in range(cnt)], "BGR clip -> oracle loader chain (resize, gray, mask) -> oracle detector")

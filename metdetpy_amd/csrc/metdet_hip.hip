@@ -379,6 +379,13 @@ extern "C" int64_t mdh_dense_passes(const mdh_ctx* c) { return c ? c->dense_pass
 extern "C" double mdh_last_density(const mdh_ctx* c) { return c ? c->last_density : -1; }
 extern "C" int mdh_dense_now(const mdh_ctx* c) { return c ? (c->dense_now ? 1 : 0) : -1; }
 
+// Dense passes: the window kernel flags candidate blocks and the morphology is driven by them (MDH_DENSE_CAND=0: round 4's form,
+// every word of every frame read back by k_morph_close_plain; A/B and parity)
+static bool dense_candidates() {
+    static const bool on = !(getenv("MDH_DENSE_CAND") && atoi(getenv("MDH_DENSE_CAND")) == 0);
+    return on;
+}
+
 template <typename T>
 static int dev_alloc(T*& p, size_t count, bool zero = true) {
     HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
@@ -629,7 +636,10 @@ static int create_impl(mdh_ctx* c) {
     for (int hi = 0; hi < c->nhset && hough; ++hi) {
         HoughSet& h = c->hset[hi];
         h.pool = (int)std::min<size_t>(K, 256);  // one hybrid workgroup per CU (it takes the whole LDS)
-        h.pool_list = (int)std::min<size_t>(K, 16);
+        // global point lists of the one-wave kernel (frames with more than 8192 lit pixels: a cloud edge): two lists of H*W entries per
+        // slot.  Round 4 kept 16 slots: a pass with 640 such frames replayed them 16 at a time.  Now as many as 4 GiB pay for, at
+        // least 16 and at most one per pooled accumulator (1080p: 256 slots, 4K: 64, 8K: 16).
+        h.pool_list = (int)std::min<size_t>(std::min<size_t>(K, (size_t)h.pool), std::max<size_t>(16, std::min<size_t>(256, ((size_t)4 << 30) / (8 * HW))));
         TRY(dev_alloc(h.d_work, (size_t)h.pool * words));
         TRY(dev_alloc(h.d_accum, (size_t)h.pool * NUM_ANGLE * c->numrho));
         TRY(dev_alloc(h.d_nz_orig, (size_t)h.pool_list * HW, false));
@@ -1173,7 +1183,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     }
     else if (PPL == 16 && c->win_dense)  // dense output format: 16-pixels-per-lane variants only (its own instantiation as well)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, 16, false, true>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
+                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, dense_candidates() ? c->d_bandflag : (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
                            c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean,
@@ -1382,9 +1392,26 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         span_begin(c, KK_MORPH, post);
         if (c->win_dense_used) {
             c->dense_passes += 1;
-            // dense format: every frame through the 64-bit direct-mapped kernel, no work lists
             static const int plain_grid = getenv("MDH_PLAIN_GRID") ? std::max(64, atoi(getenv("MDH_PLAIN_GRID"))) : 8192;
-            hipLaunchKernelGGL(k_morph_close_plain, dim3(plain_grid), dim3(64), 0, post, sl.d_bplain, c->d_act, sl.d_nzlist, sl.d_nzcount, g);
+            if (dense_candidates()) {
+                // dense format, round 5: the window kernel has flagged the blocks that hold a pair of set bits close enough for the
+                // median to keep anything (0.03 % of the words on 8K noise); their 3x3 block neighbourhoods are listed and closed
+                // from the plain words -- the 2 GB the window kernel wrote are not read back wholesale (round 4: every word of every
+                // frame through k_morph_close_plain, 0.96 ms of a 4.5 ms pass).  Frames whose list covers half of their blocks
+                // still go through that kernel, by a list of their own.
+                const size_t bm_dwords = (nb * c->WW + 31) / 32;
+                const int wpf = bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<false>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post,
+                                   sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_close_t<true>), dim3((unsigned)std::min(K * wpf, 16384)), dim3(64), 0, post, (const ActWord*)sl.d_bplain,
+                                   sl.d_worklist, sl.d_workcnt, c->d_act, sl.d_nzlist, sl.d_nzcount, g, sl.d_dense, wpf);
+                hipLaunchKernelGGL(k_morph_close_plain, dim3(plain_grid), dim3(64), 0, post, sl.d_bplain, (const unsigned*)sl.d_dense, c->d_act, sl.d_nzlist,
+                                   sl.d_nzcount, g);
+            } else {
+                // (MDH_DENSE_CAND=0, A/B and parity: every frame through the 64-bit direct-mapped kernel, no work lists)
+                hipLaunchKernelGGL(k_morph_close_plain, dim3(plain_grid), dim3(64), 0, post, sl.d_bplain, (const unsigned*)nullptr, c->d_act, sl.d_nzlist,
+                                   sl.d_nzcount, g);
+            }
         } else if (c->lean && K == 1) {
             // one frame: fourteen rows of a block on fourteen lanes (MDH_MORPH_T=0: the one-lane row pipeline of round 2, A/B and parity testing)
             static const bool transposed = !(getenv("MDH_MORPH_T") && atoi(getenv("MDH_MORPH_T")) == 0);
@@ -1404,14 +1431,14 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         static const int wpf_env = getenv("MDH_MORPH_WPF") ? atoi(getenv("MDH_MORPH_WPF")) : 0;
         const size_t bm_dwords = (nb * c->WW + 31) / 32;
         const int wpf = (wpf_env == 1 || wpf_env == 2 || wpf_env == 4) ? wpf_env : (bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1));
-        hipLaunchKernelGGL(k_morph_select_touched, dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<true>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
         // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
         // waves leave after one load when the pass has none (MDH_MORPH_DENSE=0: everything through the list, A/B and parity testing)
         static const bool dense = !(getenv("MDH_MORPH_DENSE") && atoi(getenv("MDH_MORPH_DENSE")) == 0);
         // a block's fourteen rows on fourteen lanes, one wave per frame (MDH_MORPH_BT=0: one lane per listed block, A/B and parity)
         static const bool batched_t = !(getenv("MDH_MORPH_BT") && atoi(getenv("MDH_MORPH_BT")) == 0);
         if (batched_t)
-            hipLaunchKernelGGL(k_morph_close_t, dim3((unsigned)std::min(K * wpf, 16384)), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_close_t<false>), dim3((unsigned)std::min(K * wpf, 16384)), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,
                                sl.d_nzlist, sl.d_nzcount, g, dense ? sl.d_dense : nullptr, wpf);
         else
         hipLaunchKernelGGL(k_morph_close, dim3(4096), dim3(64), 0, post, sl.d_bbits, sl.d_worklist, sl.d_workcnt, c->d_act,

@@ -588,6 +588,9 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     const int gw = gw0 + lane / LPW;
     const int frame_bytes = g.H * g.W;
     const int off = gw < words ? gw * 64 + q * PPL : 0x7FFFFFF0;  // past the frame -> zeros
+    // DENSE: bit 0 = this lane's word is the first of its image row, bit 1 = the last (a set pixel on the replicated border
+    // counts twice in the median's window: see the candidate test below)
+    const unsigned edge_lr = DENSE ? ((gw % g.WW == 0 ? 1u : 0u) | (gw % g.WW == g.WW - 1 ? 2u : 0u)) : 0u;
     union PK {
         unsigned u;
         u16x2 v;
@@ -920,6 +923,36 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         if constexpr (DENSE) {
                             nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0));
                             if (q == 0 && gw < words) __builtin_nontemporal_store(v, &((u64*)bbits)[(size_t)i * words + gw]);
+                            // CANDIDATE BLOCKS (round 5).  The median keeps a pixel only with >= 5 set samples in its 3x3 window, i.e.
+                            // only where SOME ROW holds two set bits at most two columns apart (at the left / right image border a
+                            // single bit counts twice: the border is replicated).  On the noise a lowered threshold lets through --
+                            // 9 % of the words carry a bit, 0.03 % such a pair -- that names a few hundred of a frame's 65 000 blocks,
+                            // and the morphology reads those neighbourhoods instead of all 2 GB of plain words back.  A pair inside a
+                            // word: v & (v >> 1 | v >> 2).  A pair across two words: the left word's top two bits come over a DPP
+                            // row shift (row_shr:4: a word sits in every fourth lane); the first word of a 16-lane row and the edge
+                            // words of an image row have no neighbour to ask and take their edge bits for a pair (a few false
+                            // candidates, never a missed one).  Flagged through the block bitmap of the sparse format (non-returning
+                            // atomic, rare path: ~1 % of the wave-frames).
+                            if (blockcnt != nullptr) {
+                                const unsigned top2 = (unsigned)(v >> 62);
+                                const unsigned lt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)top2, 0x114, 0xF, 0xF, false);  // row_shr:4
+                                const unsigned lo2 = (unsigned)v & 3u;
+                                bool cand = (v & ((v >> 1) | (v >> 2))) != 0;
+                                cand = cand || ((lane & 15) == 0 ? lo2 != 0 : (((lo2 & 1u) && lt) || ((lo2 & 2u) && (lt & 2u))));
+                                cand = cand || (((unsigned)v & 1u) & edge_lr) || (((unsigned)(v >> 63)) & (edge_lr >> 1));
+                                cand = cand && q == 0 && gw < words;
+                                if (__ballot(cand) != 0) {
+                                    if (cand) {
+                                        int gwr = gw;
+                                        asm volatile("" : "+v"(gwr));
+                                        const int nbands_ = (g.H + MORPH_RB - 1) / MORPH_RB;
+                                        const unsigned per_frame_ = (unsigned)(nbands_ * g.WW);
+                                        const unsigned blk = (unsigned)(gwr / g.WW / MORPH_RB) * (unsigned)g.WW + (unsigned)(gwr % g.WW);
+                                        unsigned* bitmap = blockcnt + (size_t)g.Kcap * per_frame_;
+                                        atomicOr(&bitmap[(size_t)i * block_bitmap_stride(per_frame_) + (blk >> 5)], 1u << (blk & 31));
+                                    }
+                                }
+                            }
                         } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             // (the word index through an opaque move: everything derived from it -- the store's address, the block
@@ -1179,9 +1212,13 @@ __device__ __forceinline__ u128 hor_and3_open(u128 d, const Win& q) {
 // for it (absent words read as zero).  The blocks that may produce output are compacted into a work list, so that
 // the stencil kernel runs with full waves instead of a few live lanes per wave.
 // (device function: frame i, block `tid` of the frame; whole waves call it together -- k_post_single walks a frame with one workgroup)
+template <bool COUNTED = true>
 __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ blockcnt, const PassGeom& g, int i, int tid) {
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     bool keep = false;
+    // (COUNTED = false: the bitmap names candidate blocks of a DENSE pass -- there are no counts: every block of a candidate's
+    // 3x3 neighbourhood is listed)
+    if (!COUNTED) return tid >= 0 && tid < nb * g.WW;
     if (tid < nb * g.WW) {
         const int band = tid / g.WW, w = tid - band * g.WW;
         const int y0 = band * MORPH_RB;
@@ -1210,6 +1247,7 @@ __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ bl
 // wpf (1, 2 or 4): waves per frame -- the 64-dword rounds of a frame's bitmap are dealt out to them (960x540: 32 dwords, one round,
 // one wave; 4K: 507 dwords, eight rounds, and a long streak's candidates on top: one wave per frame made the launch as long as
 // its longest frame, 0.19 ms per 1000-frame pass).  The waves of a frame share nothing but the frame's list counter.
+template <bool COUNTED>
 __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
                                                               unsigned* __restrict__ workcount, PassGeom g, int wpf) {
     RAISE_WAVE_PRIORITY();
@@ -1239,7 +1277,7 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
         // tests itself, as round 3's selection did for all frames
         for (unsigned b0 = 64 * sub; b0 < per_frame; b0 += 64 * (unsigned)wpf) {
             const int tid = (int)b0 + lane;
-            append(morph_block_keep(blockcnt, g, i, tid), tid);
+            append(morph_block_keep<COUNTED>(blockcnt, g, i, tid), tid);
         }
         return;
     }
@@ -1287,7 +1325,7 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
             const bool have = e < total;
             const unsigned v = have ? q[e] : 0u;
             const int tid = 32 * (int)(d0 + (v >> 5)) + (int)(v & 31u);
-            append(have && morph_block_keep(blockcnt, g, i, tid), tid);
+            append(have && morph_block_keep<COUNTED>(blockcnt, g, i, tid), tid);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1430,16 +1468,22 @@ __device__ __forceinline__ void edge_bits(u64 c, unsigned& lbit, unsigned& rbit)
     lbit = from_left & 1u;          // the left neighbour's top bit
     rbit = (from_right >> 1) & 1u;  // the right neighbour's bottom bit
 }
-__global__ void __launch_bounds__(64) k_morph_close_plain(const u64* __restrict__ bplain, ActWord* __restrict__ act_ring,
+__global__ void __launch_bounds__(64) k_morph_close_plain(const u64* __restrict__ bplain, const unsigned* __restrict__ frames,
+                                                          ActWord* __restrict__ act_ring,
                                                           unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g) {
+    // frames: null = every frame of the pass; else frames[0] = how many, frames[1 ..] = which (the frames whose candidate blocks
+    // cover at least half of the frame: k_morph_close_t<true> leaves those to this kernel; a pass without any costs a load per wave)
+    const unsigned nf = frames != nullptr ? frames[0] : (unsigned)g.K;
+    if (nf == 0) return;
     RAISE_WAVE_PRIORITY();
     const int lane = threadIdx.x;
     const unsigned cgroups = (unsigned)(g.WW + MORPH_PLAIN_COLS - 1) / MORPH_PLAIN_COLS;
     const unsigned bands = (unsigned)(g.H + MORPH_PLAIN_ROWS - 1) / MORPH_PLAIN_ROWS;
     const unsigned per_frame = cgroups * bands;
     const size_t words = (size_t)g.H * g.WW;
-    for (unsigned item = blockIdx.x; item < (unsigned)g.K * per_frame; item += gridDim.x) {
-        const unsigned i = item / per_frame, rest = item - i * per_frame;
+    for (unsigned item = blockIdx.x; item < nf * per_frame; item += gridDim.x) {
+        const unsigned fi = item / per_frame, rest = item - fi * per_frame;
+        const unsigned i = frames != nullptr ? frames[1 + fi] : fi;
         const unsigned band = rest / cgroups, cg = rest - band * cgroups;
         const int w = (int)cg * MORPH_PLAIN_COLS - 1 + lane;
         const bool live = w >= 0 && w < g.WW;
@@ -1600,6 +1644,7 @@ __device__ __forceinline__ void morph_nz_flush(unsigned* __restrict__ q, unsigne
     __syncthreads();
     qn = 0;
 }
+template <bool PLAIN = false>
 __device__ __forceinline__ void morph_close_group_t(const ActWord* __restrict__ src, u64 t, ActWord* __restrict__ dst, unsigned idx_base,
                                                     bool have, int blk, unsigned* __restrict__ q, unsigned& qn, const PassGeom& g,
                                                     int lane, int j) {
@@ -1610,7 +1655,8 @@ __device__ __forceinline__ void morph_close_group_t(const ActWord* __restrict__ 
     const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
     const Win wq = make_win(w, g.W);
     u128 b = 0;
-    if (have && j < 14) b = load_win_act(src + (size_t)yc * g.WW, w, g.WW, t);
+    // (PLAIN: src is the window kernel's dense output, u64 [H][WW] of this frame, every word written: no tags)
+    if (have && j < 14) b = PLAIN ? load_win((const u64*)src + (size_t)yc * g.WW, w, g.WW) : load_win_act(src + (size_t)yc * g.WW, w, g.WW, t);
     // median of this lane's row from the rows above and below (lanes j - 1, j + 1)
     u128 h0, h1;
     hsum3_replicate(b, wq, h0, h1);
@@ -1664,6 +1710,7 @@ __global__ void __launch_bounds__(64) k_morph_close_frame_t(const ActWord* __res
 // per 16 000-frame pass at 960x540, a third of the window kernel's time, at a few per cent of the machine.  Here a wave takes a
 // frame and four of its listed blocks at a time, a block's fourteen rows on fourteen lanes of a 16-lane group: sixteen times the
 // waves, each a fraction as long.  Frames with at least half of their blocks listed go to k_morph_close_dense as before.
+template <bool PLAIN>
 __global__ void __launch_bounds__(64) k_morph_close_t(const ActWord* __restrict__ bbits, const unsigned* __restrict__ worklist,
                                                       const unsigned* __restrict__ workcount, ActWord* __restrict__ act_ring,
                                                       unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g,
@@ -1685,13 +1732,13 @@ __global__ void __launch_bounds__(64) k_morph_close_t(const ActWord* __restrict_
         }
         const unsigned* seg = worklist + (size_t)i * per_frame;
         const long long t = g.t_base + 1 + (long long)i;
-        const ActWord* src = bbits + (size_t)i * words;
+        const ActWord* src = PLAIN ? (const ActWord*)((const u64*)bbits + (size_t)i * words) : bbits + (size_t)i * words;
         ActWord* dst = act_ring + (size_t)((t - 1) % g.R) * words;
         for (unsigned e0 = 4 * sub; e0 < cnt; e0 += 4 * (unsigned)wpf) {
             const unsigned e = e0 + (unsigned)grp;
             const bool have = e < cnt;
             const int blk = have ? (int)(seg[e] - i * per_frame) : 0;
-            morph_close_group_t(src, (u64)t, dst, (unsigned)(i * words), have, blk, q, qn, g, lane, j);
+            morph_close_group_t<PLAIN>(src, (u64)t, dst, (unsigned)(i * words), have, blk, q, qn, g, lane, j);
             if (qn > MORPH_NZQ - 64) morph_nz_flush(q, qn, nzlist, nzcount, lane);
         }
     }
@@ -2597,10 +2644,22 @@ __device__ void ppht_grouped(Ppht& C, int N, unsigned* list) {
 // working mask, point lists) -- a workgroup keeps its slot for every frame it walks through.
 __device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsigned* lds_dyn) {
     // dynamic LDS: [ point list: list_cap dwords | accumulator cells: cell_cap/2 dwords | 64 dummy dwords ]
-    unsigned* lds_list = lds_dyn;
-    unsigned* lds_cells = lds_dyn + P.list_cap;
+    // The split is PER FRAME (round 5).  Round 4 fixed it at 8192 list entries: a frame with more lit pixels -- a cloud edge, a
+    // wavy strip of 12-17 k pixels across the whole frame -- kept its point list in GLOBAL memory and was replayed one point at
+    // a time, three dependent L2 round trips per point (list swap, working-mask bit, returning votes): 17 ms per frame.  A list
+    // of up to ~31 k points still fits next to 16 k accumulator cells; such a frame takes the group-speculative replay
+    // (ppht_grouped: sixteen draws resolved at once, their mask bits in one round trip, their votes issued back to back) with
+    // the smallest rho windows in LDS and the others in the pooled global accumulator.
     const int lane = threadIdx.x;
     const int N = P.litcount[i];
+    const int lds_dwords = P.list_cap + P.cell_cap / 2;
+    int list_cap = P.list_cap, cell_cap = P.cell_cap;
+    if (N > list_cap && N <= lds_dwords - 8192) {
+        list_cap = (N + 63) & ~63;
+        cell_cap = 2 * (lds_dwords - list_cap);
+    }
+    unsigned* lds_list = lds_dyn;
+    unsigned* lds_cells = lds_dyn + list_cap;
     const long long c0 = P.dbg ? clock64() : 0;
     const int line_gap = (int)rint(P.out_gap[i]);  // maxLineGap (k_hough_classify) -> cvRound
     // Accumulator windows: rho is monotone in x and in y for a fixed angle (rounded float products and sum), so over
@@ -2628,7 +2687,7 @@ __device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsig
     // where the votes pile up), found by bisecting the size limit; the remaining angles use the global accumulator.
     {
         int limit = 0x7FFFFFFF;
-        if (cells_needed > P.cell_cap) {
+        if (cells_needed > cell_cap) {
             int lo = 0, hi = P.numrho;  // largest `limit` with sum(size <= limit) <= cell_cap
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
@@ -2636,7 +2695,7 @@ __device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsig
 #pragma unroll
                 for (int q = 0; q < 3; ++q) sum += w_size[q] <= mid ? w_size[q] : 0;
                 for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                if (sum <= P.cell_cap) lo = mid; else hi = mid - 1;
+                if (sum <= cell_cap) lo = mid; else hi = mid - 1;
             }
             limit = lo;
         }
@@ -2688,14 +2747,14 @@ __device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsig
     const long long c1 = P.dbg ? clock64() : 0;
     Ppht C{P, wrk, (unsigned*)wrk,
            P.accum + (size_t)slot * NUM_ANGLE * P.numrho, {0, 0, 0}, {0, 0, 0}, line_gap, i, 0, lane, 0, 0, 0, 0, 0, 0, 0, P.dbg != nullptr,
-           lds_cells, P.cell_cap / 2, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, {-1, -1, -1}, false};
+           lds_cells, cell_cap / 2, {0, 0, 0}, {-1, -1, -1}, {0, 0, 0}, {-1, -1, -1}, false};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int n = lane + 64 * q;
         C.tc[q] = n < NUM_ANGLE ? P.trig[2 * n] : 0.f;
         C.ts[q] = n < NUM_ANGLE ? P.trig[2 * n + 1] : 0.f;
     }
-    if (!P.no_lds_acc && N <= P.list_cap && cells_needed <= P.cell_cap) {
+    if (!P.no_lds_acc && N <= list_cap && cells_needed <= cell_cap) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             C.lo[q] = w_lo[q];
@@ -2705,7 +2764,7 @@ __device__ void ppht_one_wave_frame(const HoughParams& P, int i, int slot, unsig
         }
         for (int p = lane; p < (cells_needed + 1) / 2; p += 64) lds_cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
     }
-    if (N <= P.list_cap) {
+    if (N <= list_cap) {
         for (int p = lane; p < N; p += 64) lds_list[p] = ld_l2(&nzo[p]);
         __threadfence_block();  // one wave: its LDS operations execute in order
         if (P.serial)

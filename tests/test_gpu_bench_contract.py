@@ -51,7 +51,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # against the oracle's steady-state period x the number of periods it processed
     assert d["parity"]["verdict"] == "identical" and d["parity"]["frames_checked"] == 384
     tr = d["parity"]["timed_region"]
-    assert tr["verdict"] == "identical" and tr["periods"] == 8 * 3 and tr["gpu_tally"] == tr["expected_tally"] and tr["oracle_steady"]
+    assert tr["verdict"] == "identical" and tr["periods"] == 8 * 3 and tr["gpu_tally"] == tr["expected_tally"] and tr["gpu_every_pass_equal"]
     assert tr["gpu_tally"][0] == d["detections"]["raw_segments"] > 0
 
 

@@ -58,6 +58,12 @@ def family(kind, H, W, rng):
     elif kind == "grid":  # many short segments: more than 500 lines on big images
         img[::6, :] = 255
         img[:, ::37] = 0
+    elif kind == "cloud":  # a cloud edge: a wavy strip across the whole frame (12 k+ points: the one-wave kernel with its list in LDS) + a streak
+        xs = np.arange(W)
+        ys = np.rint(H * (0.5 + 0.08 * np.sin(xs / W * 2 * np.pi * rng.uniform(1, 3) + rng.uniform(0, 6)))).astype(int)
+        for d in range(max(3, -(-11520 // W))):
+            img[np.clip(ys + d, 0, H - 1), xs] = 255
+        draw_line(img, W * 0.2, H * 0.2, W * 0.2 + 150, H * 0.2 + 90, width=3)
     elif kind == "single":
         img[H // 2, W // 3] = 255
     elif kind == "empty":
@@ -67,7 +73,7 @@ def family(kind, H, W, rng):
 
 CASES = [("fan", 200, 320), ("borders", 97, 131), ("noise", 270, 480), ("dense", 120, 200), ("segments", 300, 500), ("dashed", 90, 400),
          ("blobs", 128, 128), ("grid", 360, 640), ("single", 33, 70), ("empty", 64, 64), ("segments", 1, 300), ("segments", 300, 1),
-         ("dense", 300, 420), ("fan", 1080, 1920), ("segments", 540, 960)]
+         ("dense", 300, 420), ("fan", 1080, 1920), ("segments", 540, 960), ("cloud", 1080, 1920), ("cloud", 540, 960)]
 
 
 @pytest.mark.parametrize("mask_share", [1.0, 0.02])

@@ -275,13 +275,15 @@ def test_m3_dense_binaries_direct_mapped_morphology(shape):
     run_pair(frames, n, mask, cfg, batch=13, max_batch=13)
 
 
+@pytest.mark.parametrize("cand", ["1", "0"])
 @pytest.mark.parametrize("shape,n", [((70, 192), 4), ((40, 64 * 62), 8), ((33, 64 * 63), 5), ((50, 64 * 125), 16), ((9, 64), 2)])
-def test_m3_dense_output_format_forced(shape, n, monkeypatch):
+def test_m3_dense_output_format_forced(shape, n, cand, monkeypatch):
     """MDH_DENSE=1: every batched pass runs in the dense format (the window kernel writes every word of b plainly, the 64-bit
     direct-mapped morphology kernel k_morph_close_plain reads it: 62 word columns + 2 halo lanes per wave, edge bits through DPP
     wave shifts at every stage) -- noise frames, flat frames, streak frames; widths of one word, below / at / across the 62-column
     wave boundary and across two of them; every window length class of the wide-load kernels."""
     monkeypatch.setenv("MDH_DENSE", "1")
+    monkeypatch.setenv("MDH_DENSE_CAND", cand)  # 1 (default): morphology driven by the window kernel's candidate blocks; 0: round 4's form
     mask = np.ones(shape, np.uint8)
     cfg = binary_cfg(adaptive=False, init_value=3, hough=(10, 10, 2))
     noise = frames_normal(sum(shape) + n, 12, shape, 30, 2.5)
@@ -298,6 +300,66 @@ def test_m3_dense_output_format_forced(shape, n, monkeypatch):
     det.detect()
     assert det._ctx.dense_passes == 1
     det.close()
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_m3_dense_candidate_blocks_crafted(n, monkeypatch):
+    """The dense format's candidate test (round 5): the window kernel flags a block only when one of its words holds two set bits
+    at most two columns apart IN ONE ROW -- the least a 3x3 window needs to collect its 5 of 9 -- and the morphology looks at the
+    flagged blocks' neighbourhoods only.  Crafted clusters that just make the median, placed where the test has to reach across:
+    a word boundary (x = 63 | 64), the boundary between two 16-lane DPP rows (x = 255 | 256: four words per row), a wave boundary
+    (x = 1023 | 1024: sixteen words per wave), the image's left / right / top / bottom borders (replicated: a single bit counts
+    twice there), clusters whose pair and whose single bits sit in different words and different rows, and clusters one bit short
+    (nothing may come out, nothing may be missed next to them).  Isolated noise bits all around keep 9 % of the words busy."""
+    monkeypatch.setenv("MDH_DENSE", "1")
+    H, W = 48, 64 * 36
+    mask = np.ones((H, W), np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=9, hough=(10, 10, 2))
+    rng = np.random.default_rng(77 + n)
+    base = np.full((H, W), 30, np.uint8)
+
+    def lit(points):
+        f = base.copy()
+        for (y, x) in points:
+            if 0 <= y < H and 0 <= x < W:
+                f[y, x] = 90
+        # isolated bits: one per ~11 words, never within 3 columns / 2 rows of another or of a crafted point
+        busy = np.zeros((H, W), bool)
+        for (y, x) in points:
+            busy[max(0, y - 3):y + 4, max(0, x - 4):x + 5] = True
+        for _ in range(H * W // 64 // 11):
+            y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+            if not busy[max(0, y - 2):y + 3, max(0, x - 3):x + 4].any():
+                f[y, x] = 90
+                busy[y, x] = True
+        return f
+
+    def cluster(y, x, kind):
+        """3x3 window centred at (y, x) with exactly 5 (or 4: "short") samples set, in shapes that split across rows and columns."""
+        shapes = {"row3+2": [(0, -1), (0, 0), (0, 1), (1, -1), (1, 0)], "2+2+1": [(-1, -1), (-1, 0), (0, 0), (0, 1), (1, 1)],
+                  "col": [(-1, 0), (0, 0), (1, 0), (0, 1), (1, 1)], "2+1+2": [(-1, 0), (-1, 1), (0, -1), (1, 0), (1, 1)],
+                  "short": [(-1, -1), (-1, 0), (0, 1), (1, 1)], "pair_far": [(0, -1), (0, 1), (-1, 0), (1, 0), (1, 1)]}
+        return [(y + dy, x + dx) for dy, dx in shapes[kind]]
+
+    frames = []
+    kinds = ["row3+2", "2+2+1", "col", "2+1+2", "short", "pair_far"]
+    xs = [63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 0, 1, W - 1, W - 2, 700, 2047, 2048]
+    for k, kind in enumerate(kinds):
+        pts = []
+        for j, x in enumerate(xs):
+            y = [0, 1, H - 1, H - 2, 7, 8, 9, 23, 24][(j + k) % 9]
+            pts += cluster(y, x, kind)
+        frames.append(lit(pts))
+        frames.append(base.copy())
+    # border singles: one bit on the replicated left / right / top / bottom border counts twice (2 + 2 + 1 from three bits, etc.)
+    frames.append(lit([(10, 0), (11, 0), (12, 0), (20, W - 1), (21, W - 1), (22, W - 1), (0, 300), (0, 301), (1, 300), (H - 1, 900), (H - 1, 901), (H - 2, 901)]))
+    frames += [base.copy()] * (n + 1)
+    total = run_pair(frames, n, mask, cfg, batch=7, max_batch=7)
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=8)
+    info, _raw, _nms, _prob = det._ctx.process_batch(np.stack(frames[:8]))
+    assert det._ctx.dense_passes == 1 and int(info["lit_count"].sum()) > 0
+    det.close()
+    assert total >= 0
 
 
 def test_m3_output_format_flips_mid_stream():
