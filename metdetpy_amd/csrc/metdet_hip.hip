@@ -1183,7 +1183,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     }
     else if (PPL == 16 && c->win_dense)  // dense output format: 16-pixels-per-lane variants only (its own instantiation as well)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, 16, false, true>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, dense_candidates() ? c->d_bandflag : (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
+                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
                            c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean,
@@ -1394,17 +1394,22 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
             c->dense_passes += 1;
             static const int plain_grid = getenv("MDH_PLAIN_GRID") ? std::max(64, atoi(getenv("MDH_PLAIN_GRID"))) : 8192;
             if (dense_candidates()) {
-                // dense format, round 5: the window kernel has flagged the blocks that hold a pair of set bits close enough for the
-                // median to keep anything (0.03 % of the words on 8K noise); their 3x3 block neighbourhoods are listed and closed
-                // from the plain words -- the 2 GB the window kernel wrote are not read back wholesale (round 4: every word of every
-                // frame through k_morph_close_plain, 0.96 ms of a 4.5 ms pass).  Frames whose list covers half of their blocks
-                // still go through that kernel, by a list of their own.
+                // dense format, round 5: one streaming sweep over the plain words flags the blocks that hold a pair of set bits close
+                // enough for the median to keep anything (0.03 % of the words on 8K noise: k_dense_candidates); their 3x3 block
+                // neighbourhoods are listed and closed from the plain words (round 4: every word of every frame through
+                // k_morph_close_plain's dependent row loads, 0.96 ms of a 4.5 ms pass).  Frames whose list covers half of their
+                // blocks still go through that kernel, by a list of their own.
                 const size_t bm_dwords = (nb * c->WW + 31) / 32;
                 const int wpf = bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1);
+                static const int cand_grid = getenv("MDH_CAND_GRID") ? std::max(64, atoi(getenv("MDH_CAND_GRID"))) : 4096;
+                hipLaunchKernelGGL(k_dense_candidates, dim3(cand_grid), dim3(256), 0, post, sl.d_bplain, sl.d_bandflag, g);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<false>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post,
                                    sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_close_t<true>), dim3((unsigned)std::min(K * wpf, 16384)), dim3(64), 0, post, (const ActWord*)sl.d_bplain,
-                                   sl.d_worklist, sl.d_workcnt, c->d_act, sl.d_nzlist, sl.d_nzcount, g, sl.d_dense, wpf);
+                // (the list kernel is a chain of dependent steps per workgroup: enough one-wave workgroups per frame that a frame's
+                // few thousand listed blocks are a few dozen steps each)
+                const int lwpf = (int)std::max<long long>(wpf, std::min<long long>(32, 16384 / std::max(K, 1)));
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_close_t<true>), dim3((unsigned)std::min(K * lwpf, 16384)), dim3(64), 0, post, (const ActWord*)sl.d_bplain,
+                                   sl.d_worklist, sl.d_workcnt, c->d_act, sl.d_nzlist, sl.d_nzcount, g, sl.d_dense, lwpf);
                 hipLaunchKernelGGL(k_morph_close_plain, dim3(plain_grid), dim3(64), 0, post, sl.d_bplain, (const unsigned*)sl.d_dense, c->d_act, sl.d_nzlist,
                                    sl.d_nzcount, g);
             } else {

@@ -588,9 +588,6 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     const int gw = gw0 + lane / LPW;
     const int frame_bytes = g.H * g.W;
     const int off = gw < words ? gw * 64 + q * PPL : 0x7FFFFFF0;  // past the frame -> zeros
-    // DENSE: bit 0 = this lane's word is the first of its image row, bit 1 = the last (a set pixel on the replicated border
-    // counts twice in the median's window: see the candidate test below)
-    const unsigned edge_lr = DENSE ? ((gw % g.WW == 0 ? 1u : 0u) | (gw % g.WW == g.WW - 1 ? 2u : 0u)) : 0u;
     union PK {
         unsigned u;
         u16x2 v;
@@ -923,36 +920,6 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         if constexpr (DENSE) {
                             nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0));
                             if (q == 0 && gw < words) __builtin_nontemporal_store(v, &((u64*)bbits)[(size_t)i * words + gw]);
-                            // CANDIDATE BLOCKS (round 5).  The median keeps a pixel only with >= 5 set samples in its 3x3 window, i.e.
-                            // only where SOME ROW holds two set bits at most two columns apart (at the left / right image border a
-                            // single bit counts twice: the border is replicated).  On the noise a lowered threshold lets through --
-                            // 9 % of the words carry a bit, 0.03 % such a pair -- that names a few hundred of a frame's 65 000 blocks,
-                            // and the morphology reads those neighbourhoods instead of all 2 GB of plain words back.  A pair inside a
-                            // word: v & (v >> 1 | v >> 2).  A pair across two words: the left word's top two bits come over a DPP
-                            // row shift (row_shr:4: a word sits in every fourth lane); the first word of a 16-lane row and the edge
-                            // words of an image row have no neighbour to ask and take their edge bits for a pair (a few false
-                            // candidates, never a missed one).  Flagged through the block bitmap of the sparse format (non-returning
-                            // atomic, rare path: ~1 % of the wave-frames).
-                            if (blockcnt != nullptr) {
-                                const unsigned top2 = (unsigned)(v >> 62);
-                                const unsigned lt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)top2, 0x114, 0xF, 0xF, false);  // row_shr:4
-                                const unsigned lo2 = (unsigned)v & 3u;
-                                bool cand = (v & ((v >> 1) | (v >> 2))) != 0;
-                                cand = cand || ((lane & 15) == 0 ? lo2 != 0 : (((lo2 & 1u) && lt) || ((lo2 & 2u) && (lt & 2u))));
-                                cand = cand || (((unsigned)v & 1u) & edge_lr) || (((unsigned)(v >> 63)) & (edge_lr >> 1));
-                                cand = cand && q == 0 && gw < words;
-                                if (__ballot(cand) != 0) {
-                                    if (cand) {
-                                        int gwr = gw;
-                                        asm volatile("" : "+v"(gwr));
-                                        const int nbands_ = (g.H + MORPH_RB - 1) / MORPH_RB;
-                                        const unsigned per_frame_ = (unsigned)(nbands_ * g.WW);
-                                        const unsigned blk = (unsigned)(gwr / g.WW / MORPH_RB) * (unsigned)g.WW + (unsigned)(gwr % g.WW);
-                                        unsigned* bitmap = blockcnt + (size_t)g.Kcap * per_frame_;
-                                        atomicOr(&bitmap[(size_t)i * block_bitmap_stride(per_frame_) + (blk >> 5)], 1u << (blk & 31));
-                                    }
-                                }
-                            }
                         } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             // (the word index through an opaque move: everything derived from it -- the store's address, the block
@@ -1202,6 +1169,61 @@ __device__ __forceinline__ u128 hor_or3(u128 m) { return m | (m << 1) | (m >> 1)
 __device__ __forceinline__ u128 hor_and3_open(u128 d, const Win& q) {
     const u128 e = d | ~q.valid;
     return e & ((e << 1) | 1) & ((e >> 1) | ((u128)1 << 127));
+}
+
+// CANDIDATE BLOCKS of a dense pass (round 5).  The median keeps a pixel only with >= 5 set samples in its 3x3 window, i.e. only
+// where SOME ROW holds two set bits at most two columns apart (at the left / right image border a single bit counts twice: the
+// border is replicated).  On the noise a lowered threshold lets through (8K at m3det_high: 9 % of the words carry a bit, 0.03 %
+// such a pair) that names a few hundred of a frame's 65 000 blocks: this kernel streams once through the plain words the window
+// kernel wrote (8 bytes per lane, a wave per image row, four rows in flight) and flags those blocks in the sparse format's block
+// bitmap; k_morph_select_touched<false> lists their 3x3 block neighbourhoods and k_morph_close_t<true> closes them from the plain
+// words -- instead of k_morph_close_plain's 22 dependent row loads per 16 output rows over EVERY word (0.96 ms of a 4.5 ms pass).
+// A pair across two words: the left word's top two bits come over a DPP wave shift (lane 0 fetches its neighbour's word).
+// (Tried first inside the window kernel, on the word it has just gathered: ~15 vector instructions per wave-frame on a kernel
+// whose vector-memory front end is the bound -- 3.50 -> 3.96 ms per 500 8K frames, more than the morphology had to give.)
+__global__ void __launch_bounds__(256) k_dense_candidates(const u64* __restrict__ bplain, unsigned* __restrict__ blockcnt, PassGeom g) {
+    RAISE_WAVE_PRIORITY();
+    const int lane = threadIdx.x & 63;
+    const int nbands = (g.H + MORPH_RB - 1) / MORPH_RB;
+    const unsigned per_frame = (unsigned)(nbands * g.WW);
+    unsigned* bitmap = blockcnt + (size_t)g.Kcap * per_frame;
+    const unsigned stride = block_bitmap_stride(per_frame);
+    const unsigned rows_total = (unsigned)g.K * (unsigned)g.H;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int pl = (g.W - 1) & 63;  // position of pixel W - 1 in the last word
+    constexpr int RB = 4;           // rows a wave has in flight
+    for (unsigned r0 = wave * RB; r0 < rows_total; r0 += nwaves * RB) {
+        for (int w0 = 0; w0 < g.WW; w0 += 64) {
+            const int w = w0 + lane;
+            u64 v[RB];
+            u64 lw[RB];  // lane 0: the word left of the wave's first
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const unsigned rt = r0 + (unsigned)k;
+                const u64* row = bplain + (size_t)rt * g.WW;
+                v[k] = (rt < rows_total && w < g.WW) ? row[w] : 0ull;
+                lw[k] = (rt < rows_total && lane == 0 && w0 > 0) ? row[w0 - 1] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const unsigned rt = r0 + (unsigned)k;
+                const unsigned top2 = (unsigned)(v[k] >> 62);
+                unsigned lt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)top2, 0x138, 0xF, 0xF, false);  // wave_shr:1  lane l <- l - 1
+                if (lane == 0) lt = (unsigned)(lw[k] >> 62);
+                const unsigned lo2 = (unsigned)v[k] & 3u;
+                bool cand = (v[k] & ((v[k] >> 1) | (v[k] >> 2))) != 0;
+                cand = cand || ((lo2 & 1u) && lt) || ((lo2 & 2u) && (lt & 2u));
+                cand = cand || (w == 0 && (v[k] & 1ull)) || (w == g.WW - 1 && ((v[k] >> pl) & 1ull));
+                if (__ballot(cand) != 0) {
+                    if (cand) {
+                        const unsigned i = rt / (unsigned)g.H, y = rt - i * (unsigned)g.H;
+                        const unsigned blk = (y / MORPH_RB) * (unsigned)g.WW + (unsigned)w;
+                        atomicOr(&bitmap[(size_t)i * stride + (blk >> 5)], 1u << (blk & 31));
+                    }
+                }
+            }
+        }
+    }
 }
 
 // a5 + a6 + a7: act = MORPH_CLOSE( median3(diff) > T ) computed from b = (diff > T):
