@@ -289,7 +289,7 @@ def parity_check(frames, n, mask, local, count, timed=None):
     "per_pass_equal": every timed pass gave the same tallies}: the timed region processes the stream's period over and over in
     its steady state (the threshold has settled, every window is full), so its tallies must be the oracle's tallies of one
     steady-state period times the number of periods -- checked here against the LAST whole period the oracle saw (count is
-    raised to at least three periods -- the first two still carry the warm-up of the window and of the threshold's EMA; see
+    raised to at least two whole periods -- the first carries the warm-up of the windows; see
     below for how the oracle gets from there to the timed region)."""
     from metdetpy_amd import M3Detector
     from metdetpy_amd.utils import select_std_roi
@@ -297,7 +297,9 @@ def parity_check(frames, n, mask, local, count, timed=None):
     period = len(frames)
     want_steady = timed is not None and timed["frames"] % period == 0 and count > 0
     if want_steady:
-        count = max(count, 3 * period) // period * period
+        # whole periods: three where a frame is cheap for the oracle (the threshold has usually settled by the third, which then
+        # serves as the steady period itself), two at 4K / 8K (the second one starts with full windows)
+        count = max(count, (3 if mask.size <= 1080 * 1920 else 2) * period) // period * period
         want_steady = timed["warm_frames"] >= count  # (the timed region must lie beyond what the oracle runs through frame by frame)
     src = frames
     co.lib().om3_set_threads(min(16, len(os.sched_getaffinity(0))))

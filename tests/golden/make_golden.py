@@ -487,5 +487,18 @@ def gen_exposure():
     json.dump(g8, open(os.path.join(HERE, "g8_exposure.json"), "w"))
 
 
+def gen_config1_truth():
+    """config1_truth.json: the DATA the reference holds about its missing sample video test/20220413Red.mp4 (a Git-LFS blob) --
+    test/20220413_annotation.json (whole file) and entry 0 of test/clip_test.json -- copied as data; metdetpy_amd.synth.Config1Clip
+    builds the stand-in clip of BASELINE config 1 from it (tests/config1_chain.py, tests/test_config1_standin.py)."""
+    truth = json.load(open(os.path.join(REF, "test", "20220413_annotation.json"), encoding="utf-8"))
+    clip = json.load(open(os.path.join(REF, "test", "clip_test.json"), encoding="utf-8"))[0]
+    out = {"source": "data the reference holds about its missing sample video test/20220413Red.mp4 (a Git-LFS blob): "
+                     "test/20220413_annotation.json (whole file) and test/clip_test.json entry 0",
+           "annotation": truth, "clip_test_entry_0": clip}
+    json.dump(out, open(os.path.join(HERE, "config1_truth.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     main()
+    gen_config1_truth()

@@ -48,7 +48,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert c["single_thread"]["c_port"] > 0 and c["single_thread"]["numpy_oracle"] > 0 and "1" in c["c_port_by_threads"]
     # parity: three periods of the resident stream (128 frames each here) against the oracle, and the TIMED region's tallies
-    # against the oracle's steady-state period x the number of periods it processed
+    # against the oracle's tallies of one period at the threshold its own scalar chain reaches there x the number of periods
     assert d["parity"]["verdict"] == "identical" and d["parity"]["frames_checked"] == 384
     tr = d["parity"]["timed_region"]
     assert tr["verdict"] == "identical" and tr["periods"] == 8 * 3 and tr["gpu_tally"] == tr["expected_tally"] and tr["gpu_every_pass_equal"]
