@@ -379,11 +379,19 @@ extern "C" int64_t mdh_dense_passes(const mdh_ctx* c) { return c ? c->dense_pass
 extern "C" double mdh_last_density(const mdh_ctx* c) { return c ? c->last_density : -1; }
 extern "C" int mdh_dense_now(const mdh_ctx* c) { return c ? (c->dense_now ? 1 : 0) : -1; }
 
-// Dense passes: the window kernel flags candidate blocks and the morphology is driven by them (MDH_DENSE_CAND=0: round 4's form,
-// every word of every frame read back by k_morph_close_plain; A/B and parity)
-static bool dense_candidates() {
-    static const bool on = !(getenv("MDH_DENSE_CAND") && atoi(getenv("MDH_DENSE_CAND")) == 0);
-    return on;
+// Dense passes: a streaming sweep flags candidate blocks and the morphology is driven by them (k_dense_candidates), or every word
+// of every frame goes through k_morph_close_plain (round 4).  Which one is faster depends on what the binaries hold.  The sweep
+// and the listed blocks cost the same whatever the bit density; k_morph_close_plain skips the rows whose neighbourhood cannot
+// pass the median, which is almost all of them on plain noise (8K at m3det_high, 9 % of the words with a bit: 0.99 ms per
+// 500-frame pass against 0.86 for the candidates -- and at the pipeline's pace the candidates lose 1.5 %) and almost none when the
+// bits are dense but still isolated (1 % hot pixels at 1080p, a quarter of the words with a bit: 1.50 ms against 0.50, +23 % frames
+// per second).  MDH_DENSE_CAND: 1 (default) = by the share of words with set bits the last collected dense pass reported (>= 15 %:
+// candidates), 2 = always candidates, 0 = never (A/B and parity).
+static bool dense_candidates(const mdh_ctx* c) {
+    static const int mode = getenv("MDH_DENSE_CAND") ? atoi(getenv("MDH_DENSE_CAND")) : 1;
+    if (mode == 0) return false;
+    if (mode >= 2) return true;
+    return c->last_density >= 0.15;
 }
 
 template <typename T>
@@ -1393,7 +1401,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         if (c->win_dense_used) {
             c->dense_passes += 1;
             static const int plain_grid = getenv("MDH_PLAIN_GRID") ? std::max(64, atoi(getenv("MDH_PLAIN_GRID"))) : 8192;
-            if (dense_candidates()) {
+            if (dense_candidates(c)) {
                 // dense format, round 5: one streaming sweep over the plain words flags the blocks that hold a pair of set bits close
                 // enough for the median to keep anything (0.03 % of the words on 8K noise: k_dense_candidates); their 3x3 block
                 // neighbourhoods are listed and closed from the plain words (round 4: every word of every frame through
