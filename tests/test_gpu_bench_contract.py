@@ -104,10 +104,14 @@ def test_bench_secondary_block_of_the_headline_run():
     d = _run(["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-pmc", "--parity-frames", "16", "--standalone-passes", "4"], timeout=1500)
     assert d["config"]["passes_per_step"] == 64 and d["config"]["frames_per_step"] == 256000
     sec = d["secondary"]
-    assert set(sec) == {"C3_4k_n16_mask", "C5_8k_high", "C1s_960x540", "per_frame_pinned", "per_frame_recycled_ring", "per_frame_pageable"}
+    unfriendly = {"C2_noisy_sky_m3det_low", "C2_hot_pixels_1pct", "C2_cloud_edge_every_50", "C2_streak_share_5pct", "C2_streak_share_80pct"}
+    assert set(sec) == {"C3_4k_n16_mask", "C5_8k_high", "C1s_960x540", "C5_8k_as_8_row_bands_one_gpu", "per_frame_pinned",
+                        "per_frame_recycled_ring", "per_frame_pageable"} | unfriendly
     for name, e in sec.items():
         assert "error" not in e, (name, e)
-        assert e["value"] > 0 and e["timed_s"] >= 0.3 and e["parity"] == "identical" and e["parity_frames"] >= 64, (name, e)
+        assert e["value"] > 0 and e["timed_s"] >= 0.05 and e["parity"] == "identical" and e["parity_frames"] >= 16, (name, e)
+    for name in unfriendly:  # parity, fps and the slowest frame's Hough replay for every unfriendly sky
+        assert sec[name]["timed_region_tallies"] == "identical" and sec[name]["hough_frame_cost"]["slowest_frame"]["replay_us"] > 0, (name, sec[name])
     for name in ("C3_4k_n16_mask", "C5_8k_high", "C1s_960x540"):
         assert 0.2 < sec[name]["frac_at_pipeline_pace"] < 1 and 0.2 < sec[name]["frac"] < 1 and sec[name]["timed_s"] >= 1.0, (name, sec[name])
         assert sec[name]["timed_region_tallies"] == "identical", (name, sec[name])  # no configuration is timed that was not compared
