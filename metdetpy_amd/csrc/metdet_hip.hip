@@ -128,6 +128,7 @@ struct HoughSet {
     u64* d_work = nullptr;
     int* d_accum = nullptr;
     unsigned *d_nz_orig = nullptr, *d_nz_work = nullptr;
+    unsigned short* d_perm_big = nullptr;  // [pool][HOUGH_BIG_LIST]: visiting-order table of the frame a hybrid workgroup is on, when it has more than HOUGH_MAX_LIST points
     int *d_tier_list = nullptr, *d_tier_count = nullptr;  // [HOUGH_TIERS][Kmax], [HOUGH_TIERS]: frame routing of the pass in the set
     int last_slot = -1;  // slot of the pass that used the set last
 };
@@ -191,6 +192,7 @@ struct mdh_ctx {
     int prev_slot = -1;        // slot of the pass submitted before the one being queued
     float* d_trig = nullptr;
     const unsigned short* d_perm = nullptr;  // PPHT visiting-order tables (shared by every context on the device)
+    const unsigned* d_rnd = nullptr;         // the first HOUGH_BIG_LIST outputs of cv::RNG(-1) (likewise)
     int lds_small = 80 * 1024, lds_large = 160 * 1024;  // dynamic LDS of the two three-wave PPHT launches (MDH_HOUGH_LDS_SMALL / _LARGE)
     int lds_tiny = 40 * 1024;                           // ... and of the launch for short streaks (MDH_HOUGH_LDS_TINY; 0: no such launch)
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
@@ -476,7 +478,7 @@ static void free_all(mdh_ctx* c) {
         if (e) hipEventDestroy(e);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
     for (HoughSet& h : c->hset) {
-        void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work, h.d_tier_list, h.d_tier_count};
+        void* hdev[] = {h.d_work, h.d_accum, h.d_nz_orig, h.d_nz_work, h.d_tier_list, h.d_tier_count, h.d_perm_big};
         for (void* p : hdev)
             if (p) hipFree(p);
         if (h.ev_big) hipEventDestroy(h.ev_big);
@@ -495,14 +497,17 @@ static void free_all(mdh_ctx* c) {
 // (67 MB for lists of up to HOUGH_MAX_LIST points) and shared by every context.
 static std::mutex g_perm_mutex;
 static unsigned short* g_perm[64] = {nullptr};
-static int perm_table(int device, const unsigned short** out) {
+static unsigned* g_rnd[64] = {nullptr};
+static int perm_table(int device, const unsigned short** out, const unsigned** rnd_out) {
     std::lock_guard<std::mutex> lock(g_perm_mutex);
     if (device < 0 || device >= 64) { set_err("perm_table: device index out of range"); return MDH_E_ARG; }
     if (!g_perm[device]) {
         const int n_max = HOUGH_MAX_LIST;
-        std::vector<unsigned> rnd(n_max);
+        // (HOUGH_BIG_LIST entries of the generator's output stay on the device: a frame with more than HOUGH_MAX_LIST points builds
+        // its own visiting-order table from them, hough3_frame)
+        std::vector<unsigned> rnd(HOUGH_BIG_LIST);
         uint64_t st = 0xFFFFFFFFFFFFFFFFull;  // cv::RNG rng((uint64)-1), hough.cpp
-        for (int k = 0; k < n_max; ++k) {
+        for (int k = 0; k < HOUGH_BIG_LIST; ++k) {
             st = (uint64_t)(unsigned)st * 4164903690ull + (st >> 32);  // RNG::next(): multiply-with-carry
             rnd[k] = (unsigned)st;
         }
@@ -512,24 +517,26 @@ static int perm_table(int device, const unsigned short** out) {
         unsigned short* d_perm = nullptr;
         hipStream_t st_build = nullptr;
         hipError_t e = hipStreamCreateWithFlags(&st_build, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_rnd, sizeof(unsigned) * n_max);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_rnd, sizeof(unsigned) * HOUGH_BIG_LIST);
         if (e == hipSuccess) e = hipMalloc((void**)&d_perm, sizeof(unsigned short) * ((size_t)n_max * (n_max + 1) / 2));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_rnd, rnd.data(), sizeof(unsigned) * n_max, hipMemcpyHostToDevice, st_build);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rnd, rnd.data(), sizeof(unsigned) * HOUGH_BIG_LIST, hipMemcpyHostToDevice, st_build);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_perm_build, dim3(n_max), dim3(64), 0, st_build, d_rnd, d_perm, n_max);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st_build);
-        if (d_rnd) hipFree(d_rnd);
         if (st_build) hipStreamDestroy(st_build);
         if (e != hipSuccess) {
             if (d_perm) hipFree(d_perm);
+            if (d_rnd) hipFree(d_rnd);
             set_err(std::string("perm_table: ") + hipGetErrorString(e));
             return MDH_E_HIP;
         }
         g_perm[device] = d_perm;
+        g_rnd[device] = d_rnd;
     }
     *out = g_perm[device];
+    *rnd_out = g_rnd[device];
     return MDH_OK;
 }
 
@@ -541,7 +548,7 @@ extern "C" int mdh_device_reset(int device) {
     HIPCHK(hipSetDevice(device));
     {
         std::lock_guard<std::mutex> lock(g_perm_mutex);
-        if (device >= 0 && device < 64) g_perm[device] = nullptr;  // (freed by the reset)
+        if (device >= 0 && device < 64) { g_perm[device] = nullptr; g_rnd[device] = nullptr; }  // (freed by the reset)
     }
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
@@ -652,10 +659,11 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(h.d_accum, (size_t)h.pool * NUM_ANGLE * c->numrho));
         TRY(dev_alloc(h.d_nz_orig, (size_t)h.pool_list * HW, false));
         TRY(dev_alloc(h.d_nz_work, (size_t)h.pool_list * HW, false));
+        TRY(dev_alloc(h.d_perm_big, (size_t)h.pool * HOUGH_BIG_LIST, false));
         TRY(dev_alloc(h.d_tier_list, (size_t)HOUGH_TIERS * K));
         TRY(dev_alloc(h.d_tier_count, HOUGH_TIERS + 4));  // (+ the work queue's head of k_hough3_big)
     }
-    if (hough) TRY(perm_table(c->device, &c->d_perm));
+    if (hough) TRY(perm_table(c->device, &c->d_perm, &c->d_rnd));
     TRY(dev_alloc(c->d_trig, 2 * NUM_ANGLE));
     TRY(dev_alloc(c->d_expand, HW));
     if (getenv("MDH_HOUGH_DEBUG")) TRY(dev_alloc(c->d_hdbg, K * 16));  // [K][8] stamps, then [K][8] phase cycle totals
@@ -1518,6 +1526,8 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.lds_tiny = c->lean ? 0 : c->lds_tiny;
     P.all_one_wave = c->hough_one_wave;
     P.perm = c->d_perm;
+    P.rnd = c->d_rnd;
+    P.perm_big = hs.d_perm_big;
     P.mute = (int)std::max<int64_t>(0, std::min<int64_t>(K, c->mute_until - sl.t_base));
     P.acc_mode = c->cfg.hough_mode == MDH_HOUGH_ACCUMULATOR;
     P.list_cap = HOUGH_MAX_LIST; P.cell_cap = 61440;  // the one-wave kernel's LDS

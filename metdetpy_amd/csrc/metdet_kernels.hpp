@@ -2291,7 +2291,9 @@ struct HoughParams {
     int lds_tiny;          // ... and of the launch for frames that need even less (tier 4; 0: no such launch)
     int all_one_wave;      // MDH_HOUGH_ONE_WAVE / MDH_HOUGH_SERIAL: every frame goes to the one-wave kernel
     int lds_bytes;         // dynamic LDS bytes of this launch
-    const unsigned short* perm;  // visiting-order tables: the table of an N-point frame starts at N(N-1)/2
+    const unsigned short* perm;  // visiting-order tables: the table of an N-point frame starts at N(N-1)/2 (N <= HOUGH_MAX_LIST)
+    const unsigned* rnd;         // the first HOUGH_BIG_LIST outputs of cv::RNG(-1): a larger frame builds its table itself ...
+    unsigned short* perm_big;    // ... into its pool slot's [HOUGH_BIG_LIST] entries of this buffer (hough3_frame<true>)
     const int* bbox;       // [K][4] {W-1 - min x, max x, H-1 - min y, max y} of the lit pixels
     int mute;              // the first `mute` frames of the pass are not replayed (time-window warm-up: results dropped anyway)
     int acc_mode;          // 1 = full-accumulator Hough (h3_accumulate) instead of the exact replay, in the three-wave kernels
@@ -2852,6 +2854,7 @@ __global__ void __launch_bounds__(64) k_hough_ppht(HoughParams P) {
 //   tier 3      one-wave kernel with a global point list (more than HOUGH_MAX_LIST points)
 //   none        fewer points than the vote threshold: no accumulator cell can reach it, so there is no segment
 #define HOUGH_MAX_LIST 8192
+#define HOUGH_BIG_LIST 32768  // frames of up to this many points may take the three-wave replay with a visiting-order table of their own (if their LDS need allows)
 #define HOUGH3_THREADS 192
 #define HOUGH3_FIXED_DWORDS 64  // mailboxes + scan scratch + line results
 
@@ -2891,7 +2894,16 @@ __device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
     }
     for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
     const int mask_dw = (by1 - by0 + 1) * ((bx1 >> 6) - (bx0 >> 6) + 1) * 2;
-    if (N > HOUGH_MAX_LIST || P.all_one_wave) return 3;
+    if (P.all_one_wave) return 3;
+    if (N > HOUGH_MAX_LIST) {
+        // Round 5: more points than the shared visiting-order tables cover (a cloud edge: 12-17 k points).  Such a frame takes the
+        // hybrid three-wave replay with a table of its own, built by the workgroup in the LDS its accumulator cells get afterwards
+        // -- if the point list, the un-vote list and that scratch (N dwords) fit next to each other.  Otherwise (and in the
+        // accumulator mode, whose specification replays such frames exactly in the one-wave kernel) the one-wave kernel.
+        const int uvc = hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1);
+        const bool fits = N <= HOUGH_BIG_LIST && 4 * (HOUGH3_FIXED_DWORDS + ((N + 3) & ~3) + 2 * uvc + HOUGH3_THREADS + N + 64) <= P.lds_large;
+        return (fits && !P.acc_mode && !P.no_lds_acc && P.perm_big != nullptr) ? 2 : 3;
+    }
     if (P.no_lds_acc) return 2;
     const int need = hough3_lds_need(N, hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1), cells, mask_dw);
     if (P.lds_tiny > 0 && need <= P.lds_tiny) return 4;
@@ -3175,10 +3187,9 @@ __device__ __forceinline__ int h3_cell_now(Hough3& C, float x, float y) {
 #define H3_SUB 8  // largest sub-group (A/B builds: -DH3_SUB=16 is round 2's)
 #endif
 template <bool HYBRID, bool TM>
-__device__ void h3_replay(Hough3& C, int N, const unsigned* list) {
+__device__ void h3_replay(Hough3& C, int N, const unsigned* list, const unsigned short* perm) {
     const HoughParams& P = C.P;
     const int lane = C.lane;
-    const unsigned short* perm = P.perm + (size_t)N * (N - 1) / 2;
     unsigned round = 0;
     int gsz = H3_SUB;
     unsigned nxt = lane < N ? perm[lane] : 0;  // the table entries of the following step are fetched one step ahead
@@ -3423,7 +3434,8 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     const int mask_dw = rows * wpr * 2;
     const int budget_dw = P.lds_bytes / 4 - HOUGH3_FIXED_DWORDS - Np - 2 * uvc - HOUGH3_THREADS;  // mask + cells
     bool mask_lds = true;
-    if (HYBRID) mask_lds = mask_dw <= budget_dw / 4;  // a huge bounding box: the mask stays in global memory, the LDS goes to the cells
+    const bool big_n = HYBRID && N > HOUGH_MAX_LIST;  // (its own visiting-order table, built below in the region behind the un-vote list)
+    if (HYBRID) mask_lds = !big_n && mask_dw <= budget_dw / 4;  // a huge bounding box: the mask stays in global memory, the LDS goes to the cells
     unsigned* cells = lmask + (mask_lds ? mask_dw : 0);
     const int cell_cap = HYBRID ? (P.no_lds_acc ? 0 : 2 * (budget_dw - (mask_lds ? mask_dw : 0))) : 0x7FFFFFFF;
     if (tid < HOUGH3_FIXED_DWORDS) fix[tid] = 0;
@@ -3475,6 +3487,34 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    const unsigned short* perm = P.perm + (size_t)N * (N - 1) / 2;
+    if (big_n) {
+        // The visiting order of cv::HoughLinesP for THIS list length (k_perm_build's job for N <= HOUGH_MAX_LIST, once per process):
+        // idx_k = rnd_k % (N - k) for all k at once, then the swap-remove chain by one lane on 16-bit LDS arrays (N steps of three
+        // dependent LDS accesses: ~0.15 us each), written to the workgroup's slot of perm_big.  The scratch -- 2 N half-words --
+        // is the region the mask and the cells would take; the mask of such a frame stays in global memory.
+        unsigned short* const a = (unsigned short*)lmask;
+        unsigned short* const ix = a + ((N + 1) & ~1);
+        unsigned short* const out = P.perm_big + (size_t)slot * HOUGH_BIG_LIST;
+        for (int k = tid; k < N; k += HOUGH3_THREADS) {
+            a[k] = (unsigned short)k;
+            ix[k] = (unsigned short)(P.rnd[k] % (unsigned)(N - k));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 0; k < N; ++k) {
+                const int idx = ix[k];
+                const unsigned short v = a[idx];
+                a[idx] = a[N - 1 - k];
+                out[k] = v;
+            }
+        }
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __threadfence();  // (every wave: the table was written through the L2 by one lane; this CU's vector cache may hold the slot's previous table)
+        perm = out;
+    }
     // ---- rho windows from the bounding box: rho is monotone in x and in y for a fixed angle, so its extremes are at the corners
     int w_lo = 0, w_size = 0;
     float tc = 0.f, ts = 0.f;
@@ -3694,7 +3734,7 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     }
     const long long w1 = TM && P.dbg ? wall_clock64() : 0;
     if (P.acc_mode) h3_accumulate<HYBRID, TM>(C, N, list, w_lo, w_size);
-    else h3_replay<HYBRID, TM>(C, N, list);
+    else h3_replay<HYBRID, TM>(C, N, list, perm);
     if (tid == 0) P.out_nraw[i] = C.found;
     if (TM && P.dbg && tid == 0) {  // MDH_HOUGH_DEBUG=1: points, tier, 100 MHz ticks (set-up, PPHT), segments, LDS cells
         long long* d = P.dbg + (size_t)i * 8;

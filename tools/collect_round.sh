@@ -2,7 +2,7 @@
 # Everything profiles/ holds for a round, in one go on the GPU box:  bash tools/collect_round.sh <tag>   (outputs under gpurun_out/collect_<tag>/)
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/collect_$TAG; mkdir -p $O
 S="--cpu-seconds 6 --no-secondary"
 NS="--no-secondary --cpu-seconds 0"
@@ -34,7 +34,13 @@ python bench.py --workload C3 --hough-mode accumulator $NS --steps 6 > $O/${TAG}
 python bench.py --workload C5 --unique 50 --batch 125 --hough-mode accumulator $NS --steps 6 > $O/${TAG}_bench_C5_hough_accumulator.json 2>> $O/err_acc
 python bench.py --workload C1e --cpu-seconds 0 > $O/${TAG}_bench_C1e_end_to_end.json 2> $O/err_c1e
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 1 --cpu-seconds 0 2> $O/err_2r | grep '^{' > $O/${TAG}_bench_2ranks_one_gpu.json
-for wl in C2 C3 C5; do WL=$wl python tools/hough_frame_times.py > $O/${TAG}_hough_frame_times_$wl.txt 2>&1; done
+# the unfriendly skies on their own lines (they are also legs of the headline run's `secondary` block)
+for st in noisy hot cloud sparse dense; do
+  U=100; [ $st = sparse ] && U=400; [ $st = dense ] && U=96; BB=""; [ $st = dense ] && BB="--batch 3840"
+  python bench.py --stream $st --unique $U $BB $NS --no-pmc --steps 6 --warmup 1 > $O/${TAG}_bench_C2_stream_$st.json 2>> $O/err_streams
+done
+bash tools/run_8gpu.sh --dry-run 8 $O/dry8 > $O/${TAG}_run_8gpu_dry_run.txt 2>&1
+for wl in C2 C3 C5 C1s; do WL=$wl python tools/hough_frame_times.py > $O/${TAG}_hough_frame_times_$wl.txt 2>&1; done
 ./tools/lds_atomic_rate > $O/${TAG}_lds_atomic_rate.txt 2>&1
 python tools/bench_pre_batch.py > $O/${TAG}_preprocess_batch.json 2> $O/err_pre
 python tools/bench_collector.py > $O/${TAG}_collector.json 2> $O/err_col
