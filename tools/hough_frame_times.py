@@ -11,7 +11,8 @@ WL = os.environ.get("WL", "C2")
 H, W, n, B, uniq = {"C2": (1080, 1920, 8, 1024, 250), "C3": (2160, 3840, 16, 256, 100), "C5": (4320, 7680, 8, 64, 50), "C1s": (540, 960, 8, 2048, 250)}[WL]
 mask = np.ones((H, W), np.uint8)
 bench.SENSITIVITY = bench.WORKLOADS[WL].get("sensitivity", "normal")
-frames = SkyStream(H, W, bench.WORKLOADS[WL]["seed"]).take(uniq)
+STREAM = os.environ.get("STREAM", "sky")  # bench.py --stream: sky | noisy | hot | cloud | sparse | dense
+frames = SkyStream(H, W, bench.WORKLOADS[WL]["seed"], **bench.STREAMS[STREAM]["kw"]).take(uniq)
 det = M3Detector(1, n, mask, 10, bench.make_cfg(), None, max_batch=B)
 ctx = det._ctx
 pool = ctx.device_alloc(B * H * W)
