@@ -58,13 +58,41 @@ class Group:
             self.cp.close()
             raise RuntimeError(f"backend rccl: {local_world} ranks on this node but {min(r[0] for r in reports)} HIP device(s) visible "
                                "-- RCCL refuses two ranks on one device")
+        self.rccl_note = None
         if want != "store" and own_device:
+            # RCCL with more than one rank has never run on the build's one-GPU boxes: whatever goes wrong here -- the communicator
+            # does not form, the first collective does not return what it must -- is reported on stderr and the job goes on over
+            # the store (every rank takes the same decision: the outcomes are exchanged through the control plane first) unless the
+            # caller insisted on RCCL.
             from . import _lib, rccl
-            self.comm = rccl.Communicator.from_group(self.cp, device=self.local, timeout_s=self.timeout_s)
-            self._L = _lib.load()
-            self._stream = self._L.mdh_stream_create(self.local)
-            if not self._stream:
-                raise _lib.MetDetHipError(f"mdh_stream_create failed: {_lib.last_error()}")
+            err = None
+            try:
+                self.comm = rccl.Communicator.from_group(self.cp, device=self.local, timeout_s=self.timeout_s)
+                self._L = _lib.load()
+                self._stream = self._L.mdh_stream_create(self.local)
+                if not self._stream:
+                    raise _lib.MetDetHipError(f"mdh_stream_create failed: {_lib.last_error()}")
+                got = self._all_gather_fixed(struct.pack("<q", 1000 + self.rank))  # the first collective: every rank's number, in order
+                if [struct.unpack("<q", b)[0] for b in got] != [1000 + r for r in range(self.world)]:
+                    raise rccl.RcclError(f"ncclAllGather returned {got!r}")
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            outcomes = self.cp.all_gather_object(err)
+            if any(o is not None for o in outcomes):
+                first = next(o for o in outcomes if o is not None)
+                if want == "rccl":
+                    self.cp.close()
+                    raise RuntimeError(f"backend rccl: {first}")
+                import sys
+                if self.rank == 0:
+                    print(f"[metdetpy_amd.dist] RCCL is not usable ({first}); the final gather goes through the rendezvous store", file=sys.stderr, flush=True)
+                if self.comm is not None:
+                    try:
+                        self.comm.abort()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    self.comm = None
+                self.rccl_note = first
         else:
             self.device = self.local % max(ndev, 1)  # ranks share devices round-robin
         self.backend = "rccl" if self.comm is not None else "store"
@@ -174,6 +202,8 @@ class Group:
 
     def describe(self) -> dict:
         d = {"rank": self.rank, "world": self.world, "device": self.device, "backend": self.backend}
+        if self.rccl_note:
+            d["rccl_not_usable"] = self.rccl_note
         if self.comm is not None:
             d["communicator"] = self.comm.describe()
         return d
