@@ -295,7 +295,9 @@ def parity_check(frames, n, mask, local, count, timed=None):
     from metdetpy_amd.utils import select_std_roi
     from oracle import c_oracle as co
     period = len(frames)
-    want_steady = timed is not None and timed["frames"] % period == 0 and count > 0
+    # (the resident pool must hold whole periods: a pass of 125 frames over a 50-frame period is resubmitted on a scene cut, and the
+    # stream the detector sees is then not the periodic one the oracle's chain assumes)
+    want_steady = timed is not None and timed["frames"] % period == 0 and timed.get("pool_frames", period) % period == 0 and count > 0
     if want_steady:
         # whole periods: three where a frame is cheap for the oracle (the threshold has usually settled by the third, which then
         # serves as the steady period itself), two at 4K / 8K (the second one starts with full windows)
@@ -421,7 +423,8 @@ def parity_check(frames, n, mask, local, count, timed=None):
         out["hough_frame_cost"] = hough_cost
     if timed is not None:
         if steady is None:
-            out["timed_region"] = {"verdict": "not checked", "why": "the timed region is not a whole number of stream periods"}
+            out["timed_region"] = {"verdict": "not checked", "why": "the resident pool (or the timed region) is not a whole number of stream periods, or the "
+                                   "warm-up is shorter than the oracle's frame-by-frame leg"}
         elif "tally" not in steady:
             out["timed_region"] = {"verdict": "not checked", "why": "the oracle's threshold changes inside the timed region", **steady}
         else:
@@ -753,7 +756,7 @@ def run_streams(a, D, wl, mask):
     D.fence()
     segs, kept, lit = tally
     dt = time.perf_counter() - t0
-    timed = {"tally": [segs, kept, lit], "frames": steps * P * B, "per_pass_equal": len(passes_seen) == 1, "warm_frames": a.warmup * P * B}
+    timed = {"tally": [segs, kept, lit], "frames": steps * P * B, "per_pass_equal": len(passes_seen) == 1, "warm_frames": a.warmup * P * B, "pool_frames": B}
     prof = {}
     if not a.no_profile and D.rank == 0:
         # the kernels' spans INSIDE the pipeline (overlapping each other, queueing included): the same pipelined passes again,

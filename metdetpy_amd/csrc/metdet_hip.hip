@@ -387,13 +387,18 @@ extern "C" int mdh_dense_now(const mdh_ctx* c) { return c ? (c->dense_now ? 1 : 
 // pass the median, which is almost all of them on plain noise (8K at m3det_high, 9 % of the words with a bit: 0.99 ms per
 // 500-frame pass against 0.86 for the candidates -- and at the pipeline's pace the candidates lose 1.5 %) and almost none when the
 // bits are dense but still isolated (1 % hot pixels at 1080p, a quarter of the words with a bit: 1.50 ms against 0.50, +23 % frames
-// per second).  MDH_DENSE_CAND: 1 (default) = by the share of words with set bits the last collected dense pass reported (>= 15 %:
-// candidates), 2 = always candidates, 0 = never (A/B and parity).
+// per second).  What makes k_morph_close_plain slow there is not the bits but the FRAME: a wave takes 62 word columns, and a 1080p
+// row has 30 (960x540: 15) -- half the lanes of every wave idle on a chain of 22 dependent row loads (0.7 TB/s against 2 TB/s at 8K's
+// 120 columns).  MDH_DENSE_CAND: 1 (default) = candidates when the frame fills less than three quarters of the plain kernel's lanes
+// (widths below 47 words and 63-92 words: 960x540, 1080p; not 4K's 60 or 8K's 120) or when the last collected dense pass reported
+// at least 15 % of its words with a set bit, 2 = always candidates, 0 = never (A/B and parity).
 static bool dense_candidates(const mdh_ctx* c) {
     static const int mode = getenv("MDH_DENSE_CAND") ? atoi(getenv("MDH_DENSE_CAND")) : 1;
     if (mode == 0) return false;
     if (mode >= 2) return true;
-    return c->last_density >= 0.15;
+    const int groups = (c->WW + MORPH_PLAIN_COLS - 1) / MORPH_PLAIN_COLS;
+    const double lanes_used = (double)c->WW / (groups * MORPH_PLAIN_COLS);
+    return lanes_used < 0.75 || c->last_density >= 0.15;
 }
 
 template <typename T>
@@ -652,9 +657,11 @@ static int create_impl(mdh_ctx* c) {
         HoughSet& h = c->hset[hi];
         h.pool = (int)std::min<size_t>(K, 256);  // one hybrid workgroup per CU (it takes the whole LDS)
         // global point lists of the one-wave kernel (frames with more than 8192 lit pixels: a cloud edge): two lists of H*W entries per
-        // slot.  Round 4 kept 16 slots: a pass with 640 such frames replayed them 16 at a time.  Now as many as 4 GiB pay for, at
-        // least 16 and at most one per pooled accumulator (1080p: 256 slots, 4K: 64, 8K: 16).
-        h.pool_list = (int)std::min<size_t>(std::min<size_t>(K, (size_t)h.pool), std::max<size_t>(16, std::min<size_t>(256, ((size_t)4 << 30) / (8 * HW))));
+        // slot.  Round 4 kept 16 slots: a pass with 640 such frames replayed them 16 at a time.  Now as many as 1 GiB pays for, at
+        // least 16 and at most one per pooled accumulator (1080p: 64 slots, 4K and 8K: 16) -- per CONTEXT: a process that runs eight
+        // of them next to 13 GB of frame ring each must still fit (4 GiB here made `bench.py --mode timeshard --host-input` run out of
+        // memory); and since round 5 most such frames take the hybrid three-wave replay anyway (hough_classify_frame).
+        h.pool_list = (int)std::min<size_t>(std::min<size_t>(K, (size_t)h.pool), std::max<size_t>(16, std::min<size_t>(256, ((size_t)1 << 30) / (8 * HW))));
         TRY(dev_alloc(h.d_work, (size_t)h.pool * words));
         TRY(dev_alloc(h.d_accum, (size_t)h.pool * NUM_ANGLE * c->numrho));
         TRY(dev_alloc(h.d_nz_orig, (size_t)h.pool_list * HW, false));

@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_contexts():
+    """Detector contexts hold gigabytes of HBM (frame rings, pooled Hough buffers) and pinned host memory; a test that lets one go
+    out of scope without close() keeps it until the garbage collector gets to it.  Collect after every test, so that a long
+    session's footprint is one test's, not the sum of all of them."""
+    yield
+    import gc
+    gc.collect()
