@@ -381,25 +381,18 @@ extern "C" int64_t mdh_dense_passes(const mdh_ctx* c) { return c ? c->dense_pass
 extern "C" double mdh_last_density(const mdh_ctx* c) { return c ? c->last_density : -1; }
 extern "C" int mdh_dense_now(const mdh_ctx* c) { return c ? (c->dense_now ? 1 : 0) : -1; }
 
-// Dense passes: a streaming sweep flags candidate blocks and the morphology is driven by them (k_dense_candidates), or every word
-// of every frame goes through k_morph_close_plain (round 4).  Which one is faster depends on what the binaries hold.  The sweep
-// and the listed blocks cost the same whatever the bit density; k_morph_close_plain skips the rows whose neighbourhood cannot
-// pass the median, which is almost all of them on plain noise (8K at m3det_high, 9 % of the words with a bit: 0.99 ms per
-// 500-frame pass against 0.86 for the candidates -- and at the pipeline's pace the candidates lose 1.5 %) and almost none when the
-// bits are dense but still isolated (1 % hot pixels at 1080p, a quarter of the words with a bit: 1.50 ms against 0.50, +23 % frames
-// per second).  What makes k_morph_close_plain slow there is not the bits but the FRAME: a wave takes 62 word columns, and a 1080p
-// row has 30 (960x540: 15) -- half the lanes of every wave idle on a chain of 22 dependent row loads (0.7 TB/s against 2 TB/s at 8K's
-// 120 columns).  MDH_DENSE_CAND: 1 (default) = candidates when the frame fills less than three quarters of the plain kernel's lanes
-// (widths below 47 words and 63-92 words: 960x540, 1080p; not 4K's 60 or 8K's 120) or when the last collected dense pass reported
-// at least 15 % of its words with a set bit, 2 = always candidates, 0 = never (A/B and parity).
-static bool dense_candidates(const mdh_ctx* c) {
+// Dense passes: where do the morphology's candidate blocks come from (MDH_DENSE_CAND)?
+//   1 (default)  the window kernel flags them itself, with the neighbours a pair at a block's edge can reach: the selection lists
+//                exactly the flagged blocks, the plain words are read back only there;
+//   2            a streaming sweep over the plain words flags them (k_dense_candidates), the selection dilates by one block (the
+//                first form of round 5: the sweep reads all 2 GB back -- A/B and parity);
+//   0            no candidates: every word of every frame through k_morph_close_plain (round 4 -- A/B and parity).
+static int dense_cand_mode() {
     static const int mode = getenv("MDH_DENSE_CAND") ? atoi(getenv("MDH_DENSE_CAND")) : 1;
-    if (mode == 0) return false;
-    if (mode >= 2) return true;
-    const int groups = (c->WW + MORPH_PLAIN_COLS - 1) / MORPH_PLAIN_COLS;
-    const double lanes_used = (double)c->WW / (groups * MORPH_PLAIN_COLS);
-    return lanes_used < 0.75 || c->last_density >= 0.15;
+    return (mode == 1 || mode == 3) ? (WIDE_DENSE_CAND != 0 ? 1 : 2) : (mode == 2 ? 2 : 0);
 }
+static bool dense_candidates_inline() { return dense_cand_mode() == 1; }
+static bool dense_candidates(const mdh_ctx*) { return dense_cand_mode() != 0; }
 
 template <typename T>
 static int dev_alloc(T*& p, size_t count, bool zero = true) {
@@ -1206,7 +1199,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
     }
     else if (PPL == 16 && c->win_dense)  // dense output format: 16-pixels-per-lane variants only (its own instantiation as well)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, 16, false, true>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
+                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, dense_candidates_inline() ? c->d_bandflag : (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
                            c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean,
@@ -1425,9 +1418,10 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
                 const size_t bm_dwords = (nb * c->WW + 31) / 32;
                 const int wpf = bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1);
                 static const int cand_grid = getenv("MDH_CAND_GRID") ? std::max(64, atoi(getenv("MDH_CAND_GRID"))) : 4096;
-                hipLaunchKernelGGL(k_dense_candidates, dim3(cand_grid), dim3(256), 0, post, sl.d_bplain, sl.d_bandflag, g);
+                if (!dense_candidates_inline())
+                    hipLaunchKernelGGL(k_dense_candidates, dim3(cand_grid), dim3(256), 0, post, sl.d_bplain, sl.d_bandflag, g);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<false>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post,
-                                   sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
+                                   sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf, dense_candidates_inline() ? 0 : 1);
                 // (the list kernel is a chain of dependent steps per workgroup: enough one-wave workgroups per frame that a frame's
                 // few thousand listed blocks are a few dozen steps each)
                 const int lwpf = (int)std::max<long long>(wpf, std::min<long long>(32, 16384 / std::max(K, 1)));
@@ -1459,7 +1453,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         static const int wpf_env = getenv("MDH_MORPH_WPF") ? atoi(getenv("MDH_MORPH_WPF")) : 0;
         const size_t bm_dwords = (nb * c->WW + 31) / 32;
         const int wpf = (wpf_env == 1 || wpf_env == 2 || wpf_env == 4) ? wpf_env : (bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<true>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<true>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post, sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf, 1);
         // frames with at least half of their blocks listed (dense binaries: 8K at m3det_high) go to the direct-mapped kernel, whose
         // waves leave after one load when the pass has none (MDH_MORPH_DENSE=0: everything through the list, A/B and parity testing)
         static const bool dense = !(getenv("MDH_MORPH_DENSE") && atoi(getenv("MDH_MORPH_DENSE")) == 0);

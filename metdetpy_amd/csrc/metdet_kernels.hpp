@@ -505,6 +505,9 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #ifndef WIDE_PTR_AHEAD
 #define WIDE_PTR_AHEAD 1  // frame bases requested one burst ahead of the loads that use them (A/B builds: -DWIDE_PTR_AHEAD=0)
 #endif
+#ifndef WIDE_DENSE_CAND
+#define WIDE_DENSE_CAND 1  // the dense format's candidate test inside the window kernel (see the DENSE store below; A/B builds: -DWIDE_DENSE_CAND=0)
+#endif
 #ifndef WIDE_RAREBITS
 #define WIDE_RAREBITS 1  // gather the result bits only for waves that have one set (A/B builds: -DWIDE_RAREBITS=0)
 #endif
@@ -588,6 +591,10 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     const int gw = gw0 + lane / LPW;
     const int frame_bytes = g.H * g.W;
     const int off = gw < words ? gw * 64 + q * PPL : 0x7FFFFFF0;  // past the frame -> zeros
+#if WIDE_DENSE_CAND
+    // bit 0: this lane holds the first 16 pixels of an image row, bit 1: the last 16 (a set pixel on the replicated border counts twice)
+    const unsigned edge_lr = DENSE ? (((gw % g.WW == 0 && q == 0) ? 1u : 0u) | ((gw % g.WW == g.WW - 1 && q == LPW - 1) ? 2u : 0u)) : 0u;
+#endif
     union PK {
         unsigned u;
         u16x2 v;
@@ -920,6 +927,52 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         if constexpr (DENSE) {
                             nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0));
                             if (q == 0 && gw < words) __builtin_nontemporal_store(v, &((u64*)bbits)[(size_t)i * words + gw]);
+#if WIDE_DENSE_CAND
+                            // CANDIDATE BLOCKS (round 5).  The median keeps a pixel only with >= 5 set samples in its 3x3 window, i.e.
+                            // only where SOME ROW holds two set bits at most two columns apart (on the replicated left / right image
+                            // border a single bit counts twice).  On the noise a lowered threshold lets through (8K at m3det_high: 9 %
+                            // of the words carry a bit, 0.03 % such a pair) that names a few hundred of a frame's 65 000 blocks, and
+                            // the morphology closes those from the plain words instead of reading all 2 GB of them back (0.99 -> 0.25 ms
+                            // per 500-frame pass, 118 k -> 128-135 k frames/s, 0.56 -> 0.60-0.64 of the peak at the pipeline's pace).
+                            // The test runs on the lanes' own 16-bit masks BEFORE they are gathered into words -- 32-bit operations,
+                            // the left lane's top two bits over one DPP wave shift: ~2 % on this launch (the first version, on the
+                            // gathered 64-bit word in every lane, cost 13 %).  The wave's first lane and the first / last lane of an
+                            // image row have no neighbour to ask and take their edge bits for a pair (a few false candidates, never
+                            // a missed one).  Flagged through the block bitmap of the sparse format, non-returning atomics in a
+                            // rare path (~1 % of the wave-frames).
+                            if (blockcnt != nullptr) {
+                                const unsigned lt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(bits >> 14), 0x138, 0xF, 0xF, false);  // wave_shr:1
+                                const unsigned pair = bits & ((bits >> 1) | (bits >> 2));
+                                const unsigned lo2 = bits & 3u;
+                                const unsigned cross = lane == 0 ? lo2 : ((lo2 & (0u - (lt != 0))) & 1u) | (lo2 & lt & 2u);
+                                const unsigned edge = (bits & edge_lr & 1u) | ((bits >> 15) & (edge_lr >> 1));
+                                const bool cand = (pair | cross | edge) != 0 && gw < words;
+                                if (__ballot(cand) != 0) {
+                                    if (cand) {
+                                        // the blocks this pair can light up: what comes out of median + close lies within 2 rows and
+                                        // 2 columns of the pair's bits -- its own block, the block above / below when the row is one of
+                                        // the block's first / last two, the block to the left / right when the bits sit at the word's
+                                        // edge (this lane's bits 0..2 in the word's first lane, 13..15 in its last), and the diagonal
+                                        // ones when both hold.  The selection then lists exactly the flagged blocks (no dilation).
+                                        int gwr = gw;
+                                        asm volatile("" : "+v"(gwr));
+                                        const int nbands_ = (g.H + MORPH_RB - 1) / MORPH_RB;
+                                        const unsigned per_frame_ = (unsigned)(nbands_ * g.WW);
+                                        unsigned* bitmap = blockcnt + (size_t)g.Kcap * per_frame_ + (size_t)i * block_bitmap_stride(per_frame_);
+                                        const int y = gwr / g.WW, w = gwr - y * g.WW;
+                                        const int by = y / MORPH_RB, ry = y - by * MORPH_RB;
+                                        const int dy0 = (ry < 2 && by > 0) ? -1 : 0, dy1 = (ry >= MORPH_RB - 2 && by + 1 < nbands_) ? 1 : 0;
+                                        const int dx0 = (q == 0 && (bits & 0x7u) && w > 0) ? -1 : 0;
+                                        const int dx1 = (q == LPW - 1 && (bits & 0xE000u) && w + 1 < g.WW) ? 1 : 0;
+                                        for (int dy = dy0; dy <= dy1; ++dy)
+                                            for (int dx = dx0; dx <= dx1; ++dx) {
+                                                const unsigned blk = (unsigned)((by + dy) * g.WW + w + dx);
+                                                atomicOr(&bitmap[blk >> 5], 1u << (blk & 31));
+                                            }
+                                    }
+                                }
+                            }
+#endif
                         } else {
                         if (q == 0 && gw < words && v) {  // rare: only words with set bits are stored (tagged with their frame)
                             // (the word index through an opaque move: everything derived from it -- the store's address, the block
@@ -1271,7 +1324,9 @@ __device__ __forceinline__ bool morph_block_keep(const unsigned* __restrict__ bl
 // its longest frame, 0.19 ms per 1000-frame pass).  The waves of a frame share nothing but the frame's list counter.
 template <bool COUNTED>
 __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __restrict__ blockcnt, unsigned* __restrict__ worklist,
-                                                              unsigned* __restrict__ workcount, PassGeom g, int wpf) {
+                                                              unsigned* __restrict__ workcount, PassGeom g, int wpf, int dilate) {
+    // dilate = 0 (COUNTED = false only): the bitmap already names every block that can produce output (flagged with their
+    // neighbours where needed by the window kernel's candidate test): the list is the bitmap
     RAISE_WAVE_PRIORITY();
     const int nb = (g.H + MORPH_RB - 1) / MORPH_RB;
     const unsigned per_frame = (unsigned)(nb * g.WW);
@@ -1323,7 +1378,11 @@ __global__ void __launch_bounds__(256) k_morph_select_touched(const unsigned* __
         unsigned cand = 0;
         if (d < stride) {
             const int p = 32 * (int)d;
-            for (int dy = -g.WW; dy <= g.WW; dy += g.WW) cand |= bits_at(p + dy - 1) | bits_at(p + dy) | bits_at(p + dy + 1);
+            if (dilate) {
+                for (int dy = -g.WW; dy <= g.WW; dy += g.WW) cand |= bits_at(p + dy - 1) | bits_at(p + dy) | bits_at(p + dy + 1);
+            } else {
+                cand = bm[d];
+            }
             const int left = (int)per_frame - p;  // blocks the dword covers
             if (left < 32) cand &= (1u << left) - 1u;
         }

@@ -3,6 +3,8 @@
 Bar: bit-exact -- binary images, lit counts, threshold series, raw Hough segments (discovery order), NMS output.
 The noise EMA is float64 on both sides but summed differently (exact int64 sums on the GPU vs np.std): rtol 1e-12.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -275,7 +277,7 @@ def test_m3_dense_binaries_direct_mapped_morphology(shape):
     run_pair(frames, n, mask, cfg, batch=13, max_batch=13)
 
 
-@pytest.mark.parametrize("cand", ["2", "1", "0"])
+@pytest.mark.parametrize("cand", ["1", "2", "0"])
 @pytest.mark.parametrize("shape,n", [((70, 192), 4), ((40, 64 * 62), 8), ((33, 64 * 63), 5), ((50, 64 * 125), 16), ((9, 64), 2)])
 def test_m3_dense_output_format_forced(shape, n, cand, monkeypatch):
     """MDH_DENSE=1: every batched pass runs in the dense format (the window kernel writes every word of b plainly, the 64-bit
@@ -283,7 +285,7 @@ def test_m3_dense_output_format_forced(shape, n, cand, monkeypatch):
     wave shifts at every stage) -- noise frames, flat frames, streak frames; widths of one word, below / at / across the 62-column
     wave boundary and across two of them; every window length class of the wide-load kernels."""
     monkeypatch.setenv("MDH_DENSE", "1")
-    monkeypatch.setenv("MDH_DENSE_CAND", cand)  # 2: morphology always driven by candidate blocks; 1 (default): by the bit density; 0: round 4's form
+    monkeypatch.setenv("MDH_DENSE_CAND", cand)  # 1 (default): candidate blocks flagged by the window kernel; 2: by a sweep over the plain words; 0: none (round 4)
     mask = np.ones(shape, np.uint8)
     cfg = binary_cfg(adaptive=False, init_value=3, hough=(10, 10, 2))
     noise = frames_normal(sum(shape) + n, 12, shape, 30, 2.5)
@@ -302,9 +304,10 @@ def test_m3_dense_output_format_forced(shape, n, cand, monkeypatch):
     det.close()
 
 
+@pytest.mark.parametrize("cand", ["1", "2"])
 @pytest.mark.parametrize("n", [2, 8])
-def test_m3_dense_candidate_blocks_crafted(n, monkeypatch):
-    """The dense format's candidate test (round 5): k_dense_candidates flags a block only when one of its words holds two set bits
+def test_m3_dense_candidate_blocks_crafted(n, cand, monkeypatch):
+    """The dense format's candidate test (round 5; cand 1: inside the window kernel, 2: the sweep kernel): a block is flagged only when one of its words holds two set bits
     at most two columns apart IN ONE ROW -- the least a 3x3 window needs to collect its 5 of 9 -- and the morphology looks at the
     flagged blocks' neighbourhoods only.  Crafted clusters that just make the median, placed where the test has to reach across:
     a word boundary (x = 63 | 64), the boundary between two 16-lane DPP rows (x = 255 | 256: four words per row), a wave boundary
@@ -312,7 +315,7 @@ def test_m3_dense_candidate_blocks_crafted(n, monkeypatch):
     twice there), clusters whose pair and whose single bits sit in different words and different rows, and clusters one bit short
     (nothing may come out, nothing may be missed next to them).  Isolated noise bits all around keep 9 % of the words busy."""
     monkeypatch.setenv("MDH_DENSE", "1")
-    monkeypatch.setenv("MDH_DENSE_CAND", "2")
+    monkeypatch.setenv("MDH_DENSE_CAND", cand)
     H, W = 48, 64 * 36
     mask = np.ones((H, W), np.uint8)
     cfg = binary_cfg(adaptive=False, init_value=9, hough=(10, 10, 2))
