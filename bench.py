@@ -818,7 +818,9 @@ def run_per_frame(a, D, wl, mask):
             np.copyto(b, host_frames[k % len(host_frames)])  # the loader refills the buffer (untimed: stands for its decode)
             return b
     else:
-        fresh = [host_frames[i].copy() for i in range(min(64, len(host_frames)))]
+        # (the whole period, like the other two legs: the same seamless stream, the same share of streak frames -- up to round 5's
+        # first collection this leg cycled the first 64 frames, 44 % of them with a streak against the stream's 36 %)
+        fresh = [host_frames[i].copy() for i in range(len(host_frames))]
         source = lambda k: fresh[k % len(fresh)]
     tally = [0, 0, 0]
     split = {"quiet": [0, 0.0], "streak": [0, 0.0]}
