@@ -111,3 +111,40 @@ def test_hough_planes_equal_oracle(mask_share):
             seen_tiers["gapmax"] += gap > 5
         eng.close()
     assert seen_tiers["big"] > 0 and seen_tiers["gap0" if mask_share < 1 else "gapmax"] > 0, seen_tiers
+
+
+@pytest.mark.parametrize("shape", [(540, 960), (270, 1920)])
+def test_hough_point_counts_at_the_kernel_boundaries(shape):
+    """Frames with exactly 8191 ... 8193 and 32767 ... 32769 lit pixels: the last frame of the three-wave kernels' LDS point list, the
+    first and the last of the hybrid replay with a visiting-order table of the frame's own (HOUGH_BIG_LIST), the first of the one-wave
+    kernel -- scattered pixels plus two streaks, so that every route has segments to find, in one pass so that the classifier sends
+    neighbours down different routes side by side."""
+    H, W = shape
+    cfg = binary_cfg()
+    rng = np.random.default_rng(8192)
+    counts = [8191, 8192, 8193, 32767, 32768, 32769]
+    imgs = []
+    for N in counts:
+        im = np.zeros((H, W), np.uint8)
+        draw_line(im, W * 0.1, H * 0.15, W * 0.1 + 180, H * 0.15 + 70, width=3)
+        draw_line(im, W * 0.7, H * 0.8, W * 0.7 + 120, H * 0.8 - 95, width=2)
+        free = np.flatnonzero(im.ravel() == 0)
+        need = N - int(np.count_nonzero(im))
+        im.ravel()[rng.choice(free, need, replace=False)] = 255
+        assert int(np.count_nonzero(im)) == N
+        imgs.append(im)
+    K = len(imgs)
+    plan = BandPlan(H, W, 1, (0, 0, H, W))
+    mask_area = float(H * W)
+    eng = HipBandEngine(plan, 0, 2, cfg, mask_area, K, 0)
+    planes = np.stack([pack_rows(im, plan.WW) for im in imgs])[None]
+    info, raw, nms, prob = eng.hough_stage(planes, K)
+    for j, im in enumerate(imgs):
+        dst_sum = float(np.sum(im / 255.) / mask_area * 100)
+        gap = max(0, 1 - dst_sum / 0.05) * cfg.hough_line.max_gap
+        want = co.hough_lines_p(im, 1, np.pi / 180.0, cfg.hough_line.threshold, cfg.hough_line.min_len, gap)
+        assert int(info[j]["lit_count"]) == counts[j]
+        assert int(info[j]["n_raw"]) == len(want) and len(want) > 0, (counts[j], int(info[j]["n_raw"]), len(want))
+        k = min(len(want), _lib.MDH_MAX_LINES)
+        assert np.array_equal(raw[j, :k], want[:k]), counts[j]
+    eng.close()
