@@ -143,6 +143,11 @@ def load():
     # runtime initialises, i.e. at the process's first HIP call).  The C library itself never touches the environment; this
     # binding does, once, here, and only when the host has not decided: an unchanged MetDetPy.py gets the tuned value.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(_hw_queues))
+    # a job of several ranks (WORLD_SIZE > 1): RCCL's buffers cross process boundaries through dmabuf IPC -- the only kind the
+    # MI355X hosts' driver supports; with the legacy mode the communicator fails with `hipIpcGetMemHandle: invalid argument`.
+    # Read when the runtime initialises as well, so it is set here, not next to the communicator (rccl.py), and only if unset.
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     L = C.CDLL(LIB_PATH)
     if not hasattr(L, "mdh_create") and hasattr(L, "mdh_collector_create"):
         L = _HostOnlyLibrary(L)
