@@ -1037,6 +1037,23 @@ def main():
         if a.mode == "streams" and getattr(D, "per_rank", None):
             out["detections"]["per_rank_raw_segments"] = [row[0] for row in D.per_rank]
     out.update(extra)
+    if (D.world > 1 and a.mode == "streams" and a.protocol == "batch" and a.parity_frames > 0 and r.get("frames_sample") is not None
+            and DETECTOR == "m3" and HOUGH_MODE == "exact" and a.workload != "C1e"):
+        # N > 1: every rank checks ITS OWN stream (seed + rank) against the oracle -- first periods frame by frame and the timed
+        # region's tallies, like the one-GPU line -- on its own host cores, at the same time; rank 0 prints its own object in full
+        # and the verdicts of all ranks.  (A rank that fails says so instead of leaving the others waiting.)
+        try:
+            mine = parity_check(r["frames_sample"], n, mask, D.local, a.parity_frames, timed=r.get("timed") if a.warmup > 0 else None)
+        except Exception as e:  # noqa: BLE001
+            mine = {"verdict": f"error: {type(e).__name__}: {e}"}
+        every = D.all_gather_object({"rank": D.rank, "verdict": mine.get("verdict"),
+                                     "timed_region": (mine.get("timed_region") or {}).get("verdict")})
+        if D.rank == 0:
+            mine["per_rank"] = every
+            verdicts = {e["verdict"] for e in every}
+            if len(verdicts) > 1 or mine.get("verdict") not in verdicts:
+                mine["verdict"] = "MISMATCH on some rank: " + json.dumps(sorted(str(v) for v in verdicts))
+            out["parity"] = mine
     if D.rank == 0:
         if r["prof"]:
             live = None
