@@ -2819,7 +2819,15 @@ struct mdh_pre {
     size_t src_cap = 0, out_cap = 0;
     int span_cap = 0;          // k_preprocess_rows: bytes of a source row one workgroup stages (0: the layout does not allow that kernel)
     uint64_t rows_touched = 0; // source rows the resize reads per source frame (the kernel's compulsory traffic: mdh_pre_traffic_model)
+    // Frames handed over in HOST memory travel through two pinned buffers of the library's own (CPU copy of chunk k + 1 beside the
+    // DMA of chunk k): the caller's pages are never pinned by the runtime on the fly.  Round 5: twice in ten sessions of the whole
+    // GPU suite the process was aborted inside mdh_pre_run on the one test case whose pageable source exceeds a megabyte (6 MB,
+    // on a stream created a moment before) -- not reproduced in isolation (600 iterations) nor under MALLOC_CHECK_; this path does
+    // not depend on how the runtime moves pageable memory.  MDH_PRE_STAGE=0: hipMemcpyAsync straight from the caller's memory (A/B).
+    uint8_t* h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
 };
+static const size_t PRE_STAGE_BYTES = 8u << 20;
 
 // OpenCV resize(INTER_LINEAR) coefficient tables: fx = (float)((d+0.5)*scale-0.5), clamp, weights cvRound(w*2048)
 static void linear_table(int dst_n, int src_n, std::vector<int>& idx, std::vector<short>& w) {
@@ -2845,6 +2853,10 @@ extern "C" void mdh_pre_destroy(mdh_pre* p) {
     void* dev[] = {p->d_xi, p->d_yi, p->d_xw, p->d_yw, p->d_mask, p->d_src, p->d_out};
     for (void* q : dev)
         if (q) hipFree(q);
+    for (int k = 0; k < 2; ++k) {
+        if (p->h_stage[k]) hipHostFree(p->h_stage[k]);
+        if (p->ev_stage[k]) hipEventDestroy(p->ev_stage[k]);
+    }
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
 }
@@ -2929,7 +2941,26 @@ extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int 
             HIPCHK(hipMalloc((void**)&p->d_src, need));
             p->src_cap = need;
         }
-        HIPCHK(hipMemcpyAsync(p->d_src, bgr, need, hipMemcpyHostToDevice, p->stream));
+        static const bool stage = !(getenv("MDH_PRE_STAGE") && atoi(getenv("MDH_PRE_STAGE")) == 0);
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, bgr) == hipSuccess && at.type == hipMemoryTypeHost;  // (the caller's own pinned memory: as it is)
+        if (!pinned) (void)hipGetLastError();
+        if (!stage || pinned) {
+            HIPCHK(hipMemcpyAsync(p->d_src, bgr, need, hipMemcpyHostToDevice, p->stream));
+        } else {
+            for (int k = 0; k < 2; ++k) {
+                if (!p->h_stage[k]) HIPCHK(hipHostMalloc((void**)&p->h_stage[k], PRE_STAGE_BYTES, hipHostMallocDefault));
+                if (!p->ev_stage[k]) HIPCHK(hipEventCreateWithFlags(&p->ev_stage[k], hipEventDisableTiming));
+            }
+            int k = 0;
+            for (size_t off = 0; off < need; off += PRE_STAGE_BYTES, k ^= 1) {
+                const size_t len = std::min(PRE_STAGE_BYTES, need - off);
+                if (off >= 2 * PRE_STAGE_BYTES) HIPCHK(hipEventSynchronize(p->ev_stage[k]));  // the DMA that last read this buffer
+                memcpy(p->h_stage[k], bgr + off, len);
+                HIPCHK(hipMemcpyAsync(p->d_src + off, p->h_stage[k], len, hipMemcpyHostToDevice, p->stream));
+                HIPCHK(hipEventRecord(p->ev_stage[k], p->stream));
+            }
+        }
         src = p->d_src;
     }
     const int px = p->g.dh * p->g.dw;

@@ -2944,12 +2944,14 @@ __device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int n = lane + 64 * q;
+        int size = 0;
         if (n < NUM_ANGLE) {
             const float c = P.trig[2 * n], sn = P.trig[2 * n + 1];
             const int r00 = rho_bin(bx0, by0, c, sn, 0), r10 = rho_bin(bx1, by0, c, sn, 0);
             const int r01 = rho_bin(bx0, by1, c, sn, 0), r11 = rho_bin(bx1, by1, c, sn, 0);
-            cells += max(max(r00, r10), max(r01, r11)) - min(min(r00, r10), min(r01, r11)) + 1;
+            size = max(max(r00, r10), max(r01, r11)) - min(min(r00, r10), min(r01, r11)) + 1;
         }
+        cells += max(size, __shfl_xor(size, 1));  // angles 2a and 2a + 1 share the dwords of the larger window (hough3_frame)
     }
     for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
     const int mask_dw = (by1 - by0 + 1) * ((bx1 >> 6) - (bx0 >> 6) + 1) * 2;
@@ -3000,7 +3002,14 @@ struct Hough3 {
     const HoughParams& P;
     float tc, ts;          // this thread's angle
     unsigned vinc;         // 1 for a thread with an angle, 0 for the 12 spare lanes (their votes add nothing to a private cell)
-    int cbase;             // LDS cell of rho bin r (before the +half shift): r + cbase
+    // Cells are 16 bits wide, two per dword, each biased by CELL_BIAS (a +-1 on one half never carries into the other).  Round 5:
+    // the two halves of a dword belong to two ANGLES -- thread 2a owns the low halves, thread 2a + 1 the high halves of a window of
+    // dwords the pair shares (adjacent angles: nearly the same rho range) -- so which half a vote goes to, the shifted increment and
+    // the shift that extracts a returned count are per-thread constants instead of five vector instructions per vote (up to
+    // round 4 a thread's window was a run of consecutive halves, and the parity of r + cbase picked the half).
+    int cbase;             // LDS DWORD of rho bin r (before the +half shift): r + cbase
+    int sh;                // 0 / 16: this thread's half
+    unsigned vone;         // vinc << sh: one vote
     bool in_lds;           // HYBRID: this angle's window lives in LDS
     bool dead;             // HYBRID: the window does not, and no cell of it can ever hold `threshold` votes: the angle is out of the replay
     int* acc_row;          // HYBRID: this angle's row of the pooled global accumulator, shifted by half
@@ -3056,9 +3065,8 @@ __device__ __forceinline__ unsigned h3_vote_issue(Hough3& C, float x, float y, u
     // holds it instead of once per vote by every one of the 192 threads, round 3)
     const int r = __float2int_rn(__fadd_rn(__fmul_rn(x, C.tc), __fmul_rn(y, C.ts)));
     if (!HYBRID || C.in_lds) {
-        const int c = r + C.cbase;
-        sh = (c & 1) * 16;
-        return atomicAdd(&C.cells[c >> 1], (C.vinc & inc) << sh);
+        sh = C.sh;
+        return atomicAdd(&C.cells[r + C.cbase], C.vone & (0u - inc));
     }
     sh = -1;
     if (C.dead) return (unsigned)(-KEY_BIAS - 2);  // (read as a count: below every threshold)
@@ -3077,8 +3085,7 @@ __device__ __forceinline__ void h3_unvote(Hough3& C, float x, float y) {
     const int r = __float2int_rn(__fadd_rn(__fmul_rn(x, C.tc), __fmul_rn(y, C.ts)));
     if (ACC && r == C.best_r) C.dirty = true;
     if (!HYBRID || C.in_lds) {
-        const int c = r + C.cbase;
-        atomicSub(&C.cells[c >> 1], C.vinc << ((c & 1) * 16));
+        atomicSub(&C.cells[r + C.cbase], C.vone);
     } else if (!C.dead) {
         C.touched_global = true;
         atomicSub(&C.acc_row[r], 1);
@@ -3234,10 +3241,7 @@ __device__ void h3_line(Hough3& C, int x, int y, int bn) {
 template <bool HYBRID>
 __device__ __forceinline__ int h3_cell_now(Hough3& C, float x, float y) {
     const int r = __float2int_rn(__fadd_rn(__fmul_rn(x, C.tc), __fmul_rn(y, C.ts)));
-    if (!HYBRID || C.in_lds) {
-        const int c = r + C.cbase;
-        return (int)((C.cells[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
-    }
+    if (!HYBRID || C.in_lds) return (int)((C.cells[r + C.cbase] >> C.sh) & 0xFFFFu) - CELL_BIAS;
     if (C.dead) return -KEY_BIAS;  // below the winner's count (>= threshold), whatever the angle's true count (< threshold) is
     return atomicAdd(&C.acc_row[r], 0);
 }
@@ -3278,7 +3282,6 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list, const unsigned
             unsigned hits = 0;
             {
                 unsigned raw[H3_SUB];
-                unsigned odd = 0;  // bit j: slot j's cell is the upper half of its dword
                 unsigned hasm = 0;
 #pragma unroll
                 for (int j = 0; j < H3_SUB; ++j) {
@@ -3290,7 +3293,6 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list, const unsigned
                         int sh;
                         raw[j] = h3_vote_issue<HYBRID>(C, __uint_as_float((unsigned)__builtin_amdgcn_readlane(fxb, l)),
                                                       __uint_as_float((unsigned)__builtin_amdgcn_readlane(fyb, l)), has ? 1u : 0u, sh);
-                        odd |= (sh > 0 ? 1u : 0u) << j;
                     }
                 }
                 if (TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -3302,7 +3304,7 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list, const unsigned
                 for (int j = 0; j < H3_SUB; ++j) {
                     val[j] = -KEY_BIAS;
                     if (j < gused && ((hasm >> j) & 1)) {
-                        if (!HYBRID || C.in_lds) val[j] = (int)((raw[j] >> (((odd >> j) & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
+                        if (!HYBRID || C.in_lds) val[j] = (int)((raw[j] >> C.sh) & 0xFFFFu) - CELL_BIAS;
                         else val[j] = (int)raw[j];
                         vmax = max(vmax, val[j]);
                     }
@@ -3367,8 +3369,7 @@ __device__ void h3_replay(Hough3& C, int N, const unsigned* list, const unsigned
 // segment.  It is a DIFFERENT algorithm from cv2.HoughLinesP: its segments are compared with the exact replay's under SURVEY
 // 8d's tolerance rule (rho / theta of matched segments, collector records), never bit for bit.
 __device__ __forceinline__ int h3_cell_value(const Hough3& C, int r) {
-    const int c = r + C.cbase;
-    return (int)((C.cells[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) - CELL_BIAS;
+    return (int)((C.cells[r + C.cbase] >> C.sh) & 0xFFFFu) - CELL_BIAS;
 }
 template <bool HYBRID, bool TM>
 __device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, int w_size) {
@@ -3460,9 +3461,8 @@ __device__ void h3_accumulate(Hough3& C, int N, const unsigned* list, int w_lo, 
             if (tid == bn) {
                 C.dirty = true;
                 if (!HYBRID || C.in_lds) {
-                    const int c = rho + C.cbase;
-                    atomicAnd(&C.cells[c >> 1], ~(0xFFFFu << ((c & 1) * 16)));
-                    atomicOr(&C.cells[c >> 1], (unsigned)CELL_BIAS << ((c & 1) * 16));
+                    atomicAnd(&C.cells[rho + C.cbase], ~(0xFFFFu << C.sh));
+                    atomicOr(&C.cells[rho + C.cbase], (unsigned)CELL_BIAS << C.sh);
                 } else {
                     C.acc_row[rho] = 0;
                 }
@@ -3585,9 +3585,12 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
         w_lo = min(min(r00, r10), min(r01, r11));
         w_size = max(max(r00, r10), max(r01, r11)) - w_lo + 1;
     }
-    int placed = w_size, total = 0;
+    // storage: angles 2a and 2a + 1 share a window of dwords (low / high halves), as long as the larger of their two windows --
+    // both threads of a pair ask for `w_st` halves, so every decision below (fits / goes to the global accumulator) is the pair's
+    int w_st = max(w_size, __shfl_xor(w_size, 1));
+    int placed = w_st, total = 0;
     if (HYBRID) {
-        h3_scan(w_size, total, fix + 32, lane, wave);
+        h3_scan(w_st, total, fix + 32, lane, wave);
         if (total > cell_cap && cell_cap > 0) {
             // The corner windows do not fit.  A streak is thin and usually oblique, so the rho range its points really span is
             // up to a third smaller than what the corners of its bounding box span.  Round 2 swept the point list for the exact
@@ -3636,8 +3639,9 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
                 w_lo = rmin;
                 w_size = rmax - rmin + 1;
             }
-            placed = w_size;
-            h3_scan(w_size, total, fix + 32, lane, wave);
+            w_st = max(w_size, __shfl_xor(w_size, 1));
+            placed = w_st;
+            h3_scan(w_st, total, fix + 32, lane, wave);
         }
         if (total > cell_cap) {
             // still too many: the smallest windows first (the angles across the streak, where the votes pile up) -- the largest
@@ -3645,45 +3649,45 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
             // larger than its own (180 LDS reads, one barrier) instead of a bisection with a workgroup-wide scan per step.
             unsigned* const wsz = cells;
             if (HOUGH3_THREADS + 1 <= cell_cap / 2) {
-                wsz[tid] = (unsigned)w_size;
+                wsz[tid] = (unsigned)w_st;
                 if (tid == 0) wsz[HOUGH3_THREADS] = 0;
                 __syncthreads();
                 int mine = 0;
                 for (int j = 0; j < NUM_ANGLE; ++j) {
                     const int wj = (int)wsz[j];
-                    mine += wj <= w_size ? wj : 0;
+                    mine += wj <= w_st ? wj : 0;
                 }
-                if (tid < NUM_ANGLE && mine <= cell_cap) atomicMax(&wsz[HOUGH3_THREADS], (unsigned)w_size);
+                if (tid < NUM_ANGLE && mine <= cell_cap) atomicMax(&wsz[HOUGH3_THREADS], (unsigned)w_st);
                 __syncthreads();
                 const int lo = (int)wsz[HOUGH3_THREADS];
-                placed = w_size <= lo ? w_size : 0;
+                placed = w_st <= lo ? w_st : 0;
                 __syncthreads();
             } else {
                 int lo = 0, hi = P.numrho;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     int sum;
-                    h3_scan(w_size <= mid ? w_size : 0, sum, fix + 32, lane, wave);
+                    h3_scan(w_st <= mid ? w_st : 0, sum, fix + 32, lane, wave);
                     if (sum <= cell_cap) lo = mid; else hi = mid - 1;
                 }
-                placed = w_size <= lo ? w_size : 0;
+                placed = w_st <= lo ? w_st : 0;
             }
         }
     }
-    const int off = h3_scan(placed, total, fix + 32, lane, wave);
+    const int off = h3_scan(placed, total, fix + 32, lane, wave);  // (in halves; both threads of a pair placed the same amount, so a pair starts on a dword)
     const int cell_dw = (total + 1) / 2;
     // ---- initialise: cells at the bias, one private zero cell per thread for the spare lanes
     for (int p = tid; p < cell_dw; p += HOUGH3_THREADS) cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
     cells[cell_dw + tid] = 0;
     __syncthreads();
-    Hough3 C{P, tc, ts, tid < NUM_ANGLE ? 1u : 0u, 0, true, false, nullptr, cells, mask_lds, lmask, by0, rows, 2 * wlo, 2 * wpr, gmask, P.WW,
+    Hough3 C{P, tc, ts, tid < NUM_ANGLE ? 1u : 0u, 0, 16 * (tid & 1), (tid < NUM_ANGLE ? 1u : 0u) << (16 * (tid & 1)), true, false, nullptr, cells, mask_lds, lmask, by0, rows, 2 * wlo, 2 * wpr, gmask, P.WW,
              (int)rint(P.out_gap[i]), i, 0, lane, wave, tid, fix, uv, false, {0, 0, 0, 0, 0, 0, 0, 0}};
     if (tid < NUM_ANGLE) {
         C.in_lds = placed > 0;
-        C.cbase = off - w_lo;
+        C.cbase = (((tid & 1) ? off - placed : off) >> 1) - w_lo;  // the pair's first dword, rho bin w_lo of THIS angle on it
         if (HYBRID) C.acc_row = P.accum + (size_t)slot * NUM_ANGLE * P.numrho + (size_t)tid * P.numrho + P.half;
     } else {
-        C.cbase = 2 * (cell_dw + tid);  // r is 0 for the spare lanes (tc = ts = 0): their private cell
+        C.cbase = cell_dw + tid;  // r is 0 for the spare lanes (tc = ts = 0): their private dword
     }
     if (HYBRID && !P.acc_mode && !P.no_lds_acc) {
         // Angles whose window went to the pooled global accumulator (the LARGEST windows: the directions across which the streak
