@@ -91,6 +91,8 @@ def parse():
                     "passes (4000 / 2000 / 1000 / 500 frames) are whole multiples of it, so a resubmitted pass CONTINUES the "
                     "stream (frame 249 -> frame 0 is seamless) instead of starting on a scene cut")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--window", type=int, default=None, help="override the workload's window length n (the reference's default `window_sec: 1` "
+                    "gives n = 25 / 30 at 25 / 30 frames per second, Detector.py:200; BASELINE's configs quote n = 8 and 16)")
     ap.add_argument("--stream", default="sky", choices=sorted(STREAMS), help="the synthetic stream's weather: sky = SURVEY 8d's friendly one "
                     "(N(30, 2.5), one streak per 50 frames); noisy = sigma 6 under m3det_low (Hough 10 / 15 / 8); hot = 1 %% hot pixels; cloud = a "
                     "cloud-edge frame every 50 frames (> 8192 lit pixels for n frames); sparse / dense = a streak in ~5 %% / ~80 %% of the frames")
@@ -573,7 +575,7 @@ def pmc_traffic_live(a, dense, kern=None):
     if exe is None:
         return None, "rocprofv3 is not on PATH"
     kern = kern or ("k_classic_diff" if DETECTOR == "classic" else "k_stack_threshold")
-    base = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--stream", a.stream, "--batch", str(a.batch), "--unique", str(a.unique),
+    base = [sys.executable, os.path.abspath(__file__), "--workload", a.workload] + (["--window", str(a.window)] if a.window is not None else []) + ["--stream", a.stream, "--batch", str(a.batch), "--unique", str(a.unique),
             "--steps", "3", "--warmup", "1", "--passes-per-step", "1", "--no-secondary", "--depth", "1", "--cpu-seconds", "0", "--parity-frames", "0", "--standalone-passes", "0",
             "--no-profile", "--no-pmc", "--detector", a.detector, "--hough-mode", a.hough_mode]
     if a.sensitivity:
@@ -633,9 +635,11 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=Fal
         waves = -(-words // 16)
         nchunks = max(1, min(-(-8192 // waves), B // 8))
     else:                      # launch_wide: 16 pixels per lane up to n = 16
-        waves = -(-words // 16) if W % 64 == 0 and n <= 16 else -(-words // 8)
+        waves = -(-words // 16) if W % 64 == 0 and n <= 16 else -(-words // 8)  # (n = 17 .. 32: the 8-pixels-per-lane variants)
         nchunks = max(1, min(-(-4096 // waves), B // (2 * n)))
     tc = -(-B // nchunks)
+    if DETECTOR != "classic" and W % 64 == 0 and n <= 32:
+        tc = -(-tc // n) * n  # (round 6: every time chunk but the last is a whole number of window periods, launch_wide)
     nchunks = -(-B // tc)
     compulsory = frame * (B + nchunks * (n - 1))
     if dense:
@@ -954,10 +958,15 @@ def main():
     a = parse()
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("MDH_BENCH_FORCE_DIST") != "1" and not a.no_secondary and a.gpus == 1
             and a.mode == "streams" and a.protocol == "batch" and a.workload == "C2" and a.stream == "sky" and a.detector == "m3"
-            and a.hough_mode == "exact" and not a.host_input and a.depth == 0 and a.sensitivity is None):
+            and a.hough_mode == "exact" and not a.host_input and a.depth == 0 and a.sensitivity is None and a.window is None):
         return orchestrate(a)
     D = Dist()
-    wl = WORKLOADS[a.workload]
+    wl = dict(WORKLOADS[a.workload])
+    if a.window is not None:
+        wl["n"] = a.window
+        old_text = f"{WORKLOADS[a.workload]['n']}-frame window"
+        wl["desc"] = (wl["desc"].replace(old_text, f"{a.window}-frame window (--window)") if old_text in wl["desc"]
+                      else wl["desc"] + f", {a.window}-frame window (--window)")
     H, W, n = wl["H"], wl["W"], wl["n"]
     global SENSITIVITY, DETECTOR, HOUGH_MODE, STREAM
     STREAM = a.stream

@@ -14,6 +14,7 @@
 // cross the pixel -> Hough boundary and the result mirrors exist twice ("slots"); state that is carried from frame
 // to frame (frame ring, ring of binaries, running scalars) is only touched on the main stream, in stream order.
 #include "metdet_kernels.hpp"
+#include "metdet_window.hpp"
 #include "metdet_pre.hpp"
 #include "metdet_host.hpp"  // error text, lineset_nms, the native collector: host-only code, also built alone under ASan / UBSan
 
@@ -73,6 +74,7 @@ struct Slot {
     long long* d_sums = nullptr;
     ScalarState* d_jobres = nullptr;
     int* d_thr = nullptr;
+    WinRec* d_wrec = nullptr;  // [K + WIN_PAD] the window kernel's per-frame records (k_noise_finalize)
     hipEvent_t ev_noise = nullptr;
     // dst is only written where it is non-zero; d_nzlist names the candidate words and k_sparse_clear zeroes them again
     // on the staging stream before the slot's next pass (k_pass_prepare, ahead of ev_noise).
@@ -185,6 +187,7 @@ struct mdh_ctx {
     long long* d_sums = nullptr;
     ScalarState* d_jobres = nullptr;
     int* d_thr = nullptr;
+    WinRec* d_wrec = nullptr;
     unsigned* d_bandflag = nullptr;
     ScalarState* d_state = nullptr;  // running scalars, only touched on the noise stream
     ActWord* d_bbits = nullptr;  // alias of the current slot's buffer (set by slot_begin)
@@ -454,7 +457,7 @@ static void free_all(mdh_ctx* c) {
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->h_inject) hipHostFree(c->h_inject);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_bbits, s.d_bplain, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr};
+        void* sdev[] = {s.d_bbits, s.d_bplain, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr, s.d_wrec};
         for (void* p : sdev)
             if (p) hipFree(p);
         void* shost[] = {s.h_hdr, s.h_res};
@@ -670,7 +673,8 @@ static int create_impl(mdh_ctx* c) {
     for (int si = 0; si < c->nslot; ++si) {
         Slot& s = c->slot[si];
         {
-            const size_t ptr_bytes = (sizeof(uint8_t*) * (c->n - 1 + K) + 15) & ~(size_t)15;
+            // (+ WIN_PAD copies of the last entry: the batched window kernels read their table without clamping the index, see WinRec)
+            const size_t ptr_bytes = (sizeof(uint8_t*) * (c->n - 1 + K + WIN_PAD) + 15) & ~(size_t)15;
             s.hdr_jobs_off = ptr_bytes;
             TRY(host_alloc(s.h_hdr, ptr_bytes + sizeof(NoiseJob) * K));
             TRY(dev_alloc(s.d_hdr, ptr_bytes + sizeof(NoiseJob) * K));
@@ -685,6 +689,7 @@ static int create_impl(mdh_ctx* c) {
         TRY(dev_alloc(s.d_sums, 2 * K));
         TRY(dev_alloc(s.d_jobres, K + 1));
         TRY(dev_alloc(s.d_thr, K));
+        TRY(dev_alloc(s.d_wrec, K + WIN_PAD));
         HIPCHK(hipEventCreateWithFlags(&s.ev_noise, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_k1, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s.ev_close, hipEventDisableTiming));
@@ -975,6 +980,42 @@ static PassGeom geom(const mdh_ctx* c, int K, int64_t t_base) {
     return g;
 }
 
+// Window lengths above 16 have wide-load instantiations with 8 pixels per lane (round 6: the reference's default `window_sec: 1`
+// is n = 25 / 30, Detector.py:200).  (MDH_WIDE8_MAXN=16 sends them back to round 1's byte-load kernel for A/B)
+static bool long_window_wide(int n) {
+    static const int wide8_max_n = getenv("MDH_WIDE8_MAXN") ? atoi(getenv("MDH_WIDE8_MAXN")) : 32;
+    return n > 16 && n <= std::min(32, wide8_max_n);
+}
+// The window kernels' translation units (metdet_window.hip, one object per part of the window lengths): the part that holds the
+// instantiation answers.
+static int win_launch(const WindowLaunch& w) {
+    return mdh_win_launch_p0(w) || mdh_win_launch_p1(w) || mdh_win_launch_p2(w) || mdh_win_launch_p3(w) || mdh_win_launch_p4(w) || mdh_win_launch_p5(w);
+}
+static int win_mail(const MailLaunch& m) {
+    return mdh_win_mail_p0(m) || mdh_win_mail_p1(m) || mdh_win_mail_p2(m) || mdh_win_mail_p3(m) || mdh_win_mail_p4(m) || mdh_win_mail_p5(m);
+}
+// waves per SIMD an instantiation runs at (= resident 256-thread workgroups per CU): asked of the runtime once per (n, pixels per lane)
+// (round 6: the pass tables moved several instantiations to another occupancy step; up to round 5 a table of register counts)
+static int win_occupancy(int n, int ppl) {
+    static int cache[33][2];
+    if (n < 2 || n > 32) return 2;
+    int& e = cache[n][ppl == 16];
+    if (e == 0) {
+        int v = 0;
+        for (int p = 0; p < MDH_WIN_PARTS && !v; ++p) {
+            switch (p) {
+                case 0: v = mdh_win_occupancy_p0(n, ppl); break;
+                case 1: v = mdh_win_occupancy_p1(n, ppl); break;
+                case 2: v = mdh_win_occupancy_p2(n, ppl); break;
+                case 3: v = mdh_win_occupancy_p3(n, ppl); break;
+                case 4: v = mdh_win_occupancy_p4(n, ppl); break;
+                default: v = mdh_win_occupancy_p5(n, ppl); break;
+            }
+        }
+        e = v > 0 ? v : 2;
+    }
+    return e;
+}
 // Alignment the frames of the pass being queued allow the window kernel's loads: wide loads need contiguous 64-byte words
 // (W % 64 == 0) and aligned frame bases.  >= 8 with 2 <= n <= 16: a wide-load variant runs (the only ones with a dense output).
 static unsigned pass_alignment(const mdh_ctx* c, int K) {
@@ -984,9 +1025,11 @@ static unsigned pass_alignment(const mdh_ctx* c, int K) {
         while (align > 1 && ((uintptr_t)c->h_ptrtab[e] & (align - 1))) align >>= 1;
     return align;
 }
-static bool wide_kernel_applies(const mdh_ctx* c, int K) {  // (the 16-pixels-per-lane variants: the ones with a dense output)
+static bool wide_kernel_applies(const mdh_ctx* c, int K) {  // (the variants with a dense output: 16 pixels per lane up to n = 16, 8 per lane for n = 17 .. 32)
     static const int wide16_max_n = getenv("MDH_WIDE16_MAXN") ? atoi(getenv("MDH_WIDE16_MAXN")) : 16;
-    return pass_alignment(c, K) >= 16 && c->n >= 2 && c->n <= std::min(16, wide16_max_n) && !c->force_ppl8;
+    const unsigned align = pass_alignment(c, K);
+    if (c->n > 16) return align >= 8 && long_window_wide(c->n);
+    return align >= 16 && c->n >= 2 && c->n <= std::min(16, wide16_max_n) && !c->force_ppl8;
 }
 
 // Momentum of the next EMA update (host mirror of utils.py:360-368; advances the schedule).
@@ -1018,6 +1061,7 @@ static int stage_frames(mdh_ctx* c, Slot& sl, const uint8_t* frames, int K, int 
         const int64_t rs = (t_base + i) % c->R;
         c->h_ptrtab[c->n - 1 + i] = on_device ? frames + (size_t)i * c->HW : c->d_ring + (size_t)rs * c->HW;
     }
+    for (int e = 0; e < WIN_PAD; ++e) c->h_ptrtab[c->n - 1 + K + e] = c->h_ptrtab[c->n - 2 + K];  // padding: the pass's last frame again
     if (sl.dense && !wide_kernel_applies(c, K)) sl.dense = false;  // (decided before k_pass_prepare: the sparse format wants its block counters zeroed)
     if (c->lean_direct) {
         // no copy commands at all: the table entry of the frame is the caller's (pinned) buffer, the table itself stays in
@@ -1103,28 +1147,27 @@ static void mail_cancel(mdh_ctx* c) {
     c->mail_armed = false;
     c->mail_misses += 1;
 }
-// Queue the NEXT frame's window kernel (end of mdh_update): n = 2..16, 16 pixels per lane, one chunk -- what launch_wide<N, 16>
-// launches for a direct frame.
+// Queue the NEXT frame's window kernel (end of mdh_update): n = 2..16 with 16 pixels per lane, n = 17..32 with 8, one chunk -- what
+// launch_wide<N, 16 | 8> launches for a direct frame.
+static constexpr int mail_ppl(int n) { return n > 16 ? 8 : 16; }
 static void mail_prelaunch(mdh_ctx* c, const MailClean& cl) {
     const int words = (int)c->words;
-    const unsigned grid = (unsigned)(((words + 15) / 16 + 3) / 4);
+    const int ppl = mail_ppl(c->n);
+    const unsigned grid = (unsigned)(((words + ppl - 1) / ppl + 3) / 4);
     c->mail_seq += 1;
     if (c->mail_seq == 0 || c->mail_seq == ~0u) c->mail_seq = 1;
     unsigned* go = c->d_read_count + 32;
-    switch (c->n) {
-#define MAIL_CASE(N) case N: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_mail<N>), dim3(grid, 1), dim3(256), 0, c->nstream, c->h_mail, c->mail_seq, go, cl); break;
-        MAIL_CASE(2) MAIL_CASE(3) MAIL_CASE(4) MAIL_CASE(5) MAIL_CASE(6) MAIL_CASE(7) MAIL_CASE(8) MAIL_CASE(9)
-        MAIL_CASE(10) MAIL_CASE(11) MAIL_CASE(12) MAIL_CASE(13) MAIL_CASE(14) MAIL_CASE(15) MAIL_CASE(16)
-#undef MAIL_CASE
-        default: return;
-    }
+    if (c->n > 16 && !long_window_wide(c->n)) return;
+    if (!win_mail(MailLaunch{c->n, ppl, grid, c->nstream, c->h_mail, c->mail_seq, go, cl})) return;
     if (hipGetLastError() != hipSuccess) return;  // (not queued: the next frame is launched the usual way)
     c->mail_armed = true;
     c->mail_n = c->n;
     c->mail_grid = grid;
 }
-template <int N, int PPL>
-static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
+// One launch of a wide-load window kernel, N = g.n frames per window, PPL = 16 or 8 pixels per lane (the instantiations live in
+// the window translation units: metdet_window.hip)
+static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean, const int PPL) {
+    const int N = g.n;
     const int words = (int)c->words;
     const int waves = (words + PPL - 1) / PPL;
     static const int target_waves = getenv("MDH_WIN_WAVES") ? atoi(getenv("MDH_WIN_WAVES")) : 4096;  // experiment switch
@@ -1141,21 +1184,26 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
         // is 1143 workgroups on 768 resident slots, 1.49 rounds (the isolated launch 0.47 -> 0.53-0.56 of the peak with 12-16 chunks,
         // +2 % at the pipeline's pace, where the next pass's launch fills the tail anyway).
         static const bool balance = !(getenv("MDH_WIN_BALANCE") && atoi(getenv("MDH_WIN_BALANCE")) == 0);
-        const int occ = N <= 2 ? 8 : (N == 3 ? 5 : (N <= 6 ? 4 : (N <= 9 ? 3 : 2)));  // waves per SIMD the 16-pixel kernel is built for
+        // waves per SIMD the instantiation runs at (= resident 256-thread workgroups per CU): asked of the runtime once (round 6: the
+        // pass tables moved several instantiations to another occupancy step; up to round 5 a table of register counts)
+        const int occ = win_occupancy(N, PPL);
         const double resident = 256.0 * occ * 4 / wpb;
         const double wgs = (double)((waves + wpb - 1) / wpb);
         auto eff = [&](int nc) { const double r = wgs * nc / resident; return r / std::ceil(r); };
-        if (balance && PPL == 16) {
+        if (balance) {
             int best = nchunks;
             for (int nc = nchunks + 1; nc <= std::min(cap, 2 * nchunks + 2); ++nc)
                 if (eff(nc) > eff(best) + 0.04) best = nc;
             nchunks = best;
         }
     }
-    const int Tc = (g.K + nchunks - 1) / nchunks;
+    int Tc = (g.K + nchunks - 1) / nchunks;
+#if WIDE_TABLES
+    if (!lean.copy_dst) Tc = (Tc + N - 1) / N * N;  // every time chunk but the last: whole window periods (the kernel tests nothing per frame, see WinRec)
+#endif
     nchunks = (g.K + Tc - 1) / Tc;
     if (lean.copy_dst) {  // per-frame protocol: its own instantiation, the batched one pays nothing for it
-        if (c->mail_armed && PPL == 16 && c->mail_n == N && nchunks == 1 && c->mail_grid == (unsigned)((waves + 3) / 4) && wpb == 4 &&
+        if (c->mail_armed && PPL == mail_ppl(N) && c->mail_n == N && nchunks == 1 && c->mail_grid == (unsigned)((waves + 3) / 4) && wpb == 4 &&
             c->stream == c->nstream && __atomic_load_n(&c->h_mail->state, __ATOMIC_ACQUIRE) != ~c->mail_seq) {
             // the kernel is waiting (or about to be resident): hand it the frame
             unsigned pay[MAIL_PAYLOAD] = {0};
@@ -1165,7 +1213,7 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
             a.thr_tab = c->d_thr; a.bbits = c->d_bbits; a.blockcnt = c->d_bandflag; a.g = g; a.Tc = Tc; a.lean = lean;
             memcpy(pay, &a, sizeof(a));
             memcpy(pay + MAIL_ARG_DW, c->h_ptrtab, sizeof(uint8_t*) * (size_t)(N - 1 + 1));
-            constexpr int nch = (MAIL_ARG_DW + 2 * N + 14) / 15;
+            const int nch = (MAIL_ARG_DW + 2 * N + 14) / 15;
             for (int ch = 0; ch < nch; ++ch) memcpy((void*)&c->h_mail->line[ch][0], pay + 15 * ch, 60);
             __atomic_thread_fence(__ATOMIC_RELEASE);
             for (int ch = nch - 1; ch >= 0; --ch) __atomic_store_n(&c->h_mail->line[ch][15], mail_line_tag(pay + 15 * ch, c->mail_seq), __ATOMIC_RELEASE);
@@ -1194,17 +1242,16 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean) {
             mail_cancel(c);
         }
         if (!c->mail_used)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, true>), dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream,
-                               c->d_ptrtab, c->d_thr, c->d_bbits, c->d_bandflag, g, Tc, lean, (unsigned long long*)nullptr);
+            win_launch(WindowLaunch{N, PPL, WIN_LEAN, dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr, c->d_bbits,
+                                    c->d_bandflag, g, Tc, lean, nullptr, nullptr});
     }
-    else if (PPL == 16 && c->win_dense)  // dense output format: 16-pixels-per-lane variants only (its own instantiation as well)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, 16, false, true>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, (ActWord*)c->win_plain, dense_candidates_inline() ? c->d_bandflag : (unsigned*)nullptr, g, Tc, lean, c->win_nzwords);
+    else if (wide_has_dense(N, PPL) && c->win_dense)  // dense output format (its own instantiation as well)
+        win_launch(WindowLaunch{N, PPL, WIN_DENSE, dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr,
+                                (ActWord*)c->win_plain, dense_candidates_inline() ? c->d_bandflag : (unsigned*)nullptr, g, Tc, lean, c->win_nzwords, c->d_wrec});
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stack_threshold_wide<N, PPL, false>), dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds,
-                           c->stream, c->d_ptrtab, c->d_thr, c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean,
-                           c->win_nzwords);
-    c->win_dense_used = PPL == 16 && c->win_dense && !lean.copy_dst;
+        win_launch(WindowLaunch{N, PPL, WIN_SPARSE, dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr,
+                                c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean, c->win_nzwords, c->d_wrec});
+    c->win_dense_used = wide_has_dense(N, PPL) && c->win_dense && !lean.copy_dst;
 }
 
 // copy_dst: see k_stack_threshold_wide (per-frame protocol; the caller has made sure a wide-load variant applies)
@@ -1219,19 +1266,14 @@ static void launch_stack_threshold(mdh_ctx* c, const PassGeom& g, const LeanArgs
     // 16 pixels per lane up to n = 16 (252 VGPRs at n = 16: still two waves per SIMD; 4K / n = 16: 1.35 -> 0.92 ms per 512 frames)
     static const int wide16_max_n = getenv("MDH_WIDE16_MAXN") ? atoi(getenv("MDH_WIDE16_MAXN")) : 16;  // A/B switch
     if (align >= 16 && g.n >= 2 && g.n <= std::min(16, wide16_max_n) && !c->force_ppl8) {
-        switch (g.n) {
-#define W16_CASE(N) case N: launch_wide<N, 16>(c, g, copy_dst); return;
-            W16_CASE(2) W16_CASE(3) W16_CASE(4) W16_CASE(5) W16_CASE(6) W16_CASE(7) W16_CASE(8)
-            W16_CASE(9) W16_CASE(10) W16_CASE(11) W16_CASE(12) W16_CASE(13) W16_CASE(14) W16_CASE(15) W16_CASE(16)
-#undef W16_CASE
-        }
+        launch_wide(c, g, copy_dst, 16);
+        return;
     }
-    if (align >= 8 && g.n >= 2 && g.n <= 16) {
-        switch (g.n) {
-#define W8_CASE(N) case N: launch_wide<N, 8>(c, g, copy_dst); return;
-            W8_CASE(2) W8_CASE(3) W8_CASE(4) W8_CASE(5) W8_CASE(6) W8_CASE(7) W8_CASE(8) W8_CASE(9) W8_CASE(10) W8_CASE(11) W8_CASE(12) W8_CASE(13) W8_CASE(14) W8_CASE(15) W8_CASE(16)
-#undef W8_CASE
-        }
+    // windows of 17 .. 32 frames (round 6; the reference's default `window_sec: 1` at 25 / 30 frames per second, Detector.py:200):
+    // 8 pixels per lane -- the window of a 16-pixel lane does not fit two waves per SIMD (MDH_WIDE8_MAXN=16 for A/B: round 1's byte-load kernel)
+    if (align >= 8 && g.n >= 2 && (g.n <= 16 || long_window_wide(g.n))) {
+        launch_wide(c, g, copy_dst, 8);
+        return;
     }
     switch (g.n) {
 #define TB_CASE(N) case N: launch_tb<N>(c, g); break;
@@ -1310,7 +1352,8 @@ static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
     span_begin(c, KK_NOISE_FINAL, c->nstream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
                        sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount,
-                       (c->seek_at >= 0 && c->cfg.detector == MDH_DET_M3) ? (int)std::max<int64_t>(0, std::min<int64_t>(K, c->seek_at + c->n - 1 - sl.t_base)) : 0);
+                       (c->seek_at >= 0 && c->cfg.detector == MDH_DET_M3) ? (int)std::max<int64_t>(0, std::min<int64_t>(K, c->seek_at + c->n - 1 - sl.t_base)) : 0,
+                       c->cfg.detector == MDH_DET_M3 ? sl.d_wrec : (WinRec*)nullptr, c->n, (long long)sl.t_base);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     EV_REC(c, sl.ev_noise, c->nstream);
@@ -1340,7 +1383,7 @@ static int run_noise_direct(mdh_ctx* c, Slot& sl) {
     span_end(c, c->nstream);
     span_begin(c, KK_NOISE_FINAL, c->nstream);
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), 0, c->nstream, c->d_jobs, 1, c->d_sums, c->d_state, c->d_jobres, sl.d_fscal, c->d_thr, 1,
-                       (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, (unsigned*)nullptr, 0);
+                       (double)rh * rw, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, (unsigned*)nullptr, 0, (WinRec*)nullptr, c->n, (long long)sl.t_base);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     return MDH_OK;
@@ -1746,7 +1789,7 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     static const bool tag_pass = getenv("MDH_TAG_PASS") != nullptr;
     if (tag_pass) c->tag_lds = 1024u * (1 + (unsigned)((c->pass_seq + c->in_flight) % 3));
     c->cur_spans = &sl.spans;
-    c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr;
+    c->d_ptrtab = sl.d_ptrtab; c->d_jobs = sl.d_jobs; c->d_sums = sl.d_sums; c->d_jobres = sl.d_jobres; c->d_thr = sl.d_thr; c->d_wrec = sl.d_wrec;
     c->d_bandflag = sl.d_bandflag; c->d_bbits = sl.d_bbits;
     out = &sl;
     return MDH_OK;
@@ -1943,7 +1986,7 @@ extern "C" int mdh_collect_batch(mdh_ctx* c, mdh_frame_info* info, int32_t* raw_
 // Returns the device-visible address of the frame, or null (the general path: DMA copy, header copy, prepare, noise chain).
 static const uint8_t* lean_direct_source(mdh_ctx* c, const Slot& sl, const uint8_t* frame) {
     if (!c->lean_direct_on || !sl.was_clean || !sl.h_hdr_dev) return nullptr;
-    if (c->cfg.detector != MDH_DET_M3 || c->W % 64 != 0 || c->force_generic || c->force_bytes || c->n < 2 || c->n > 16) return nullptr;
+    if (c->cfg.detector != MDH_DET_M3 || c->W % 64 != 0 || c->force_generic || c->force_bytes || c->n < 2 || (c->n > 16 && !long_window_wide(c->n))) return nullptr;
     const int64_t t = c->t + 1;
     const int64_t std_interval = (int64_t)c->cfg.interval * c->n;
     c->lean_due = t > c->n && std_interval > 0 && t % std_interval == 0;

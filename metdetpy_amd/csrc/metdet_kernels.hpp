@@ -11,9 +11,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 typedef unsigned long long u64;
 typedef unsigned __int128 u128;
+
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant in the body
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 #define NUM_ANGLE 180
 #define HOUGH_TIERS 5  // launches a pass's frames are routed to (k_hough_classify)
@@ -125,6 +133,7 @@ __global__ void __launch_bounds__(256) k_noise_sums(const uint8_t* const* __rest
     }
 }
 
+#ifndef MDH_WINDOW_ONLY
 // Same sums with one byte load per pixel: used when rows or frame bases are not 4-byte aligned.
 __global__ void __launch_bounds__(256) k_noise_sums_bytes(const uint8_t* const* __restrict__ ptrtab,
                                                           const NoiseJob* __restrict__ jobs, long long* __restrict__ sums,
@@ -158,6 +167,32 @@ __global__ void __launch_bounds__(256) k_noise_sums_bytes(const uint8_t* const* 
     }
 }
 
+#endif  // MDH_WINDOW_ONLY
+// PASS TABLES (round 6).  The batched window kernels used to spend a third of their instructions on the scalar unit: per frame a
+// clamped index, a 64-bit address and a load for the frame's table entry, the same for its threshold, three moves to make a buffer
+// descriptor of the pointer, T * len, the window length, the "is this frame still inside my chunk" test -- ~31 scalar instructions
+// beside ~32 vector ones per wave-frame at 8 pixels per lane (SQ_INST_CYCLES_SALU 0.22 of the wave cycles at n = 25, 0.15 at n = 16:
+// gpurun_out/r06_03).  Now: (1) the pointer table is PADDED with WIN_PAD copies of its last entry and the frame loads are global
+// loads with a scalar base (no descriptor), so an entry is one s_load at a constant offset from a running pointer; (2)
+// k_noise_finalize writes one WinRec per pass-frame -- T * len replicated into both halves and -len -- padded with WIN_PAD
+// records of T = 256 (no pixel can pass), loaded the same way a burst ahead; (3) every time chunk but the last is a whole number
+// of window periods, so nothing is tested per frame: the frames a chunk's last period reaches past the pass are padding that
+// cannot fire.  (A/B builds: -DWIDE_TABLES=0.  The per-frame instantiations keep the old form: their table arrives by mailbox.)
+#ifndef WIDE_TABLES
+#define WIDE_TABLES 1
+#endif
+#ifndef WIDE_EVEN_BURSTS
+#define WIDE_EVEN_BURSTS 1  // (A/B builds: -DWIDE_EVEN_BURSTS=0: bursts of the requested size plus a remainder, as up to round 5)
+#endif
+#ifndef WIDE_PIN152
+#define WIDE_PIN152 1  // (A/B builds: -DWIDE_PIN152=0)
+#endif
+#define WIN_PAD 96  // >= 2 window periods + 2 load bursts of the longest window (32): how far a chunk's loads run past its last frame
+struct WinRec {
+    unsigned v;  // low half: min(T, 256) * len, high half: (0 - len) & 0xFFFF (len = the frame's window length): one scalar register per frame
+};
+__host__ __device__ inline WinRec make_winrec(unsigned T, unsigned len) { return WinRec{(T * len) | (((0u - len) & 0xFFFFu) << 16)}; }
+#ifndef MDH_WINDOW_ONLY
 // Running scalars of LineDetector kept on the device so a pass never waits for the host.
 struct ScalarState {
     double ema_v;     // stack.snr
@@ -188,7 +223,8 @@ __global__ void __launch_bounds__(NF_THREADS) k_noise_finalize(const NoiseJob* _
                                                         const long long* __restrict__ sums, ScalarState* __restrict__ st,
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
                                                         int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
-                                                        double coef_a, double coef_b, unsigned* __restrict__ nzcount, int mute_pix) {
+                                                        double coef_a, double coef_b, unsigned* __restrict__ nzcount, int mute_pix,
+                                                        WinRec* __restrict__ wrec, int n, long long t_base) {
     RAISE_WAVE_PRIORITY();
     // the slot's list counters ([0] lit words, [1] morphology blocks): k_pass_prepare, earlier on this stream, was their last reader
     if (nzcount && threadIdx.x < 4) nzcount[threadIdx.x] = 0;  // ([2..3]: the window kernel's count of words with set bits)
@@ -285,9 +321,18 @@ __global__ void __launch_bounds__(NF_THREADS) k_noise_finalize(const NoiseJob* _
         out[i].snr = s.ema_v;
         out[i].sigma = s.sigma;
         out[i].thr = s.thr;
+        if (wrec != nullptr) {  // the window kernel's per-frame record (see WinRec): T >= 256 can never fire, the clamp keeps T * len in 16 bits
+            const long long t = t_base + 1 + i;
+            const unsigned len = (unsigned)(t < n ? t : n);
+            const unsigned T = (unsigned)min(max(i < mute_pix ? 256 : s.thr, 0), 256);
+            wrec[i] = make_winrec(T, len);
+        }
     }
+    if (wrec != nullptr)  // padding behind the pass: frames that cannot fire
+        for (int i = threadIdx.x; i < WIN_PAD; i += blockDim.x) wrec[K + i] = make_winrec(256u, (unsigned)n);
 }
 
+#endif  // MDH_WINDOW_ONLY
 // Bit images that are almost entirely zero are kept SPARSE and TAGGED.
 // (1) The thresholded difference b of a pass ([K][H][WW], per slot): the window kernel stores only the words with set bits --
 // writing the zeros too made a quarter of its run time (mixed read / write HBM traffic, tools/hbm_read_probe.hip).
@@ -335,6 +380,7 @@ __device__ __forceinline__ void note_block(unsigned* __restrict__ blockcnt, cons
 // floor(s/len) < c  <=>  s < c*len for integer c, so no division is needed:
 //   b = (max > T) && (sum < (max - T) * len)
 // Generic-n version: one lane per pixel, n byte loads per pixel (the "algorithmic" (n+1) reads of SURVEY 8d).
+#ifndef MDH_WINDOW_ONLY
 __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* const* __restrict__ ptrtab,
                                                                  const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                                  unsigned* __restrict__ blockcnt, PassGeom g) {
@@ -366,6 +412,7 @@ __global__ void __launch_bounds__(256) k_stack_threshold_generic(const uint8_t* 
     }
 }
 
+#endif  // MDH_WINDOW_ONLY
 // Time-blocked version (the fast path): one wave owns 256 pixels (4 bit words) and walks through a run of
 // consecutive frames keeping the n-frame window in registers, so every frame byte is fetched ONCE per pass
 // instead of n times.  Lane l holds pixels {l, 64+l, 128+l, 192+l} of the chunk as two packed u16 pairs, which
@@ -500,7 +547,16 @@ __global__ void __launch_bounds__(256) k_stack_threshold_tb(const uint8_t* const
 #define WIDE_MAX3 1  // sliding maximum on v_pk_maximum3_f16 (A/B builds: -DWIDE_MAX3=0 keeps round-2b's three two-input maxima per frame)
 #endif
 #ifndef WIDE_RAW_MINN
-#define WIDE_RAW_MINN 99  // window length from which the wide kernel keeps its window as raw bytes (A/B builds: -DWIDE_RAW_MINN=2)
+#define WIDE_RAW_MINN 99  // window length from which the 16-pixels-per-lane kernel keeps its window as raw bytes (A/B builds: -DWIDE_RAW_MINN=2)
+#endif
+#ifndef WIDE_RAW8_MINN
+#define WIDE_RAW8_MINN 99  // the same for the 8-pixels-per-lane kernel (A/B builds: -DWIDE_RAW8_MINN=17)
+#endif
+#ifndef WIDE_U8_BIGN
+// frames per load burst of the 8-pixels-per-lane kernel for windows of more than 16 frames: 5 up to n = 25 (168 registers: THREE waves
+// per SIMD; 1080p / n = 25 isolated 0.555 -> 0.636 of the peak against bursts of 8 at two waves, gpurun_out/r06_05), 8 above (two waves
+// either way; n = 30: 0.535 against 0.514 with bursts of 5)
+#define WIDE_U8_BIGN(N) ((N) <= 25 ? 5 : 8)
 #endif
 #ifndef WIDE_PTR_AHEAD
 #define WIDE_PTR_AHEAD 1  // frame bases requested one burst ahead of the loads that use them (A/B builds: -DWIDE_PTR_AHEAD=0)
@@ -545,7 +601,9 @@ template <int N, int PPL, bool LEAN, bool DENSE>
 __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                               unsigned* __restrict__ blockcnt, const PassGeom& g, int Tc,
-                                                              const LeanArgs& lean, unsigned long long* __restrict__ nzwords) {
+                                                              const LeanArgs& lean, unsigned long long* __restrict__ nzwords,
+                                                              const WinRec* __restrict__ wrec = nullptr) {
+    constexpr bool TAB = WIDE_TABLES != 0 && !LEAN;  // pass tables (see WinRec)
     // DENSE (its own instantiation: the sparse one must not pay a register for it; batched passes on streams whose binaries are dense: 8K at m3det_high, where the lowered threshold lets noise
     // through and 9 % of the words carry a bit): EVERY word of b is written, plainly -- u64 [K][H][WW] in the same buffer, no
     // tags, no block counters, 128 contiguous bytes per wave and frame -- and k_morph_close_plain reads it.  The sparse-tagged
@@ -571,7 +629,12 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     constexpr int DW = PPL / 4;   // dwords per load
     constexpr int LPW = 64 / PPL; // lanes per 64-pixel word
     constexpr int UW = N > 8 ? WIDE_U16_BIGN : WIDE_U16;
-    constexpr int U = PPL == 16 ? (N < UW ? N : UW) : (N < 8 ? N : 8);
+    constexpr int UREQ = PPL == 16 ? (N < UW ? N : UW) : (N < 8 ? N : (N > 16 ? WIDE_U8_BIGN(N) : 8));  // longest burst asked for
+    // Bursts of (nearly) EQUAL size (round 6): NB bursts per window period, burst b = frames b N / NB .. (b + 1) N / NB - 1.  Up to
+    // round 5 a period was cut into bursts of UREQ frames plus the remainder -- 8 + 8 + 8 + 1 at n = 25, 4 + 4 + 1 at n = 9: behind a
+    // burst of ONE frame the wave waits for the next burst's loads with nothing left to compute, once per period.
+    constexpr int NB = (N + UREQ - 1) / UREQ;                       // bursts per window period
+    constexpr int U = WIDE_EVEN_BURSTS ? (N + NB - 1) / NB : UREQ;  // the longest burst (size of the burst arrays)
     typedef unsigned dvec __attribute__((ext_vector_type(DW)));
     const int lane = threadIdx.x & 63;
     const int words = g.H * g.WW;
@@ -590,25 +653,36 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     const int q = lane % LPW;
     const int gw = gw0 + lane / LPW;
     const int frame_bytes = g.H * g.W;
-    const int off = gw < words ? gw * 64 + q * PPL : 0x7FFFFFF0;  // past the frame -> zeros
+    const int off = gw < words ? gw * 64 + q * PPL : (TAB ? 0 : 0x7FFFFFF0);  // past the frame -> zeros (TAB: any valid address; such lanes store nothing)
 #if WIDE_DENSE_CAND
-    // bit 0: this lane holds the first 16 pixels of an image row, bit 1: the last 16 (a set pixel on the replicated border counts twice)
+    // bit 0: this lane holds the first PPL pixels of an image row, bit 1: the last PPL (a set pixel on the replicated border counts twice)
     const unsigned edge_lr = DENSE ? (((gw % g.WW == 0 && q == 0) ? 1u : 0u) | ((gw % g.WW == g.WW - 1 && q == LPW - 1) ? 2u : 0u)) : 0u;
 #endif
     union PK {
         unsigned u;
         u16x2 v;
     };
-    auto fetch = [&](int e) -> dvec {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
+    typedef const __attribute__((address_space(1))) dvec* gdvec_p;
+    typedef const __attribute__((address_space(1))) uint8_t* gbyte_p;
+    auto fetchp = [&](const uint8_t* base) -> dvec {  // a frame's bytes of this lane, the frame's base in scalar registers
+        if constexpr (TAB) {
+            // global load, scalar base + 32-bit lane offset (no descriptor to assemble).  (the offset through an opaque move: extended
+            // to 64 bits once outside the loop, every load would need a 64-bit vector add instead of the scalar-base address form)
+            unsigned o = (unsigned)off;
+            asm volatile("" : "+v"(o));
+            if constexpr (WIDE_AUX == 2) return __builtin_nontemporal_load((gdvec_p)((gbyte_p)base + o));
+            else return *(gdvec_p)((gbyte_p)base + o);
+        }
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, frame_bytes, 0x00020000);
         if constexpr (PPL == 16) {
             return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         } else {
             return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         }
     };
-    auto fetchp = [&](const uint8_t* base) -> dvec {  // the same with the frame's base already in scalar registers
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, frame_bytes, 0x00020000);
+    auto fetch = [&](int e) -> dvec {
+        if constexpr (TAB) return fetchp(ptrtab[e]);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ptrtab[e], 0, frame_bytes, 0x00020000);
         if constexpr (PPL == 16) {
             return __builtin_bit_cast(dvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LEAN ? LEAN_AUX : WIDE_AUX));
         } else {
@@ -633,7 +707,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     // used: when its frame leaves the window (the running sum) and when its group is refilled (the sliding maximum) -- two more
     // permutes per pair and frame, half the window's registers: n = 16: 128 -> 64, n = 8: 64 -> 32 (a wave more per SIMD).
     constexpr bool MAX3_ = WIDE_MAX3 != 0 && GS == 4 && !LEAN;
-    constexpr bool RAW = MAX3_ && PPL == 16 && N >= WIDE_RAW_MINN;
+    constexpr bool RAW = MAX3_ && N >= (PPL == 16 ? WIDE_RAW_MINN : WIDE_RAW8_MINN);
     dvec raw[N];
     auto W = [&](int k, int r) -> PK {
         if constexpr (RAW) {
@@ -667,11 +741,14 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     // the first burst of frames.  LEAN (one frame, read from the caller's buffer over PCIe): requested BEFORE the window history,
     // so that the 45 us the bus needs start at once and the history's HBM reads (n - 1 frames) run under them
     const int e_max = g.K + N - 2;
-    constexpr int NB = (N + U - 1) / U;  // bursts per window period
+    // first frame of burst b (b = NB: the period's end) and its number of frames; static after unrolling
+#define BSTART(b) (WIDE_EVEN_BURSTS ? (b) * N / NB : ((b) * U < N ? (b) * U : N))
+#define BCNT(b) (BSTART((b) + 1) - BSTART(b))
     dvec buf2[2][U];
     if constexpr (LEAN) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
+        for (int u = 0; u < U; ++u)
+            if (u < BCNT(0)) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
     }
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
@@ -722,9 +799,19 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     // instead of being copied.  A single buffer refilled as soon as a frame is unpacked -- 16 registers less -- was measured and
     // lost 4 % stand-alone and 9 % in the pipeline at 1080p, 40 % at 4K: half the bytes in flight per wave.)
     constexpr bool PINGPONG = WIDE_MAX3 != 0 && !LEAN && (NB % 2 == 0);
+    // TAB: running pointers into the padded tables (entry of the new frame of step s of the current period: pt[s], its record: wr[s])
+    const uint8_t* const* pt = ptrtab + i0 + (N - 1);
+    const WinRec* wr = wrec + i0;
     if constexpr (!LEAN) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) buf2[0][u] = fetch(min(i0 + u + N - 1, e_max));
+        for (int u = 0; u < U; ++u)
+            if (u < BCNT(0)) buf2[0][u] = TAB ? fetchp(pt[u]) : fetch(min(i0 + u + N - 1, e_max));
+    }
+    WinRec wq2[2][U];  // TAB: the records of the burst being computed and of the next one
+    if constexpr (TAB) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u < BCNT(0)) wq2[0][u] = wr[u];
     }
     // Frame bases one burst AHEAD of the loads that use them (round 4).  A load needs its frame's table entry in scalar registers;
     // fetched right in front of it, every one of a burst's U loads waited for its own scalar load (s_load, s_waitcnt, buffer_load,
@@ -735,41 +822,50 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
         constexpr int pp = 1 / NB, bb = 1 % NB;
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (bb * U + u < N) pq[u] = ptrtab[min(i0 + pp * N + bb * U + u + N - 1, e_max)];
+            if (u < BCNT(bb)) pq[u] = TAB ? pt[pp * N + BSTART(bb) + u] : ptrtab[min(i0 + pp * N + BSTART(bb) + u + N - 1, e_max)];
     }
     for (int sb = 0; sb < steps; sb += N) {
-#pragma unroll
-        for (int bi = 0; bi < NB; ++bi) {
-            const int ub = bi * U;
+        // (the burst index as a compile-time constant -- static_for -- instead of an unrolled loop variable: with bursts of unequal
+        // size the unroller's cost estimate no longer saw through the guards and gave up "unrolled size is too large")
+        static_for<NB>([&](auto BI) __attribute__((always_inline)) {
+            constexpr int bi = decltype(BI)::value;
+            constexpr int ub = BSTART(bi), ucnt = BCNT(bi);
             // thresholds of the burst up front (scalar loads, off the per-frame critical path; per burst, not per window period:
             // sixteen of them at n = 16 pushed the kernel's scalar registers into spills once the frame bases travelled ahead too)
             int Tp[U];
+            if constexpr (!TAB) {
 #pragma unroll
             for (int u = 0; u < U; ++u)  // T >= 256 can never fire (diff <= 255); the clamp keeps T * len inside 16 bits
-                if (ub + u < N) Tp[u] = min(__builtin_amdgcn_readfirstlane(thr_tab[min(i0 + sb + ub + u, g.K - 1)]), 256);
+                if (u < ucnt) Tp[u] = min(__builtin_amdgcn_readfirstlane(thr_tab[min(i0 + sb + ub + u, g.K - 1)]), 256);
+            }
             dvec(&cur)[U] = buf2[PINGPONG ? (bi & 1) : 0];
             dvec(&nxt)[U] = buf2[PINGPONG ? ((bi + 1) & 1) : 1];
+            WinRec(&wcur)[U] = wq2[PINGPONG ? (bi & 1) : 0];
+            WinRec(&wnxt)[U] = wq2[PINGPONG ? ((bi + 1) & 1) : 1];
             // (measured in round 2c: a workgroup barrier here, to keep the four waves on the same frames so that their loads of a
             // burst -- consecutive kilobytes of one frame -- reach the memory system together, changes nothing; eight-wave
             // workgroups with it lose 10 %)
             // prefetch the following burst (wraps into the next period)
-            const int nb_first = (bi + 1 < NB) ? sb + (bi + 1) * U : sb + N;
+            const int nb_first = (bi + 1 < NB) ? sb + BSTART(bi + 1) : sb + N;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool in_period = (bi + 1 < NB) ? ((bi + 1) * U + u < N) : (u < N);
+                const bool in_period = u < BCNT((bi + 1) % NB);
                 if (in_period) nxt[u] = PTR_AHEAD ? fetchp(pq[u]) : fetch(min(i0 + nb_first + u + N - 1, e_max));
+                if constexpr (TAB) {
+                    if (in_period) wnxt[u] = wr[(bi + 1 < NB) ? BSTART(bi + 1) + u : N + u];
+                }
             }
             if constexpr (PTR_AHEAD) {  // table entries of the burst after that one
                 const int pp = (bi + 2) / NB, bb = (bi + 2) % NB;
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (bb * U + u < N) pq[u] = ptrtab[min(i0 + sb + pp * N + bb * U + u + N - 1, e_max)];
+                    if (u < BCNT(bb)) pq[u] = TAB ? pt[pp * N + BSTART(bb) + u] : ptrtab[min(i0 + sb + pp * N + BSTART(bb) + u + N - 1, e_max)];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (ub + u < N) {
+                if (u < ucnt) {
                     const int s = sb + ub + u;
-                    if (s < steps) {
+                    if (TAB || s < steps) {  // (TAB: a chunk is whole periods, or runs into padding that cannot fire)
                         const int slot = (ub + u + N - 1) % N;
                         // The frame leaving the window is taken out of the sums BEFORE the new one is unpacked into its slot's
                         // registers (round 4: written as "sum + new - old" the compiler kept the old pairs alive in eight copies
@@ -791,9 +887,16 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                         // [-255 len, 510 len], i.e. inside int16 for len <= 16 (this kernel's N), so b is the sign bit of
                         // one packed multiply-add whose addend is sum + T * len (T >= 256 can never fire; clamping it
                         // keeps T * len in 16 bits).
-                        const int len = min(g.n, len0 + s);  // window_len(g, i)
-                        const unsigned short nlen = (unsigned short)(0 - len);
-                        const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[u] * len) * 0x10001u;  // scalar unit
+                        unsigned short nlen;
+                        unsigned tl;
+                        if constexpr (TAB) {
+                            nlen = (unsigned short)(wcur[u].v >> 16);
+                            tl = (wcur[u].v & 0xFFFFu) * 0x10001u;
+                        } else {
+                            const int len = min(g.n, len0 + s);  // window_len(g, i)
+                            nlen = (unsigned short)(0 - len);
+                            tl = (unsigned)__builtin_amdgcn_readfirstlane(Tp[u] * len) * 0x10001u;  // scalar unit
+                        }
                         // FOLD_TL: the addend T * len lives INSIDE the running sums (round 3: one add per pixel pair and frame less): it
                         // changes with the threshold -- at most at every (interval * n)-th frame -- and with the window length
                         // during the first n frames of a stream; then every sum takes the difference (32-bit arithmetic on two
@@ -925,8 +1028,9 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                             for (int o = 1; o < LPW; o <<= 1) v |= __shfl_xor(v, o);
                         }
                         if constexpr (DENSE) {
-                            nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0));
-                            if (q == 0 && gw < words) __builtin_nontemporal_store(v, &((u64*)bbits)[(size_t)i * words + gw]);
+                            const bool in_pass = !TAB || i < g.K;  // (TAB: the last period of the last chunk may reach past the pass)
+                            nz_mine += (unsigned)__popcll(__ballot(q == 0 && gw < words && v != 0 && in_pass));
+                            if (q == 0 && gw < words && in_pass) __builtin_nontemporal_store(v, &((u64*)bbits)[(size_t)i * words + gw]);
 #if WIDE_DENSE_CAND
                             // CANDIDATE BLOCKS (round 5).  The median keeps a pixel only with >= 5 set samples in its 3x3 window, i.e.
                             // only where SOME ROW holds two set bits at most two columns apart (on the replicated left / right image
@@ -941,12 +1045,12 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                             // a missed one).  Flagged through the block bitmap of the sparse format, non-returning atomics in a
                             // rare path (~1 % of the wave-frames).
                             if (blockcnt != nullptr) {
-                                const unsigned lt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(bits >> 14), 0x138, 0xF, 0xF, false);  // wave_shr:1
+                                const unsigned lt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(bits >> (PPL - 2)), 0x138, 0xF, 0xF, false);  // wave_shr:1
                                 const unsigned pair = bits & ((bits >> 1) | (bits >> 2));
                                 const unsigned lo2 = bits & 3u;
                                 const unsigned cross = lane == 0 ? lo2 : ((lo2 & (0u - (lt != 0))) & 1u) | (lo2 & lt & 2u);
-                                const unsigned edge = (bits & edge_lr & 1u) | ((bits >> 15) & (edge_lr >> 1));
-                                const bool cand = (pair | cross | edge) != 0 && gw < words;
+                                const unsigned edge = (bits & edge_lr & 1u) | ((bits >> (PPL - 1)) & (edge_lr >> 1));
+                                const bool cand = (pair | cross | edge) != 0 && gw < words && in_pass;
                                 if (__ballot(cand) != 0) {
                                     if (cand) {
                                         // the blocks this pair can light up: what comes out of median + close lies within 2 rows and
@@ -963,7 +1067,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
                                         const int by = y / MORPH_RB, ry = y - by * MORPH_RB;
                                         const int dy0 = (ry < 2 && by > 0) ? -1 : 0, dy1 = (ry >= MORPH_RB - 2 && by + 1 < nbands_) ? 1 : 0;
                                         const int dx0 = (q == 0 && (bits & 0x7u) && w > 0) ? -1 : 0;
-                                        const int dx1 = (q == LPW - 1 && (bits & 0xE000u) && w + 1 < g.WW) ? 1 : 0;
+                                        const int dx1 = (q == LPW - 1 && (bits & (7u << (PPL - 3))) && w + 1 < g.WW) ? 1 : 0;
                                         for (int dy = dy0; dy <= dy1; ++dy)
                                             for (int dx = dx0; dx <= dx1; ++dx) {
                                                 const unsigned blk = (unsigned)((by + dy) * g.WW + w + dx);
@@ -991,13 +1095,29 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
             if constexpr (!PINGPONG) {
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            if constexpr (TAB) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) wcur[u] = wnxt[u];
             }
+            }
+        });
+        if constexpr (TAB) {
+            pt += N;
+            wr += N;
         }
     }
+#undef BSTART
+#undef BCNT
     if constexpr (LEAN) lean_wave_done(lean, gridDim.x * gridDim.y * (blockDim.x >> 6));
     if constexpr (DENSE) {
         if (nzwords != nullptr && lane == 0 && nz_mine) atomicAdd(nzwords, (unsigned long long)nz_mine);
     }
+#if WIDE_PIN152
+    // With the pass tables the n = 7 .. 9 instantiations need 128-140 registers: FOUR waves per SIMD, which leave a Hough wave (54
+    // registers) no room beside them -- 960x540 at the pipeline's pace 8.5 M -> 7.5 M frames/s (gpurun_out/r06_04).  Naming v151
+    // as clobbered makes the kernel's allocation 152 registers: three window waves and 56 registers for a Hough wave, as in round 5.
+    if constexpr (TAB && !DENSE && PPL == 16 && N >= 7 && N <= 9) asm volatile("" ::: "v151");
+#endif
 }
 // waves per SIMD the instantiation is held to (0: whatever its natural register use allows).  Only the raw-window build asks: its
 // n = 16 kernel lands three registers above the 168 that three waves per SIMD allow (A/B builds: -DWIDE_RAW_MINN=2 -DWIDE_RAW_OCC=1)
@@ -1006,7 +1126,7 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
 #endif
 template <int N, int PPL, bool LEAN>
 constexpr int wide_min_waves() {
-    return (WIDE_RAW_OCC != 0 && WIDE_MAX3 != 0 && !LEAN && PPL == 16 && N >= WIDE_RAW_MINN) ? (N <= 8 ? 4 : (N <= 16 ? 3 : 0)) : 0;
+    return (WIDE_RAW_OCC != 0 && WIDE_MAX3 != 0 && !LEAN && PPL == 16 && N >= WIDE_RAW_MINN) ? (N <= 8 ? 4 : (N <= 16 ? 3 : 2)) : 0;
 }
 template <int N, int PPL, bool LEAN, bool DENSE = false>
 __global__ void
@@ -1018,8 +1138,9 @@ __launch_bounds__(256)
 WIDE_OCC k_stack_threshold_wide(const uint8_t* const* __restrict__ ptrtab,
                                                               const int* __restrict__ thr_tab, ActWord* __restrict__ bbits,
                                                               unsigned* __restrict__ blockcnt, PassGeom g, int Tc,
-                                                              LeanArgs lean, unsigned long long* __restrict__ nzwords) {
-    stack_threshold_wide_body<N, PPL, LEAN, DENSE>(ptrtab, thr_tab, bbits, blockcnt, g, Tc, lean, nzwords);
+                                                              LeanArgs lean, unsigned long long* __restrict__ nzwords,
+                                                              const WinRec* __restrict__ wrec) {
+    stack_threshold_wide_body<N, PPL, LEAN, DENSE>(ptrtab, thr_tab, bbits, blockcnt, g, Tc, lean, nzwords, wrec);
 }
 
 // The per-frame protocol's window kernel, launched AHEAD of its frame (round 3).  A frame's chain used to start with the host's
@@ -1071,7 +1192,7 @@ struct MailClean {
     int H;
 };
 #define MAIL_EXPIRE_TICKS 15000  // 150 us of the 100 MHz wall clock
-template <int N>
+template <int N, int PPL = 16>
 __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* __restrict__ mail, unsigned seq, unsigned* __restrict__ go, MailClean cl) {
     if (cl.blockcnt != nullptr) {  // the previous frame's slot, left as a fresh one's (that frame's launches are done: same stream)
         const unsigned gt = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, gn = gridDim.x * gridDim.y * blockDim.x;
@@ -1153,9 +1274,10 @@ __global__ void __launch_bounds__(256) WIDE_OCC k_stack_threshold_mail(MailBox* 
     const PassGeom g = a->g;
     const LeanArgs lean = a->lean;
     // (a->ptrtab is the host's to set: the table's copy behind the arguments, dpay + MAIL_ARG_DW)
-    stack_threshold_wide_body<N, 16, true, false>(a->ptrtab, a->thr_tab, a->bbits, a->blockcnt, g, a->Tc, lean, nullptr);
+    stack_threshold_wide_body<N, PPL, true, false>(a->ptrtab, a->thr_tab, a->bbits, a->blockcnt, g, a->Tc, lean, nullptr);
 }
 
+#ifndef MDH_WINDOW_ONLY  // (to the end of the file: everything that is not a window kernel)
 // ------------------------------------------------------------------------------------------------
 // Bit-stencil helpers on a 128-bit window: position p <-> pixel x = 64*w - 3 + p.
 struct Win {
@@ -3963,3 +4085,5 @@ __global__ void __launch_bounds__(64) k_perm_build(const unsigned* __restrict__ 
         }
     }
 }
+
+#endif  // MDH_WINDOW_ONLY

@@ -83,7 +83,7 @@ def run_pair(frames, n, mask, cfg, *, batch=None, check_act=True, max_batch=64, 
     return total_lines
 
 
-@pytest.mark.parametrize("shape,n", [((128, 256), 8), ((135, 192), 4), ((96, 128), 16), ((64, 64), 2)])
+@pytest.mark.parametrize("shape,n", [((128, 256), 8), ((135, 192), 4), ((96, 128), 16), ((64, 64), 2), ((72, 192), 25), ((40, 128), 32)])
 def test_m3_per_frame_from_pinned_memory(shape, n):
     """The per-frame protocol's fast path (the window kernel reads the caller's pinned buffer and the pointer table from
     host memory, no DMA / prepare / noise commands when no sigma is due; results announced through the polled word): same
@@ -98,7 +98,7 @@ def test_m3_per_frame_from_pinned_memory(shape, n):
     run_pair([s.next() for _ in range(30)], 4, np.ones(shape2, np.uint8), binary_cfg("normal"), pinned=True)
 
 
-@pytest.mark.parametrize("n", [4, 8, 16])
+@pytest.mark.parametrize("n", [4, 8, 16, 25, 30])
 def test_m3_per_frame_window_kernel_launched_ahead(n, monkeypatch):
     """The window kernel of the NEXT frame is queued by mdh_update behind the current frame's launches and waits on a mailbox in
     pinned host memory (k_stack_threshold_mail); the next mdh_update hands it its arguments instead of launching.  Forced on for
@@ -278,7 +278,7 @@ def test_m3_dense_binaries_direct_mapped_morphology(shape):
 
 
 @pytest.mark.parametrize("cand", ["1", "2", "0"])
-@pytest.mark.parametrize("shape,n", [((70, 192), 4), ((40, 64 * 62), 8), ((33, 64 * 63), 5), ((50, 64 * 125), 16), ((9, 64), 2)])
+@pytest.mark.parametrize("shape,n", [((70, 192), 4), ((40, 64 * 62), 8), ((33, 64 * 63), 5), ((50, 64 * 125), 16), ((9, 64), 2), ((40, 64 * 33), 25), ((21, 64 * 63), 30)])
 def test_m3_dense_output_format_forced(shape, n, cand, monkeypatch):
     """MDH_DENSE=1: every batched pass runs in the dense format (the window kernel writes every word of b plainly, the 64-bit
     direct-mapped morphology kernel k_morph_close_plain reads it: 62 word columns + 2 halo lanes per wave, edge bits through DPP
@@ -583,10 +583,10 @@ def test_hough_windows_too_big_for_lds_fall_back():
     run_pair([base, img, base], n, mask, cfg, check_act=False)
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 20, 24, 25, 29, 30, 31, 32])
 def test_m3_wide_load_window_kernels(n):
-    """Widths that are multiples of 64 take the wide-load window kernels (16 px/lane for n <= 8, 8 px/lane for
-    n <= 16); height chosen so the last wave is partly out of range."""
+    """Widths that are multiples of 64 take the wide-load window kernels (16 px/lane for n <= 16, 8 px/lane for
+    n = 17 .. 32: the reference's default window_sec 1 is n = 25 / 30); height chosen so the last wave is partly out of range."""
     shape = (37, 192)
     mask = np.ones(shape, np.uint8)
     frames = busy_frames(300 + n, 3 * n + 20, shape)

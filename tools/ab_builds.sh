@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of several builds of the library on ONE box (one gpurun call):  bash tools/ab_builds.sh OUTDIR "name=libpath ..." "WL ..."
-# e.g. hipcc ... -DWIDE_U16_BIGN=2 -shared -o metdetpy_amd/libmetdet_hip_u2.so metdet_hip.hip;  bash tools/ab_builds.sh r04_21 "def=metdetpy_amd/libmetdet_hip.so u2=metdetpy_amd/libmetdet_hip_u2.so" "C3"
+# e.g. make -C metdetpy_amd/csrc -j8 OUT=../../_ab/libu2.so OBJ=/tmp/ab_u2 EXTRA=-DWIDE_U16_BIGN=2;  bash tools/ab_builds.sh r04_21 "def=metdetpy_amd/libmetdet_hip.so u2=metdetpy_amd/libmetdet_hip_u2.so" "C3"
 # Every build is loaded through MDH_LIB; two alternating repetitions per workload; prints frames/s, the isolated launch, frac, frac at pace, stand-alone spans.
 O=gpurun_out/$1; mkdir -p $O
 C="--no-pmc --cpu-seconds 0 --parity-frames 0 --standalone-passes 12 --no-secondary --steps 5 --warmup 1"

@@ -20,6 +20,6 @@ for name in ("a", "b"):
         for row in csv.DictReader(open(f)):
             if "stack_threshold" in row["Kernel_Name"]: dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     n = max(len(seen), 1); wc = acc.get("SQ_WAVE_CYCLES", 1) / n
-    print(f"pass {name}: {n} launches of k_stack_threshold_wide (1080p, n = 8, 1024 frames), mean duration under the counters {sum(dur) / max(len(dur), 1) / 1e3:.1f} us")
+    print(f"pass {name}: {n} launches of k_stack_threshold_wide (1080p, n = " + __import__('os').environ.get('MDH_PROBE_N', '8') + f", 1024 frames), mean duration under the counters {sum(dur) / max(len(dur), 1) / 1e3:.1f} us")
     for c, v in sorted(acc.items()): print(f"   {c:28s} {v / n:16.0f}   {v / n / wc:6.3f} of SQ_WAVE_CYCLES")
 PY

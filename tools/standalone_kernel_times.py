@@ -6,7 +6,7 @@ import bench
 from metdetpy_amd import M3Detector, _lib
 from metdetpy_amd.synth import SkyStream
 
-H, W, n, B, uniq = 1080, 1920, 8, 1024, 256
+H, W, n, B, uniq = 1080, 1920, int(os.environ.get("MDH_PROBE_N", "8")), 1024, 256  # MDH_PROBE_N: window length
 mask = np.ones((H, W), np.uint8)
 frames = SkyStream(H, W, bench.WORKLOADS["C2"]["seed"]).take(uniq)
 det = M3Detector(1, n, mask, 10, bench.make_cfg(), None, max_batch=B)
