@@ -515,6 +515,15 @@ class Dist:
         if self.world > 1 or os.environ.get("MDH_BENCH_FORCE_DIST") == "1":
             from metdetpy_amd import dist
             self.g = dist.Group(self.rank, self.local, self.world)
+            if self.g.backend == "store" and self.g.rccl_note is not None and os.environ.get("MDH_DIST_BACKEND") != "store":
+                # Every rank has a GPU of its own and RCCL still could not be used: the run FAILS -- the
+                # store is the fall-back for ranks that share a device (the one-GPU dry runs), not a way for a broken RCCL path to
+                # look like a pass.  (every rank takes this branch: the outcomes were exchanged; MDH_DIST_BACKEND=store asks for the store)
+                if self.rank == 0:
+                    print(f"bench.py: {self.world} ranks with a GPU each, but RCCL is not usable ({self.g.rccl_note}); refusing to fall back "
+                          "to the rendezvous store (set MDH_DIST_BACKEND=store to run the collectives through it on purpose)", file=sys.stderr, flush=True)
+                self.g.close()
+                sys.exit(3)
             self.local = self.g.device
             if os.environ.get("MDH_BENCH_VERBOSE_RANKS") == "1":  # tools/run_8gpu.sh: who sits where
                 print(f"[rank {self.rank}] of {self.world}: {json.dumps(self.g.describe())}", file=sys.stderr, flush=True)

@@ -43,13 +43,13 @@ class Group:
         want = backend or os.environ.get("MDH_DIST_BACKEND") or "auto"
         if want not in ("auto", "rccl", "store"):
             raise ValueError("backend must be auto | rccl | store")
-        ndev = 0
-        if want != "store":
-            from . import _lib
-            try:
-                ndev = int(_lib.load().mdh_device_count())
-            except _lib.MetDetHipError:
-                ndev = 0
+        # (asked whatever the backend: with the store forced -- tools/run_8gpu.sh --dry-run -- the ranks still spread over the
+        # devices there are, round-robin, instead of piling onto device 0)
+        from . import _lib
+        try:
+            ndev = int(_lib.load().mdh_device_count())
+        except (_lib.MetDetHipError, OSError):
+            ndev = 0
         # every rank must take the same branch: rank 0 decides from what all ranks report (devices visible, local rank)
         reports = self.cp.all_gather_object((ndev, self.local))
         local_world = 1 + max(r[1] for r in reports)
@@ -170,7 +170,9 @@ class Group:
         return float(out.value)
 
     def all_gather_object(self, obj) -> list:
-        import pickle
+        if self.comm is None or self.world == 1:
+            return self.cp.all_gather_object(obj)  # (sealed and verified before unpickling: rendezvous.Group)
+        import pickle  # over RCCL the bytes travel between this job's own device buffers
         return [pickle.loads(b) for b in self.all_gather_bytes(pickle.dumps(obj, protocol=4))]
 
     def gather_object(self, obj, dst: int = 0):

@@ -158,8 +158,20 @@ class Communicator:
     def from_group(cls, group, device: int | None = None, timeout_s: float | None = None):
         """The id is made on rank 0 and broadcast through the control plane (`rendezvous.Group`, or anything with its
         rank / world / broadcast_bytes)."""
-        uid = group.broadcast_bytes(new_unique_id() if group.rank == 0 else None, 0)
-        return cls(group.rank, group.world, uid, device=device, timeout_s=timeout_s)
+        # The broadcast is UNCONDITIONAL: a rank 0 that cannot make the id (librccl missing, ncclGetUniqueId failing) still takes
+        # part and sends the reason instead -- raised before the collective, rank 0 alone would have stayed one collective behind
+        # the others, and the "RCCL is not usable: go on over the store" agreement that follows (dist.Group) would have met a
+        # time-out instead of an answer (ADVICE round 5).
+        blob = None
+        if group.rank == 0:
+            try:
+                blob = b"U" + new_unique_id()
+            except Exception as e:  # noqa: BLE001
+                blob = b"E" + f"{type(e).__name__}: {e}".encode("utf-8", "replace")
+        blob = group.broadcast_bytes(blob, 0)
+        if blob[:1] != b"U":
+            raise RcclError("rank 0 could not make the ncclUniqueId: " + blob[1:].decode("utf-8", "replace"))
+        return cls(group.rank, group.world, blob[1:], device=device, timeout_s=timeout_s)
 
     def all_reduce_sum_i64(self, ptr: int, count: int, stream: int):
         """In place, on `stream` (a hipStream_t as an integer)."""

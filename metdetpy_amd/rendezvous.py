@@ -12,13 +12,24 @@ and `Group` builds barrier / broadcast / all-gather / gather of small byte strin
 host-buffer fall-back of the tests only; the data path of a real multi-GPU run is RCCL on the library's streams (rccl.py).
 
 Where rank 0 listens.  MASTER_PORT itself belongs to the launcher (torch.distributed.run keeps its own store there), so rank 0
-binds an ephemeral port on MASTER_ADDR and publishes it in a file keyed by MASTER_ADDR / MASTER_PORT under the temporary
-directory (one node: BASELINE's configurations are "N GPUs of ONE node"); a client that reads a stale file of a crashed run
-fails the store's handshake (a nonce the file also carries) or the connect, and re-reads the file until rank 0 has rewritten it.
-MDH_RDV_PORT names the port explicitly instead (several nodes, or no shared temporary directory).
+binds an ephemeral port on MASTER_ADDR and publishes it in a file keyed by MASTER_ADDR / MASTER_PORT in a directory of this user's
+own under the temporary directory (one node: BASELINE's configurations are "N GPUs of ONE node"); a client that reads a stale file
+of a crashed run fails the store's handshake or the connect, and re-reads the file until rank 0 has rewritten it.
+MDH_RDV_PORT names the port explicitly instead (several nodes, or no shared temporary directory); the job's secret then comes
+from MDH_RDV_SECRET, which every rank must be given (there is no default: a store on a routable port without one is refused).
+
+Who may talk to the store (round 6).  The job has a 16-byte secret: random per job and carried by the port file (created
+exclusively, mode 0600, in a directory mode 0700 that must belong to this user), or derived from MDH_RDV_SECRET.  It never
+crosses the wire: the handshake is a mutual challenge / response (HMAC-SHA256 of the other side's random challenge), so a
+listener that is not this run's store, and a client that is not one of this run's ranks, both fail it.  The object collectives
+pickle (the ranks exchange NumPy records); every pickled value travels with an HMAC over (collective number, sender, payload)
+under the same secret and is verified BEFORE it is unpickled: bytes a stranger managed to put into the dictionary never reach
+`pickle.loads`.
 """
 from __future__ import annotations
 
+import hashlib
+import hmac
 import os
 import pickle
 import socket
@@ -59,11 +70,11 @@ def _recv_msg(sock):
 class _Server:
     """Rank 0's dictionary: one thread per client connection, GET parks on a condition until the key exists."""
 
-    def __init__(self, host: str, port: int, nonce: bytes):
+    def __init__(self, host: str, port: int, secret: bytes):
         self.data: dict[bytes, bytes] = {}
         self.reads: dict[bytes, int] = {}
         self.cv = threading.Condition()
-        self.nonce = nonce
+        self.secret = secret
         self.sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self.sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         self.sock.bind((host, port))
@@ -84,11 +95,20 @@ class _Server:
 
     def _serve(self, conn):
         try:
-            hello = _recv_exact(conn, len(_MAGIC) + len(self.nonce))
-            if hello != _MAGIC + self.nonce:
+            # mutual challenge / response: neither side ever sends the secret
+            conn.settimeout(10.0)
+            hello = _recv_exact(conn, len(_MAGIC) + 16)
+            if hello[:len(_MAGIC)] != _MAGIC:
+                conn.sendall(b"\0" * 48)
+                return
+            challenge = os.urandom(16)
+            conn.sendall(challenge + _mac(self.secret, b"S" + hello[len(_MAGIC):]))
+            answer = _recv_exact(conn, 32)
+            if not hmac.compare_digest(answer, _mac(self.secret, b"C" + challenge)):
                 conn.sendall(b"\0")
                 return
             conn.sendall(b"\1")
+            conn.settimeout(None)
             while True:
                 op, key, val = _recv_msg(conn)
                 if op == _OP_SET:  # value = [reads: u32][payload]; reads > 0: the key is dropped after that many GETs
@@ -139,8 +159,34 @@ class _Server:
             self.cv.notify_all()
 
 
+def _mac(secret: bytes, msg: bytes) -> bytes:
+    return hmac.new(secret, msg, hashlib.sha256).digest()
+
+
+def _port_dir() -> str:
+    """A directory only this user can enter (0700, owned by this user, not a symlink): where the port files live."""
+    d = os.path.join(tempfile.gettempdir(), f"mdh_rdv_{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RendezvousError(f"{d} is not a private directory of this user (mode {oct(st.st_mode & 0o777)}, owner {st.st_uid})")
+    return d
+
+
 def _port_file(addr: str, port: int) -> str:
-    return os.path.join(tempfile.gettempdir(), f"mdh_rdv_{addr.replace(':', '_')}_{port}.port")
+    return os.path.join(_port_dir(), f"{addr.replace(':', '_').replace('/', '_')}_{port}.port")
+
+
+def _fixed_port_secret() -> bytes:
+    text = os.environ.get("MDH_RDV_SECRET")
+    if not text:
+        raise RendezvousError("MDH_RDV_PORT is set (the store listens on a port any host that reaches MASTER_ADDR can connect to): "
+                              "MDH_RDV_SECRET must give every rank the job's secret")
+    return hashlib.sha256(b"mdh-rdv:" + text.encode()).digest()[:16]
 
 
 class Store:
@@ -151,15 +197,18 @@ class Store:
         self.server = None
         self.file = None
         fixed = os.environ.get("MDH_RDV_PORT")
+        self.addr = addr
         if self.rank == 0:
-            nonce = b"\0" * 16 if fixed else os.urandom(16)
+            nonce = _fixed_port_secret() if fixed else os.urandom(16)
             self.server = _Server(addr, int(fixed) if fixed else 0, nonce)
             if not fixed:
                 self.file = _port_file(addr, port)
-                tmp = f"{self.file}.{os.getpid()}"
-                with open(tmp, "wb") as f:
+                tmp = f"{self.file}.{os.getpid()}.{os.urandom(4).hex()}"
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)  # (never through a link somebody else left there)
+                with os.fdopen(fd, "wb") as f:
                     f.write(struct.pack("<I", self.server.port) + nonce)
                 os.replace(tmp, self.file)  # (atomic: a reader sees the old file or the new one)
+            self.secret, self.port = nonce, self.server.port
             self.sock = self._connect(addr, self.server.port, nonce)
         else:
             deadline = time.monotonic() + self.timeout_s
@@ -167,7 +216,7 @@ class Store:
             while self.sock is None:
                 try:
                     if fixed:
-                        p, nonce = int(fixed), b"\0" * 16
+                        p, nonce = int(fixed), _fixed_port_secret()
                     else:
                         with open(_port_file(addr, port), "rb") as f:
                             blob = f.read()
@@ -175,7 +224,10 @@ class Store:
                             raise OSError("short port file")
                         p, nonce = struct.unpack("<I", blob[:4])[0], blob[4:]
                     self.sock = self._connect(addr, p, nonce)
-                except (OSError, ConnectionError, RendezvousError):
+                    self.secret, self.port = nonce, p
+                except (OSError, ConnectionError, RendezvousError) as e:
+                    if fixed and isinstance(e, RendezvousError) and "MDH_RDV_SECRET" in str(e):
+                        raise
                     if time.monotonic() > deadline:
                         raise RendezvousError(f"rank {rank}: no store of rank 0 reachable through {addr}:{port} within {timeout_s} s") from None
                     time.sleep(0.05)
@@ -184,11 +236,17 @@ class Store:
     def _connect(addr, port, nonce):
         s = socket.create_connection((addr, port), timeout=5.0)
         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-        s.sendall(_MAGIC + nonce)
+        mine = os.urandom(16)
+        s.sendall(_MAGIC + mine)
+        reply = _recv_exact(s, 48)
+        if not hmac.compare_digest(reply[16:], _mac(nonce, b"S" + mine)):  # (a stale port file, or somebody else's listener)
+            s.close()
+            raise RendezvousError("the listener is not this run's store")
+        s.sendall(_mac(nonce, b"C" + reply[:16]))
         ok = _recv_exact(s, 1)
         if ok != b"\1":
             s.close()
-            raise RendezvousError("the listener is not this run's store")
+            raise RendezvousError("this run's store refused the connection")
         s.settimeout(None)
         return s
 
@@ -198,6 +256,18 @@ class Store:
             _send_msg(self.sock, op, key.encode(), val)
             _op, _k, out = _recv_msg(self.sock)
         except socket.timeout:
+            # The request is still parked on the server's side of this connection (a GET waits for its key) and its late reply
+            # would be read as the answer to the NEXT request: the connection is of no further use.  A fresh one keeps the paths
+            # that go on talking after a timeout working (dist.Group agrees on the store fall-back, Group.close() still meets
+            # its barrier).
+            try:
+                self.sock.close()
+            except OSError:
+                pass
+            try:
+                self.sock = self._connect(self.addr, self.port, self.secret)
+            except (OSError, ConnectionError, RendezvousError):
+                pass  # (rank 0 is gone: the next call fails on the closed socket)
             raise RendezvousError(f"rank {self.rank}: the store did not answer `{key}` within {self.timeout_s} s (a peer is missing)") from None
         return out
 
@@ -279,16 +349,30 @@ class Group:
                 self.store.set(f"c{s}/{self.rank}/to{r}", b, reads=1)
         return [blobs[r] if r == self.rank else self.store.get(f"c{s}/{r}/to{self.rank}") for r in range(self.world)]
 
-    # objects (pickle: the ranks are processes of one job started by one launcher)
+    # objects (pickle: the ranks are processes of one job started by one launcher, and they exchange NumPy records).  Every pickle
+    # is sealed -- HMAC-SHA256 over (collective number, sender, payload) under the job's secret -- and opened (verified) before it
+    # is unpickled: what did not come from a rank of this job never reaches pickle.loads.
+    def _seal(self, seq: int, sender: int, obj) -> bytes:
+        body = pickle.dumps(obj, protocol=4)
+        return _mac(self.store.secret, struct.pack("<QI", seq, sender) + body) + body
+
+    def _open(self, seq: int, sender: int, blob: bytes):
+        if len(blob) < 32 or not hmac.compare_digest(blob[:32], _mac(self.store.secret, struct.pack("<QI", seq, sender) + blob[32:])):
+            raise RendezvousError(f"rank {self.rank}: the value of rank {sender} in collective {seq} does not carry this job's seal")
+        return pickle.loads(blob[32:])
+
     def all_gather_object(self, obj) -> list:
-        return [pickle.loads(b) for b in self.all_gather_bytes(pickle.dumps(obj, protocol=4))]
+        s = self.seq + 1
+        return [self._open(s, r, b) for r, b in enumerate(self.all_gather_bytes(self._seal(s, self.rank, obj)))]
 
     def gather_object(self, obj, dst: int = 0):
-        got = self.gather_bytes(pickle.dumps(obj, protocol=4), dst)
-        return None if got is None else [pickle.loads(b) for b in got]
+        s = self.seq + 1
+        got = self.gather_bytes(self._seal(s, self.rank, obj), dst)
+        return None if got is None else [self._open(s, r, b) for r, b in enumerate(got)]
 
     def broadcast_object(self, obj, src: int = 0):
-        return pickle.loads(self.broadcast_bytes(pickle.dumps(obj, protocol=4) if self.rank == src else None, src))
+        s = self.seq + 1
+        return self._open(s, src, self.broadcast_bytes(self._seal(s, src, obj) if self.rank == src else None, src))
 
     def close(self):
         self.store.timeout_s = min(self.store.timeout_s, 15.0)

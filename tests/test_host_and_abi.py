@@ -255,6 +255,184 @@ def test_rendezvous_store_survives_a_stale_port_file(tmp_path, monkeypatch):
         tempfile.tempdir = None
 
 
+def _two_threads(port, body0, body1, timeout_s=20):
+    """Ranks 0 and 1 of a store-backed group as two threads of this process; returns {rank: result or exception}."""
+    import threading
+    from metdetpy_amd import rendezvous as rv
+    box = {}
+
+    def run(rank, body):
+        try:
+            g = rv.Group(rank, 2, "127.0.0.1", port, timeout_s=timeout_s)
+            try:
+                box[rank] = body(g)
+            finally:
+                g.close()
+        except BaseException as e:  # noqa: BLE001
+            box[rank] = e
+
+    th = [threading.Thread(target=run, args=(r, b)) for r, b in ((0, body0), (1, body1))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    return box
+
+
+def test_rccl_unique_id_failure_on_rank_0_reaches_every_rank(monkeypatch):
+    """rank 0 failing to make the ncclUniqueId (no usable librccl) must not leave it one collective behind the
+    others -- every rank gets the reason at once, and the agreement on the store fall-back that follows still works."""
+    from metdetpy_amd import rccl
+    from tests.mp import free_port
+
+    def boom():
+        raise OSError("librccl.so: cannot open shared object file")
+    monkeypatch.setattr(rccl, "new_unique_id", boom)
+
+    def body(g):
+        try:
+            rccl.Communicator.from_group(g, device=0, timeout_s=5)
+            err = None
+        except rccl.RcclError as e:
+            err = str(e)
+        return err, g.all_gather_object(err)  # what dist.Group does next: the outcomes, through the same control plane
+
+    import time
+    t0 = time.monotonic()
+    box = _two_threads(free_port(), body, body, timeout_s=10)
+    assert time.monotonic() - t0 < 8, "the ranks waited for a time-out instead of getting the answer"
+    for r in (0, 1):
+        assert not isinstance(box[r], BaseException), box[r]
+        err, outcomes = box[r]
+        assert err and "cannot open shared object file" in err
+        assert outcomes == [box[0][0], box[1][0]]
+
+
+def test_rendezvous_unpickles_only_what_carries_the_jobs_seal():
+    """The object collectives pickle; a value that was not sealed by a rank of this job (somebody else's SET on the store's port) is
+    refused before pickle.loads sees it.  A stranger without the secret does not even get through the handshake."""
+    import pickle
+    import socket
+    from metdetpy_amd import rendezvous as rv
+    from tests.mp import free_port
+    port = free_port()
+    hit = []
+
+    class Evil:
+        def __reduce__(self):
+            return (hit.append, ("unpickled",))
+
+    def body0(g):
+        # a forged value for the NEXT collective's key of rank 1, written through rank 0's own (authenticated) connection: the worst case
+        g.store.set(f"c{g.seq + 1}/1/v", pickle.dumps(Evil(), protocol=4), reads=1)
+        try:
+            g.all_gather_object("zero")
+        except rv.RendezvousError as e:
+            return str(e)
+        return "accepted"
+
+    def body1(g):
+        import time
+        time.sleep(1.0)  # (rank 0 reads the forged value first; this rank's own SET then overwrites a key nobody waits for)
+        try:
+            return g.all_gather_object("one")
+        except rv.RendezvousError as e:
+            return str(e)
+
+    box = _two_threads(port, body0, body1, timeout_s=5)
+    assert "does not carry this job's seal" in str(box[0]) and not hit
+    # the handshake: a client that does not know the secret is turned away, and never learns it from the exchange
+    srv = rv._Server("127.0.0.1", 0, b"s" * 16)
+    try:
+        with pytest.raises(rv.RendezvousError):
+            rv.Store._connect("127.0.0.1", srv.port, b"x" * 16)
+        s = socket.create_connection(("127.0.0.1", srv.port), timeout=5)
+        s.sendall(rv._MAGIC + b"c" * 16)
+        reply = rv._recv_exact(s, 48)
+        assert b"s" * 16 not in reply
+        s.sendall(b"\0" * 32)
+        assert rv._recv_exact(s, 1) == b"\0"
+        s.close()
+    finally:
+        srv.close()
+
+
+def test_rendezvous_fixed_port_needs_a_secret_and_port_files_are_private(tmp_path, monkeypatch):
+    import stat
+    import tempfile
+    from metdetpy_amd import rendezvous as rv
+    from tests.mp import free_port
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    tempfile.tempdir = None
+    try:
+        monkeypatch.setenv("MDH_RDV_PORT", str(free_port()))
+        monkeypatch.delenv("MDH_RDV_SECRET", raising=False)
+        with pytest.raises(rv.RendezvousError, match="MDH_RDV_SECRET"):
+            rv.Group(0, 1, "127.0.0.1", free_port(), timeout_s=2)
+        with pytest.raises(rv.RendezvousError, match="MDH_RDV_SECRET"):
+            rv.Group(1, 2, "127.0.0.1", free_port(), timeout_s=2)
+        monkeypatch.setenv("MDH_RDV_SECRET", "tonight's job")
+        g = rv.Group(0, 1, "127.0.0.1", free_port(), timeout_s=2)
+        assert g.all_gather_object({"a": 1}) == [{"a": 1}]
+        g.close()
+        monkeypatch.delenv("MDH_RDV_PORT")
+        port = free_port()
+        g = rv.Group(0, 1, "127.0.0.1", port, timeout_s=2)
+        f = rv._port_file("127.0.0.1", port)
+        assert stat.S_IMODE(os.stat(f).st_mode) == 0o600 and stat.S_IMODE(os.stat(os.path.dirname(f)).st_mode) == 0o700
+        g.close()
+        os.chmod(os.path.dirname(f), 0o755)  # a directory others could have prepared is refused
+        with pytest.raises(rv.RendezvousError, match="private directory"):
+            rv.Group(0, 1, "127.0.0.1", port, timeout_s=2)
+    finally:
+        tempfile.tempdir = None
+
+
+def test_rendezvous_connection_is_usable_after_a_timeout():
+    """a GET that timed out used to leave its request parked on the connection -- every later call on the same
+    Store blocked and failed.  The client reconnects: the recovery paths (agreeing on the store fall-back, the barrier of close())
+    keep working."""
+    from metdetpy_amd import rendezvous as rv
+    from tests.mp import free_port
+    g = rv.Group(0, 2, "127.0.0.1", free_port(), timeout_s=0.5)
+    with pytest.raises(rv.RendezvousError):
+        g.store.get("never/set")
+    g.store.set("k", b"v")
+    assert g.store.get("k") == b"v"
+    assert g.store.add("n", 5) == 5
+    g.store.close()
+
+
+NO_FALLBACK_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import bench
+from metdetpy_amd import _lib, rccl
+
+class FakeLib:  # a node with a GPU per rank ...
+    def mdh_device_count(self): return 2
+_lib.load = lambda: FakeLib()
+def no_rccl(*a, **k): raise rccl.RcclError("ncclCommInitRank: unhandled system error")   # ... on which RCCL does not come up
+rccl.Communicator.from_group = classmethod(lambda cls, *a, **k: no_rccl())
+try:
+    D = bench.Dist()
+    out = {"exit": None, "backend": D.backend}
+    D.close()
+except SystemExit as e:
+    out = {"exit": e.code}
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("forced_store", [False, True])
+def test_bench_refuses_the_store_fallback_when_every_rank_has_a_gpu(tmp_path, forced_store):
+    """N distinct devices visible and RCCL cannot form -> `bench.py --gpus N` fails (exit code 3) on every
+    rank instead of quietly running its collectives through the rendezvous store; MDH_DIST_BACKEND=store still asks for the store."""
+    from tests.mp import run_ranks
+    res = run_ranks(tmp_path, "no_fallback", NO_FALLBACK_WORKER, 2, env={"MDH_DIST_BACKEND": "store"} if forced_store else {"MDH_RCCL_TIMEOUT": "20"}, timeout=120)
+    assert res == ({"exit": None, "backend": "store"} if forced_store else {"exit": 3})
+
+
 def test_every_environment_switch_is_documented():
     """The library and the bench read MDH_* switches from the environment (A/B builds of one path, experiments, instrumentation);
     INTEGRATION.md's table is where a maintainer finds out what each does: none may be missing from it."""
