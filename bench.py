@@ -116,6 +116,9 @@ def parse():
                     "allows; 1 = one at a time: nothing overlaps, the kernel spans are the kernels' own durations)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic leg (roofline.traffic): two short re-executions of this "
                     "command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes) when rocprofv3 is on PATH")
+    ap.add_argument("--with-collector", action="store_true", help="the native MeteorCollector inside the timed region: every collected pass is "
+                    "handed to mdh_collector_update_batch on a second host thread (collector.py:420-528); `value` then counts frames whose "
+                    "results have gone through the collector, and the line carries a `collector` object (records, seconds of the thread's work)")
     ap.add_argument("--host-input", action="store_true", help="frames come from PINNED HOST memory every pass (PCIe-inclusive "
                     "rate; never the headline value, see DESIGN.md)")
     return ap.parse_args()
@@ -736,13 +739,49 @@ def run_streams(a, D, wl, mask):
     prob = np.zeros((B, _lib.MDH_MAX_LINES), np.float64)
     tally = [0, 0, 0]
     passes_seen = {}  # distinct per-pass tallies -> how many passes gave them (the timed region: ONE entry in steady state)
+    # --with-collector: the pass's results go on to the native collector on a second host thread (the detector's host thread keeps
+    # submitting and collecting); a ring of result buffers, so that the collector reads pass p while pass p + 1 is collected
+    col = col_thread = col_q = None
+    col_state = {"passes": 0, "busy_s": 0.0}
+    ring = [(info, raw, nms, prob)]
+    if a.with_collector:
+        import queue
+        import threading
+        from metdetpy_amd.collector import MeteorCollector
+        from metdetpy_amd.metstruct import CollectorCfg, MeteorCfg, RecheckSwitch, RuntimeParams
+        ccfg = CollectorCfg(MeteorCfg(15, 4, [0, 8], [2, 21], [0, 0.6], 0.5, 2048), RecheckSwitch(False), {})  # config/m3det_normal.json's collector block
+        rt = RuntimeParams(fps=25.0, exp_frame=1, eq_fps=25.0, eq_int_fps=25, exp_time=0.04, runtime_size=[W, H], raw_size=[W, H],
+                           positive_category_list=["METEOR", "RED_SPRITE"])
+        col = MeteorCollector(ccfg, rt)
+        ring += [(np.zeros_like(info), None, np.zeros_like(nms), np.zeros_like(prob)) for _ in range(3)]
+        col_q = queue.Queue(maxsize=len(ring) - 2)
+
+        def col_worker():
+            while True:
+                item = col_q.get()
+                if item is None:
+                    return
+                base, (i_, _r, n_, p_) = item
+                t_ = time.perf_counter()
+                col.update_batch(base, base, i_, n_, p_)
+                col_state["busy_s"] += time.perf_counter() - t_
+                col_state["passes"] += 1
+                col_q.task_done()
+        col_thread = threading.Thread(target=col_worker, name="bench-collector", daemon=True)
+        col_thread.start()
+    seen = {"passes": 0}
 
     def collect():
-        ctx.collect_into(info, raw, nms, prob)
-        one = (int(info["n_raw"].sum()), int(info["n_nms"].sum()), int(info["lit_count"].sum()))
+        bufs = ring[seen["passes"] % len(ring)]
+        ctx.collect_into(bufs[0], bufs[1], bufs[2], bufs[3])
+        info_ = bufs[0]
+        one = (int(info_["n_raw"].sum()), int(info_["n_nms"].sum()), int(info_["lit_count"].sum()))
         passes_seen[one] = passes_seen.get(one, 0) + 1
         for k_ in range(3):
             tally[k_] += one[k_]
+        if col is not None:
+            col_q.put((seen["passes"] * B, bufs))  # (blocks when the collector is two passes behind: its pace then is the pipeline's)
+        seen["passes"] += 1
 
     P = a.passes_per_step
 
@@ -757,9 +796,12 @@ def run_streams(a, D, wl, mask):
             ctx.submit(pool, B, not a.host_input)
         while ctx.in_flight:
             collect()
+        if col is not None:
+            col_q.join()  # a run ends when the collector has seen its last pass
 
     if a.warmup:
         run(a.warmup * P)
+    col_state.update(passes=0, busy_s=0.0)
     steps = a.steps if a.steps is not None else 20
     tally[:] = [0, 0, 0]
     passes_seen.clear()
@@ -790,6 +832,19 @@ def run_streams(a, D, wl, mask):
     dt_all, tot = D.max_time_and_sum(dt, [segs, kept, lit])
     res = dict(frames=steps * P * B * D.world, dt=dt_all, steps=steps, tot=tot, prof=prof, prof_alone=prof_alone, frames_sample=frames,
                B=B, P=P, uniq=uniq, dense=bool(DETECTOR == "m3" and ctx.dense_now), timed=timed)
+    if col is not None:
+        timed_passes, busy = steps * P, col_state["busy_s"]
+        col_q.put(None)
+        col_thread.join(30)
+        col.clear()
+        recs = col.met_exporter.meteor_list
+        res["extra"] = {"collector": {
+            "in_timed_region": True, "thread": "second host thread, mdh_collector_update_batch per collected pass (ring of 4 result buffers)",
+            "records_all_passes": len(recs), "collector_busy_s_all_passes": busy, "collector_passes": col_state["passes"],
+            "collector_alone_frames_per_s": (col_state["passes"] * B / busy) if busy else None,
+            "note": "value = frames per second with every pass's results consumed by the native collector before the region ends; "
+                    "collector_alone = what the collector thread's own busy time would allow; records identical to the oracle's: parity.records"}}
+        del timed_passes
     (ctx.host_free if a.host_input else ctx.device_free)(pool)
     det.close()
     return res
@@ -890,6 +945,15 @@ SECONDARY = [
     # (1000 frames per pass, 12 passes per step -- as many frames per step as the workload's default 500 x 24: 127 k -> 134 k frames/s on one box)
     ("C5_8k_high", ["--workload", "C5", "--unique", "50", "--batch", "1000", "--passes-per-step", "12", "--steps", "13", "--warmup", "2"]),
     ("C1s_960x540", ["--workload", "C1s", "--steps", "17", "--warmup", "2"]),
+    # the reference's own default window (config/m3det_normal.json: window_sec 1 -> n = int(window_sec * fps) = 25 / 30, Detector.py:200)
+    ("C2_n25_reference_default_window", ["--window", "25", "--unique", "100", "--steps", "8", "--warmup", "1"]),
+    ("C1s_960x540_n25", ["--workload", "C1s", "--window", "25", "--unique", "100", "--steps", "8", "--warmup", "1"]),
+    ("C1s_960x540_n30", ["--workload", "C1s", "--window", "30", "--unique", "100", "--steps", "8", "--warmup", "1"]),
+    # what a consumer with a latency budget sees: the headline workload in passes of 1000 and 250 frames
+    ("C2_pass_1000_frames", ["--batch", "1000", "--passes-per-step", "128", "--steps", "8", "--warmup", "1"]),
+    ("C2_pass_250_frames", ["--batch", "250", "--passes-per-step", "256", "--steps", "8", "--warmup", "1"]),
+    # the headline workload with the native collector inside the timed region, on a second host thread (item 7)
+    ("C2_with_collector", ["--with-collector", "--steps", "8", "--warmup", "1"]),
     # the unfriendly skies: 1080p, a 100-frame period (sparse: 400, dense: 96), parity + worst-frame replay time each
     ("C2_noisy_sky_m3det_low", ["--stream", "noisy", "--unique", "100", "--steps", "6", "--warmup", "1"]),
     ("C2_hot_pixels_1pct", ["--stream", "hot", "--unique", "100", "--steps", "6", "--warmup", "1"]),
@@ -928,7 +992,8 @@ def run_secondary(a):
             continue
         print(f"[secondary {name}] {line[-1]}", file=sys.stderr)
         rf = d.get("roofline") or {}
-        e = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+        e = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "window": d["config"].get("window"),
+             "frac_isolated": rf.get("frac_isolated"),
              "timed_s": d["ms_per_step"] * d["steps"] * 1e-3,
              "frames_per_step": d["config"]["frames_per_step"], "passes_per_step": d["config"].get("passes_per_step"),
              "frac": rf.get("frac"), "frac_at_pipeline_pace": rf.get("frac_at_pipeline_pace"),
@@ -938,6 +1003,9 @@ def run_secondary(a):
              "wall_s": round(time.perf_counter() - t0, 1), "command": "python bench.py " + " ".join(cmd[2:])}
         if "per_frame" in d:
             e["per_frame"] = {k: d["per_frame"][k] for k in ("frames", "update_stats", "us_per_frame", "frames_by_kind", "frames_per_s_by_kind")}
+        if "collector" in d:
+            e["collector"] = {k: d["collector"].get(k) for k in ("records_all_passes", "collector_alone_frames_per_s")}
+            e["records_identical"] = (d.get("parity") or {}).get("records_identical")
         out[name] = e
         time.sleep(2.0)  # (a child that held ~100 GB of HBM has just exited: the driver releases -- and wipes -- its memory in the background)
     return out
@@ -956,9 +1024,25 @@ def orchestrate(a):
     if p.returncode != 0 or not lines:
         sys.stdout.write(p.stdout)
         sys.exit(p.returncode or 1)
-    out = json.loads(lines[-1])
+    head = json.loads(lines[-1])
     time.sleep(2.0)
-    out["secondary"] = run_secondary(a)
+    sec = run_secondary(a)
+    # The driver keeps the LAST 16 KB of this process's output (round 5: its tail began in the middle of the line and the C3 / C5 /
+    # C1s legs were cut off).  So the line is ordered for its tail: the bulky objects first, then the headline's own figures, and
+    # last of all `secondary_summary` -- leg -> [frames/s, frac at the pipeline's pace, isolated frac, parity | timed-region tallies] in
+    # well under 2 KB.  The same summary is also printed as a line of its own in front of the JSON line.
+    def short(v):
+        return None if v is None else ("ok" if v == "identical" else str(v)[:24])
+    summary = {k: ([round(v["value"]), None if v.get("frac") is None else round(v["frac"], 3),
+                    None if v.get("frac_isolated") is None else round(v["frac_isolated"], 3), short(v.get("parity")), short(v.get("timed_region_tallies"))]
+                   if "error" not in v else ["error", v["error"][:60]]) for k, v in sec.items()}
+    bulky = ("cpu_baseline", "parity", "kernels_ms_per_pass", "kernels_ms_standalone", "detections")
+    out = {k: head[k] for k in bulky if k in head}
+    out["secondary"] = sec
+    out.update({k: v for k, v in head.items() if k not in bulky})
+    out["secondary_summary_columns"] = ["frames_per_s", "frac_at_pipeline_pace", "frac_isolated", "parity", "timed_region_tallies"]
+    out["secondary_summary"] = summary
+    print("[secondary_summary] " + json.dumps(summary), flush=True)
     print(json.dumps(out), flush=True)
 
 
@@ -1013,6 +1097,7 @@ def main():
         extra = r.pop("extra", {})
     else:
         r = run_streams(a, D, wl, mask)
+        extra = r.pop("extra", {})
     fps = r["frames"] / r["dt"]
     B = r["B"]
     P = r.get("P", 1)

@@ -112,7 +112,7 @@ def hough_inputs():
     return out
 
 
-COLOR_SHAPES = [(2, 2), (67, 131), (270, 480), (216, 384), (540, 960), (4, 4096), (432, 768)]
+COLOR_SHAPES = [(2, 2), (67, 131), (270, 480), (216, 384), (540, 960), (4, 4096), (432, 768), (1080, 1920)]
 RESIZES = {  # src (h, w) -> dsizes (w, h)
     (67, 131): [(131, 67), (65, 33), (40, 21), (262, 134), (100, 100)],
     (270, 480): [(240, 135), (120, 68), (96, 54), (480, 270), (333, 187)],
@@ -121,6 +121,7 @@ RESIZES = {  # src (h, w) -> dsizes (w, h)
     (2, 2): [(1, 1), (4, 4), (3, 5)],
     (4, 4096): [(1024, 1)],      # the contested triples through a 4:1 reduction as well
     (432, 768): [(192, 108)],    # 4:1 in both directions, the reduction of config 1 (3840x2160 -> resize 960)
+    (1080, 1920): [(960, 540)],  # 2:1 at full size: a 1080p source under the reference's default `resize: 960` (round 6)
 }
 
 
@@ -148,6 +149,15 @@ def color_inputs():
             assert len(tri) >= h * w, len(tri)
             out.append((f"bgr_{h}x{w}", np.ascontiguousarray(tri[:h * w].reshape(h, w, 3))))
             continue
+        if (h, w) == (1080, 1920):
+            # full size, but smooth (sinusoids + a ramp + 0.5 % salt): the four pinned arrays of this shape compress to a few hundred KB
+            yy, xx = np.mgrid[:h, :w].astype(np.float32)
+            img = np.stack([(np.sin(xx / 23.0) * np.cos(yy / 31.0) + 1) * 110 + 10, (xx + 2 * yy) % 251,
+                            (np.cos((xx - yy) / 17.0) + 1) * 90 + 40], axis=-1).astype(np.uint8)
+            salt = rng.random((h, w)) < 0.005
+            img[salt] = rng.integers(0, 256, (int(salt.sum()), 3), dtype=np.uint8)
+            out.append((f"bgr_{h}x{w}", img))
+            continue
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         if h >= 60:  # some smooth structure as well, so that the bilinear taps matter
             yy, xx = np.mgrid[:h, :w]
@@ -168,3 +178,6 @@ def classic_frames():
 
 
 M3_STREAM = dict(H=270, W=480, n=8, seed=20220413, frames=70, speed=10, streak_period=30, sensitivities=["normal", "high", "low"])
+# the reference's default window (config/m3det_normal.json: window_sec 1 at 25 frames per second -> n = 25: the window lengths above 16
+# have window kernels of their own since round 6); keys carry the prefix "n25_"
+M3_STREAM_LONG = dict(H=192, W=320, n=25, seed=20220430, frames=95, speed=6, streak_period=40, sensitivities=["normal"], prefix="n25_")

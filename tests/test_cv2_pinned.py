@@ -102,10 +102,11 @@ def oracle_classic(window, T):
     return orc.dst, lines
 
 
-def m3_series(z, tag, sens, step):
+def m3_series(z, tag, sens, step, S=None):
     """Drive `step(frame) -> (lines, cls_pred, bi_threshold, lines_num, dst_sum, dst or None)` over the seeded stream."""
     from metdetpy_amd.synth import SkyStream
-    S = cases.M3_STREAM
+    S = S or cases.M3_STREAM
+    tag = S.get("prefix", "") + tag
     stream = SkyStream(S["H"], S["W"], S["seed"], speed=S["speed"], streak_period=S["streak_period"])
     for t in range(S["frames"]):
         lines, pred, thr, nraw, dst_sum, dst = step(stream.next())
@@ -114,7 +115,7 @@ def m3_series(z, tag, sens, step):
         assert np.array_equal(np.asarray(pred, np.float64).reshape(len(z[f"{key}/lines"]), -1), z[f"{key}/cls_pred"]), (key, "cls_pred")
         sc = z[f"{key}/scalars"]
         assert thr == sc[0] and nraw == sc[1], (key, thr, nraw, sc)
-        if tag == "m3":
+        if tag.endswith("m3"):
             assert dst_sum == sc[2], (key, dst_sum, sc[2])
         if dst is not None and f"{key}/dst" in z:
             assert np.array_equal(np.packbits(dst > 0, axis=1), z[f"{key}/dst"]), (key, "dst")
@@ -176,6 +177,22 @@ def test_oracle_m3_detector_equals_reference(sens):
         return lines, pred, orc.bi_threshold, orc.lines_num, orc.dst_sum, orc.dst
 
     m3_series(z, "m3", sens, step)
+
+
+def test_oracle_m3_detector_long_window_equals_reference():
+    """n = 25: the reference's default window_sec 1 at 25 frames per second (Detector.py:200) -- round 6's window kernels."""
+    z = pinned("m3")
+    S = cases.M3_STREAM_LONG
+    if f"{S['prefix']}m3_normal/0/lines" not in z:
+        pytest.skip("PARITY UNPINNED: g9_cv2_m3.npz predates the long-window stream (re-run tools/pin_cv2.py)")
+    orc = mo.M3Oracle(S["n"], np.ones((S["H"], S["W"]), np.uint8), hough_fn=co.hough_lines_p, **oracle_kwargs(binary_cfg("normal")))
+
+    def step(f):
+        orc.update(f)
+        lines, pred = orc.detect()
+        return lines, pred, orc.bi_threshold, orc.lines_num, orc.dst_sum, orc.dst
+
+    m3_series(z, "m3", "normal", step, S)
 
 
 # ---- the script's file format, exercised without OpenCV ----------------------------------------------------------------------
@@ -286,6 +303,24 @@ def test_hip_m3_detector_equals_reference(sens):
         return lines, pred, det.bi_threshold, det.lines_num, det.dst_sum, det.dst
 
     m3_series(z, "m3", sens, step)
+    det.close()
+
+
+@pytest.mark.gpu
+def test_hip_m3_detector_long_window_equals_reference():
+    from metdetpy_amd import M3Detector
+    z = pinned("m3")
+    S = cases.M3_STREAM_LONG
+    if f"{S['prefix']}m3_normal/0/lines" not in z:
+        pytest.skip("PARITY UNPINNED: g9_cv2_m3.npz predates the long-window stream (re-run tools/pin_cv2.py)")
+    det = M3Detector(1, S["n"], np.ones((S["H"], S["W"]), np.uint8), 10, binary_cfg("normal"), None)
+
+    def step(f):
+        det.update(f)
+        lines, pred = det.detect()
+        return lines, pred, det.bi_threshold, det.lines_num, det.dst_sum, det.dst
+
+    m3_series(z, "m3", "normal", step, S)
     det.close()
 
 

@@ -150,6 +150,7 @@ def _bench_ranks(N, extra=()):
     return d
 
 
+@pytest.mark.slow  # (45 s; the two-rank launch below stays in the default selection)
 def test_config4_bench_eight_ranks_as_the_driver_launches_it():
     """The command the driver runs for the 8-GPU point of the scaling curve, on this box's ONE device: eight ranks, eight
     independent streams (seeds 20220413 + rank), barrier / max-over-ranks / final gather through the store."""

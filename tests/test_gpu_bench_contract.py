@@ -98,6 +98,7 @@ def test_bench_per_frame_protocol_entry():
     assert d["per_frame"]["update_stats"]["direct_frames"] == 0 and d["value"] > 500
 
 
+@pytest.mark.slow  # (4-6 minutes: every secondary leg once; the driver runs the same command itself at the end of the round)
 def test_bench_secondary_block_of_the_headline_run():
     """The plain headline command on one GPU also runs the other BASELINE workloads and the per-frame protocol (subprocesses of
     the same script, after the headline region) and reports them in ONE line: `secondary`."""
@@ -105,14 +106,19 @@ def test_bench_secondary_block_of_the_headline_run():
     assert d["config"]["passes_per_step"] == 64 and d["config"]["frames_per_step"] == 256000
     sec = d["secondary"]
     unfriendly = {"C2_noisy_sky_m3det_low", "C2_hot_pixels_1pct", "C2_cloud_edge_every_50", "C2_streak_share_5pct", "C2_streak_share_80pct"}
+    long_windows = {"C2_n25_reference_default_window", "C1s_960x540_n25", "C1s_960x540_n30"}
     assert set(sec) == {"C3_4k_n16_mask", "C5_8k_high", "C1s_960x540", "C5_8k_as_8_row_bands_one_gpu", "per_frame_pinned",
-                        "per_frame_recycled_ring", "per_frame_pageable"} | unfriendly
+                        "per_frame_recycled_ring", "per_frame_pageable", "C2_pass_1000_frames", "C2_pass_250_frames",
+                        "C2_with_collector"} | unfriendly | long_windows
+    assert d["secondary_summary"].keys() == sec.keys() and len(json.dumps(d["secondary_summary"])) < 2048
+    assert list(d)[-1] == "secondary_summary"  # the line ends with it: the driver keeps the last 16 KB of the output
+    assert sec["C2_with_collector"]["records_identical"] is True and sec["C2_with_collector"]["collector"]["records_all_passes"] > 0
     for name, e in sec.items():
         assert "error" not in e, (name, e)
         assert e["value"] > 0 and e["timed_s"] >= 0.05 and e["parity"] == "identical" and e["parity_frames"] >= 16, (name, e)
     for name in unfriendly:  # parity, fps and the slowest frame's Hough replay for every unfriendly sky
         assert sec[name]["timed_region_tallies"] == "identical" and sec[name]["hough_frame_cost"]["slowest_frame"]["replay_us"] > 0, (name, sec[name])
-    for name in ("C3_4k_n16_mask", "C5_8k_high", "C1s_960x540"):
+    for name in ("C3_4k_n16_mask", "C5_8k_high", "C1s_960x540") + tuple(sorted(long_windows)):
         assert 0.2 < sec[name]["frac_at_pipeline_pace"] < 1 and 0.2 < sec[name]["frac"] < 1 and sec[name]["timed_s"] >= 1.0, (name, sec[name])
         assert sec[name]["timed_region_tallies"] == "identical", (name, sec[name])  # no configuration is timed that was not compared
     assert sec["per_frame_recycled_ring"]["per_frame"]["update_stats"]["auto_registered"] == 8

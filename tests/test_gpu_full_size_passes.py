@@ -6,6 +6,11 @@ under mask-east, 500 frames of 7680x4320 at m3det_high in either output format o
 fresh detectors on <= 256 frames; these run the timed shapes themselves -- the same resident pool, the same submit / collect calls
 -- and compare EVERY frame of every pass with the C port of the oracle (oracle/metdet_oracle.c): threshold, lit count, the raw
 Hough segments in discovery order, the lineset_nms output.
+
+Selection (round 6): `pytest -m gpu` runs one full-size pass per shape -- 1080p twice on one detector, 4K, 8K in its production
+(dense) format, and the long windows n = 25 and 32 through bench.py's own timed-region check; `-m "gpu and slow"` adds the
+8K pass in the sparse format and the long windows n = 17 and 30 (tests/conftest.py leaves `slow` tests out unless the marker
+expression names them: the whole default selection must stay well inside the driver's 1200 s step).
 """
 import os
 
@@ -103,7 +108,7 @@ def test_4k_pass_of_1000_frames_window16_mask():
     assert compare(rows, out, K) > 500
 
 
-@pytest.mark.parametrize("dense", ["0", "1"])
+@pytest.mark.parametrize("dense", [pytest.param("0", marks=pytest.mark.slow), "1"])  # (8K's production format is the dense one)
 def test_8k_pass_of_500_frames_both_output_formats(dense, monkeypatch):
     """7680x4320 at m3det_high: the window kernel's two output formats (MDH_DENSE pins one) over a full 500-frame pass."""
     monkeypatch.setenv("MDH_DENSE", dense)
@@ -116,3 +121,24 @@ def test_8k_pass_of_500_frames_both_output_formats(dense, monkeypatch):
     except NameError:
         rows = _rows_8k = oracle_rows(frames, idx, 8, np.ones(frames.shape[1:], np.uint8), "high")
     assert compare(rows, out, K) > 100
+
+
+@pytest.mark.parametrize("n", [pytest.param(17, marks=pytest.mark.slow), 25, pytest.param(30, marks=pytest.mark.slow), 32])
+def test_long_window_full_size_passes_through_the_bench(n):
+    """Windows of 17 .. 32 frames (the reference's default window_sec 1 gives n = 25 / 30, Detector.py:200; 8-pixels-per-lane window
+    kernels since round 6): full-size 1080p passes of 4000 frames -- two time chunks per launch, the second pass continuing the
+    first's window -- through bench.py itself: the first periods frame by frame against the oracle AND the timed region's tallies
+    (raw segments, NMS segments, lit pixels of every pass) against the oracle's tallies carried through the periodic stream."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--window", str(n), "--unique", "100", "--steps", "2", "--warmup", "1",
+                        "--passes-per-step", "3", "--no-secondary", "--no-pmc", "--cpu-seconds", "0", "--parity-frames", "128", "--standalone-passes", "2"],
+                       capture_output=True, text=True, timeout=580, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["window"] == n and d["config"]["frames_per_pass"] == 4000
+    assert d["parity"]["verdict"] == "identical" and d["parity"]["frames_checked"] >= 128, d["parity"]
+    assert d["parity"]["timed_region"]["verdict"] == "identical", d["parity"]["timed_region"]
+    assert d["detections"]["raw_segments"] > 0 and 0.2 < d["roofline"]["frac_isolated"] < 1

@@ -100,13 +100,19 @@ def pin_m3(reference):
     from MetLib.metstruct import BinaryCfg
     from MetLib.utils import get_num_class
     from metdetpy_amd.synth import SkyStream
-    S = cases.M3_STREAM
     out = {}
+    for S in (cases.M3_STREAM, cases.M3_STREAM_LONG):
+        _pin_m3_stream(S, out, M3Detector, ClassicDetector, BinaryCfg, get_num_class, SkyStream)
+    return out
+
+
+def _pin_m3_stream(S, out, M3Detector, ClassicDetector, BinaryCfg, get_num_class, SkyStream):
+    prefix = S.get("prefix", "")
     mask = np.ones((S["H"], S["W"]), np.uint8)
     for sens in S["sensitivities"]:
         cfg = BinaryCfg.from_dict({"binary": {"adaptive_bi_thre": True, "init_value": 7, "sensitivity": sens, "area": 0.1, "interval": 2},
                                    "hough_line": {"threshold": 10, "min_len": 10, "max_gap": 10}, "dynamic": {"dy_mask": True, "window_sec": 5}})
-        for cls, tag in ((M3Detector, "m3"), (ClassicDetector, "classic")):
+        for cls, tag in ((M3Detector, prefix + "m3"),) + (((ClassicDetector, "classic"),) if not prefix else ()):
             det = cls(window_sec=1, fps=S["n"], mask=mask, num_cls=get_num_class(), cfg=cfg, logger=None)
             stream = SkyStream(S["H"], S["W"], S["seed"], speed=S["speed"], streak_period=S["streak_period"])
             for t in range(S["frames"]):
