@@ -143,7 +143,7 @@ struct mdh_ctx;
 struct HostPool {
     uintptr_t base, bytes, dev;
     int device;
-    int kind;        // 0: mdh_host_alloc, 1: mdh_host_register, 2: registered by the library (auto)
+    int kind;        // 0: mdh_host_alloc, 1: mdh_host_register, 2: registered by the library (auto), 3: mdh_host_register of memory the caller had pinned itself
     mdh_ctx* owner;  // the context that unregisters an auto entry when it is destroyed
 };
 static std::mutex g_pool_mutex;
@@ -2005,10 +2005,11 @@ static const uint8_t* lean_direct_source(mdh_ctx* c, const Slot& sl, const uint8
             if (hp.device == c->device && (uintptr_t)frame >= hp.base && (uintptr_t)frame + c->HW <= hp.base + hp.bytes)
                 return usable(hp.dev + ((uintptr_t)frame - hp.base));
     }
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, frame) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
-        return usable((uintptr_t)a.devicePointer);  // pinned by the caller (hipHostMalloc / hipHostRegister of its own)
-    (void)hipGetLastError();  // pageable memory: not an error, just not reachable from a kernel -- yet
+    // (Up to round 5 the runtime was asked as well -- hipPointerGetAttributes: memory the caller pinned with hipHostMalloc /
+    // hipHostRegister of its own was read in place.  The runtime gives the same answer for a range that was registered once and
+    // freed without being unregistered, and a frame read through such a stale mapping is a GPU memory fault that aborts the process
+    // (tools/stress_pre_run.py --mode stale): only ranges this library knows -- mdh_host_alloc, mdh_host_register,
+    // its own auto-registrations -- are read in place now; a loader with pinned memory of its own registers it with mdh_host_register.)
     // A caller that hands over the same address again and again recycles a fixed set of buffers: the third time round the
     // buffer is registered (pinned and mapped, ~0.2 ms once) and from then on read in place like a pool of mdh_host_alloc.
     if (!c->auto_register_on || c->auto_registered >= AUTO_REG_MAX_BUFFERS) return nullptr;
@@ -2800,16 +2801,29 @@ extern "C" int mdh_host_register(mdh_ctx* c, void* p, uint64_t bytes) {
                 return MDH_E_STATE;
             }
     }
-    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterMapped));
+    // memory the caller pinned itself (hipHostMalloc / hipHostRegister of its own) is announced the same way: it cannot be registered
+    // a second time, and stays the caller's to release (round 6: the library no longer takes the runtime's word for what is pinned)
+    int kind = 1;
+    const hipError_t reg = hipHostRegister(p, bytes, hipHostRegisterMapped);
+    if (reg != hipSuccess) {
+        (void)hipGetLastError();
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            set_err(std::string("mdh_host_register: hipHostRegister failed: ") + hipGetErrorString(reg));
+            return MDH_E_HIP;
+        }
+        kind = 3;
+    }
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) {
         (void)hipGetLastError();
-        hipHostUnregister(p);
+        if (kind == 1) hipHostUnregister(p);
         set_err("mdh_host_register: the registered range has no device-visible address");
         return MDH_E_HIP;
     }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    g_pools.push_back({(uintptr_t)p, (uintptr_t)bytes, (uintptr_t)dp, c->device, 1, c});
+    g_pools.push_back({(uintptr_t)p, (uintptr_t)bytes, (uintptr_t)dp, c->device, kind, c});
     return MDH_OK;
 }
 extern "C" int mdh_host_unregister(mdh_ctx* c, void* p) {
@@ -2817,19 +2831,20 @@ extern "C" int mdh_host_unregister(mdh_ctx* c, void* p) {
     HIPCHK(hipSetDevice(c->device));
     mail_cancel(c);
     HIPCHK(hipDeviceSynchronize());
-    bool found = false;
+    bool found = false, ours = true;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         for (size_t k = 0; k < g_pools.size(); ++k)
             if (g_pools[k].base == (uintptr_t)p && g_pools[k].kind != 0) {
                 if (g_pools[k].kind == 2 && g_pools[k].owner) g_pools[k].owner->auto_registered -= 1;
+                ours = g_pools[k].kind != 3;
                 g_pools.erase(g_pools.begin() + k);
                 found = true;
                 break;
             }
     }
     if (!found) { set_err("mdh_host_unregister: not a range registered through this library"); return MDH_E_ARG; }
-    HIPCHK(hipHostUnregister(p));
+    if (ours) HIPCHK(hipHostUnregister(p));
     return MDH_OK;
 }
 extern "C" int mdh_set_auto_register(mdh_ctx* c, int on) {
@@ -2985,9 +3000,18 @@ extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int 
             p->src_cap = need;
         }
         static const bool stage = !(getenv("MDH_PRE_STAGE") && atoi(getenv("MDH_PRE_STAGE")) == 0);
-        hipPointerAttribute_t at;
-        const bool pinned = hipPointerGetAttributes(&at, bgr) == hipSuccess && at.type == hipMemoryTypeHost;  // (the caller's own pinned memory: as it is)
-        if (!pinned) (void)hipGetLastError();
+        // Pinned memory is copied as it is -- but only memory THIS LIBRARY pinned (mdh_host_alloc) or registered at the caller's explicit
+        // request (mdh_host_register) counts.  Up to round 5 the runtime was asked (hipPointerGetAttributes), and the runtime also
+        // answers "host memory" for a range somebody registered once and freed without unregistering: a fresh array the allocator
+        // places on such a range then took the direct copy through the stale mapping -- "Memory access fault by GPU", the process
+        // aborted inside this call, staging or not (tools/stress_pre_run.py --mode stale reproduces it on round 5's library:
+        // gpurun_out/r06_09).  Everything else goes through the staging buffers, where only the CPU reads it.
+        bool pinned = false;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            for (const HostPool& hp : g_pools)
+                if (hp.kind != 2 && (uintptr_t)bgr >= hp.base && (uintptr_t)bgr + need <= hp.base + hp.bytes) { pinned = true; break; }
+        }
         if (!stage || pinned) {
             HIPCHK(hipMemcpyAsync(p->d_src, bgr, need, hipMemcpyHostToDevice, p->stream));
         } else {
