@@ -654,17 +654,18 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=Fal
         tc = -(-tc // n) * n  # (round 6: every time chunk but the last is a whole number of window periods, launch_wide)
     nchunks = -(-B // tc)
     compulsory = frame * (B + nchunks * (n - 1))
-    if dense:
+    if dense and DETECTOR != "classic":
         compulsory += words * 8 * B  # the dense output format writes every word of the thresholded difference (1 bit per pixel)
-    if DETECTOR == "classic":
-        compulsory += 2 * words * 8 * B  # k_classic_diff_tb stores TWO plain bit planes per frame (|f1 - f0| > T and |f3 - f2| > T), every word
+    if DETECTOR == "classic" and dense:
+        compulsory += 2 * words * 8 * B  # dense format: k_classic_diff_tb stores TWO plain bit planes per frame (|f1 - f0| > T and |f3 - f2| > T), every word
     avg_ms = ms / launches
     frac_of = lambda t_ms: compulsory / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out.update({
         "bytes_per_launch": compulsory, "frames_per_launch": B,
         "bytes_model": f"H*W*(frames + chunks*(n-1)) = {frame}*({B}+{nchunks}*{n - 1}): each frame byte once per launch plus the "
                        "window history per time chunk"
-                       + (f"; + 2*{words}*8*{B} bytes written: the difference kernel stores two plain bit planes per frame" if DETECTOR == "classic"
+                       + (f"; + 2*{words}*8*{B} bytes written: the difference kernel stores two plain bit planes per frame (dense format)" if DETECTOR == "classic" and dense
+                          else "; sparse format: only the words with set bits are stored (tagged), not counted" if DETECTOR == "classic"
                           else f"; + {words}*8*{B} bytes written: the run was in the DENSE output format (every word of the bit image stored)"
                           if dense else "; stores (sparse tagged words, ~0.6 % of the reads: measured) not counted"),
         "launch_ms_in_pipeline": avg_ms, "launches_in_pipeline": launches,
@@ -831,7 +832,7 @@ def run_streams(a, D, wl, mask):
         ctx.profile_enable(False)
     dt_all, tot = D.max_time_and_sum(dt, [segs, kept, lit])
     res = dict(frames=steps * P * B * D.world, dt=dt_all, steps=steps, tot=tot, prof=prof, prof_alone=prof_alone, frames_sample=frames,
-               B=B, P=P, uniq=uniq, dense=bool(DETECTOR == "m3" and ctx.dense_now), timed=timed)
+               B=B, P=P, uniq=uniq, dense=bool(ctx.dense_now), timed=timed)
     if col is not None:
         timed_passes, busy = steps * P, col_state["busy_s"]
         col_q.put(None)

@@ -84,6 +84,9 @@ struct Slot {
     u64* d_bplain = nullptr;         // [K][H][WW] the same image as plain words (dense passes; allocated when the first one is queued)
     bool dense = false;              // the pass in the slot runs in the dense format
     u64* d_planes = nullptr;         // Classic: [K][2][H][WW]
+    ActWord* d_cplanes = nullptr;    // Classic, sparse format (round 6): [K][2][H][WW] tagged words, only those with set bits ever written
+    bool classic_dense_last = false; // the slot's last Classic pass ran the dense kernels (they write every word of dst: a sparse pass clears it first)
+    bool classic_sparse = false;     // format of the pass being queued
     unsigned* d_worklist = nullptr;  // [K][bands][WW] morphology blocks that can produce output
     hipEvent_t ev_k1 = nullptr;      // window kernel done (main stream) -> the post stream may start
     hipEvent_t ev_close = nullptr;   // binaries of this pass are in the ring (the next pass's dynamic mask reads them)
@@ -165,6 +168,15 @@ struct mdh_ctx {
     hipEvent_t ev_base = nullptr;  // MDH_HOST_LOG: origin of the GPU-side span times
     unsigned tag_lds = 0;  // MDH_TAG_PASS=1: dynamic LDS bytes that tag a pass's kernels in a rocprofv3 trace (1024 * (1 + pass % 3))
     int nhset = 1;  // (one set since the three-wave PPHT: the stage is short, and every extra stream costs the command processor)
+    // ONE STREAM PER PASS (round 6; contexts made for short passes: max_batch x frame <= MDH_ONE_STREAM_MAX_MB, default 2500 MB = 1200 frames of
+    // 1080p): a pass's window kernel, morphology, dynamic mask and Hough stage all go on ONE stream -- one of NCHAIN, pass after pass --
+    // with a Hough buffer set per chain stream.  The by-stage streams above hand a pass from stream to stream four times, and every
+    // hand-over (event record -> the other queue's barrier packet) costs 40-50 us of nothing: invisible behind a 1.5 ms window
+    // kernel, but a 250-frame pass (window kernel 0.1 ms) lasted 0.6 ms from its first launch to its results, one such pass
+    // completing every 0.23 ms (rocprofv3 kernel trace, gpurun_out/r06_12).  On one stream the stages follow each other at kernel-boundary
+    // cost, and NCHAIN passes run side by side.
+    bool one_stream = false;
+    hipStream_t pass_stream[NHSET] = {nullptr, nullptr, nullptr, nullptr};
     int nmain = 2;  // main streams in use (MDH_MAIN_STREAMS): with 2, the window kernel of pass p+1 ramps up while that of pass p drains
     int64_t pass_seq = 0;
     hipStream_t cstream = nullptr;                  // strided copy of the segments at collect time
@@ -274,6 +286,11 @@ struct mdh_ctx {
     // of words with set bits the last collected pass reported (both formats report it); identical results either way.
     int dense_cfg = -1;        // MDH_DENSE: 1 = always dense, 0 = never, unset = automatic
     bool dense_now = false;
+    // ClassicDetector's output format (round 6): sparse (tagged difference planes, block lists) unless MDH_CLASSIC_SPARSE=0; a pass
+    // that lists more than a quarter of its blocks (a lowered threshold lets the noise through) sends the next 32 passes to the dense kernels
+    bool classic_sparse_on = true;
+    bool classic_fast4 = true;  // MDH_CLASSIC_FAST4=0: the general time-blocked kernel with sparse stores (A/B and parity)
+    int classic_dense_passes = 0;
     double dense_leave = 0.015;  // back to the sparse format below this share of words with set bits (MDH_DENSE_LEAVE)
     int64_t dense_passes = 0;  // passes queued in the dense format (mdh_dense_passes)
     // hand-over between run_pixels and the window kernel's launcher: dense output wanted (and where), and whether the kernel
@@ -382,7 +399,11 @@ extern "C" int mdh_in_flight(const mdh_ctx* c) { return c ? c->in_flight : -1; }
 extern "C" int mdh_max_in_flight(const mdh_ctx* c) { return c ? c->nslot : -1; }
 extern "C" int64_t mdh_dense_passes(const mdh_ctx* c) { return c ? c->dense_passes : -1; }
 extern "C" double mdh_last_density(const mdh_ctx* c) { return c ? c->last_density : -1; }
-extern "C" int mdh_dense_now(const mdh_ctx* c) { return c ? (c->dense_now ? 1 : 0) : -1; }
+extern "C" int mdh_dense_now(const mdh_ctx* c) {
+    if (!c) return -1;
+    if (c->cfg.detector != MDH_DET_M3) return (!c->classic_sparse_on || c->classic_dense_passes > 0) ? 1 : 0;  // ClassicDetector: its own two formats
+    return c->dense_now ? 1 : 0;
+}
 
 // Dense passes: where do the morphology's candidate blocks come from (MDH_DENSE_CAND)?
 //   1 (default)  the window kernel flags them itself, with the neighbours a pair at a block's edge can reach: the selection lists
@@ -457,7 +478,7 @@ static void free_all(mdh_ctx* c) {
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->h_inject) hipHostFree(c->h_inject);
     for (Slot& s : c->slot) {
-        void* sdev[] = {s.d_bbits, s.d_bplain, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr, s.d_wrec};
+        void* sdev[] = {s.d_bbits, s.d_bplain, s.d_planes, s.d_worklist, s.d_res, s.d_bandflag, s.d_nzlist, s.d_nzcount, s.d_dst, s.d_rowcount, s.d_lines, s.d_hdr, s.d_sums, s.d_jobres, s.d_thr, s.d_wrec, s.d_cplanes};
         for (void* p : sdev)
             if (p) hipFree(p);
         void* shost[] = {s.h_hdr, s.h_res};
@@ -491,6 +512,8 @@ static void free_all(mdh_ctx* c) {
     hipStream_t st[] = {c->mstream[0], c->mstream[1], c->nstream, c->cstream, c->pstream[0], c->pstream[1]};
     for (hipStream_t q : st)
         if (q && !c->streams_borrowed) hipStreamDestroy(q);
+    for (hipStream_t q : c->pass_stream)
+        if (q) hipStreamDestroy(q);
     delete c;
 }
 
@@ -603,6 +626,8 @@ static int create_impl(mdh_ctx* c) {
     HIPCHK(make_stream(&c->nstream, "MDH_PRIO_NOISE"));
     HIPCHK(make_stream(&c->pstream[0], "MDH_PRIO_HOUGH"));
     HIPCHK(make_stream(&c->pstream[1], "MDH_PRIO_HOUGH"));
+    if (c->one_stream)
+        for (hipStream_t& q : c->pass_stream) HIPCHK(make_stream(&q, "MDH_PRIO_MAIN"));
     HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     // MDH_HOUGH_CUS = m (experiment switch, default 0 = everywhere): the Hough streams alone are confined to m CUs of every XCD,
@@ -699,6 +724,10 @@ static int create_impl(mdh_ctx* c) {
                 TRY(dev_alloc(s.d_worklist, K * nb * c->WW, false));
             } else {
                 TRY(dev_alloc(s.d_planes, 2 * K * words));
+                if (c->classic_sparse_on) {
+                    TRY(dev_alloc(s.d_cplanes, 2 * K * words));
+                    TRY(dev_alloc(s.d_worklist, K * nb * c->WW, false));
+                }
             }
             // [K][nb * WW] block bit counts | [K][ceil(nb * WW / 32)] bitmap of the blocks with a non-zero count (note_block)
             TRY(dev_alloc(s.d_bandflag, K * nb * c->WW + K * ((nb * c->WW + 31) / 32)));
@@ -863,6 +892,11 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     // pixel stages and a second set lets two passes' Hough stages overlap (+15 %).
     c->nhset = (size_t)H * W > (size_t)12 << 20 ? 2 : 1;
     if (const char* v = getenv("MDH_HOUGH_SETS")) c->nhset = std::max(1, std::min(NHSET, atoi(v)));
+    {   // one stream per pass: see mdh_ctx::one_stream
+        const double max_mb = getenv("MDH_ONE_STREAM_MAX_MB") ? atof(getenv("MDH_ONE_STREAM_MAX_MB")) : 0.0;  // (off by default: measured 0.92 M against 1.02 M frames/s at 250-frame passes, +2 % at 1000: gpurun_out/r06_13, r06_16)
+        c->one_stream = role == MDH_ROLE_FULL && cfg->detector == MDH_DET_M3 && (double)c->Kmax * H * W <= max_mb * 1e6 && c->Kmax > 8;
+        if (c->one_stream) c->nhset = NHSET;
+    }
     if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
     // (frames of up to a megapixel only: at 960x540 the Hough stage is the largest item next to the window kernel and four
@@ -872,6 +906,8 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
     if (c->lds_tiny >= c->lds_small) c->lds_tiny = 0;
     if (role != MDH_ROLE_FULL) c->nmain = 1;  // (see post_stream)
     if (const char* v = getenv("MDH_MAIN_STREAMS")) c->nmain = std::max(1, std::min(2, atoi(v)));
+    if (const char* v = getenv("MDH_CLASSIC_SPARSE")) c->classic_sparse_on = atoi(v) != 0;
+    if (const char* v = getenv("MDH_CLASSIC_FAST4")) c->classic_fast4 = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_DIRECT")) c->lean_direct_on = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_POLL")) c->lean_poll = atoi(v) != 0;
     if (const char* v = getenv("MDH_LEAN_DUE")) c->lean_due_on = atoi(v) != 0;
@@ -1301,10 +1337,20 @@ static int noise_prepare(mdh_ctx* c, Slot& sl, int K, int* nj_out) {
     // collected).
     const size_t nb = (size_t)(c->H + MORPH_RB - 1) / MORPH_RB;
     const bool m3 = c->cfg.detector == MDH_DET_M3;
+    if (!m3 && c->role == MDH_ROLE_FULL) {
+        // ClassicDetector: the format of this pass (see mdh_ctx::classic_sparse_on); a slot whose last pass ran the dense kernels has
+        // every word of its dst written: cleared in full before its first sparse pass (the sparse format only ever clears what it listed)
+        static const bool classic_tb = !(getenv("MDH_CLASSIC_TB") && atoi(getenv("MDH_CLASSIC_TB")) == 0);
+        sl.classic_sparse = c->classic_sparse_on && sl.d_cplanes != nullptr && classic_tb && c->W % 64 == 0 && !c->force_bytes && !c->force_generic &&
+                            (c->n == 3 || c->n == 4) && c->classic_dense_passes <= 0;
+        if (c->classic_dense_passes > 0) c->classic_dense_passes -= 1;
+        if (sl.classic_sparse && sl.classic_dense_last) HIPCHK(hipMemsetAsync(sl.d_dst, 0, sizeof(u64) * (size_t)c->Kmax * c->words, c->nstream));
+    }
     hipLaunchKernelGGL(k_pass_prepare, dim3(1024), dim3(256), 0, c->nstream, (unsigned*)sl.d_rowcount,
                        (unsigned)((size_t)c->Kmax * c->H + (6 + WORKCNT_STRIDE) * (size_t)c->Kmax + 1), sl.d_bandflag,
                        (unsigned)(nb * c->WW), (unsigned)c->Kmax,  // (only what the slot's previous pass touched)
-                       (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist, (m3 && sl.used) ? sl.d_nzcount : nullptr);
+                       (unsigned*)c->d_sums, (unsigned)(4 * nj), sl.d_dst, sl.d_nzlist,
+                       ((m3 || (sl.d_cplanes != nullptr && !sl.classic_dense_last)) && sl.used) ? sl.d_nzcount : nullptr);
     if (nj) {
         bool aligned4 = (c->W % 4) == 0;
         for (int e = 0; e < c->n - 1 + K && aligned4; ++e) aligned4 = ((uintptr_t)c->h_ptrtab[e] & 3) == 0;
@@ -1353,7 +1399,8 @@ static int noise_finish(mdh_ctx* c, Slot& sl, int K, int nj, double roi_px) {
     hipLaunchKernelGGL(k_noise_finalize, dim3(1), dim3(NF_THREADS), c->tag_lds, c->nstream, c->d_jobs, nj, c->d_sums, c->d_state, c->d_jobres,
                        sl.d_fscal, c->d_thr, K, roi_px, c->cfg.adaptive_bi_thre, c->coef_a, c->coef_b, sl.d_nzcount,
                        (c->seek_at >= 0 && c->cfg.detector == MDH_DET_M3) ? (int)std::max<int64_t>(0, std::min<int64_t>(K, c->seek_at + c->n - 1 - sl.t_base)) : 0,
-                       c->cfg.detector == MDH_DET_M3 ? sl.d_wrec : (WinRec*)nullptr, c->n, (long long)sl.t_base);
+                       // (ClassicDetector's fast kernel reads its thresholds from the same records: len = 1, so the low half is T itself)
+                       sl.d_wrec, c->cfg.detector == MDH_DET_M3 ? c->n : 1, (long long)sl.t_base);
     span_end(c, c->nstream);
     HIPCHK(hipGetLastError());
     EV_REC(c, sl.ev_noise, c->nstream);
@@ -1400,7 +1447,7 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     // downstream of it -- morphology, dynamic mask, Hough, result packing -- is short or latency-bound and runs on the
     // pass's post streams, overlapping the window kernel of the following pass(es).
     // (the post streams are NOT the Hough streams: morphology of pass p must not queue behind the Hough stage of pass p-2)
-    hipStream_t post = c->lean ? c->nstream : post_stream(c, c->pass_seq);
+    hipStream_t post = c->lean ? c->nstream : (c->one_stream ? c->stream : post_stream(c, c->pass_seq));
     if (!c->lean_direct) EV_WAIT(c, c->stream, sl.ev_noise);  // thresholds, pointer table, history copies, cleared counters
     if (c->cfg.detector == MDH_DET_M3) {
         span_begin(c, KK_STACK_THR, c->stream);
@@ -1428,17 +1475,31 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         static const bool classic_tb = !(getenv("MDH_CLASSIC_TB") && atoi(getenv("MDH_CLASSIC_TB")) == 0);
         bool wide = classic_tb && c->W % 64 == 0 && !c->force_bytes && !c->force_generic && (g.n == 3 || g.n == 4) && K >= 1;
         for (int e = 0; e < c->n - 1 + K && wide; ++e) wide = ((uintptr_t)c->h_ptrtab[e] & 15) == 0;
+        if (sl.classic_sparse && !wide) sl.classic_sparse = false;  // (a misaligned frame in this very pass: the dense kernels, which write every word of dst)
+        sl.classic_dense_last = !sl.classic_sparse;
         if (wide) {
             const int waves = (words + 15) / 16;
             int nchunks = std::max(1, std::min((8192 + waves - 1) / waves, K / 8));
             const int Tc = (K + nchunks - 1) / nchunks;
             nchunks = (K + Tc - 1) / Tc;
+            if (sl.classic_sparse) {
+                if (g.n == 4 && c->classic_fast4) {
+                    const int Tc4 = (Tc + 3) / 4 * 4;  // a time chunk is a whole number of four-frame bursts
+                    hipLaunchKernelGGL(k_classic_diff4_sparse, dim3((waves + 3) / 4, (K + Tc4 - 1) / Tc4), dim3(256), 0, c->stream, c->d_ptrtab,
+                                       (const WinRec*)sl.d_wrec, sl.d_cplanes, sl.d_bandflag, g, Tc4);
+                } else if (g.n == 4)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classic_diff_tb<4, true>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream, c->d_ptrtab,
+                                       c->d_thr, sl.d_planes, g, Tc, sl.d_cplanes, sl.d_bandflag);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classic_diff_tb<3, true>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream, c->d_ptrtab,
+                                       c->d_thr, sl.d_planes, g, Tc, sl.d_cplanes, sl.d_bandflag);
+            } else
             if (g.n == 4)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classic_diff_tb<4>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream, c->d_ptrtab,
-                                   c->d_thr, sl.d_planes, g, Tc);
+                                   c->d_thr, sl.d_planes, g, Tc, (ActWord*)nullptr, (unsigned*)nullptr);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classic_diff_tb<3>), dim3((waves + 3) / 4, nchunks), dim3(256), 0, c->stream, c->d_ptrtab,
-                                   c->d_thr, sl.d_planes, g, Tc);
+                                   c->d_thr, sl.d_planes, g, Tc, (ActWord*)nullptr, (unsigned*)nullptr);
         } else {
             hipLaunchKernelGGL(k_classic_diff, dim3((words + 3) / 4, K), dim3(256), 0, c->stream, c->d_ptrtab, c->d_thr, sl.d_planes, g);
         }
@@ -1529,6 +1590,15 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
     } else {
         static const bool classic_rb = !(getenv("MDH_CLASSIC_TB") && atoi(getenv("MDH_CLASSIC_TB")) == 0);
         span_begin(c, KK_MORPH, post);
+        if (sl.classic_sparse) {
+            const size_t bm_dwords = (nb * c->WW + 31) / 32;
+            const int wpf = bm_dwords > 256 ? 4 : (bm_dwords > 64 ? 2 : 1);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_morph_select_touched<false>), dim3((unsigned)((K + 4 / wpf - 1) / (4 / wpf))), dim3(256), 0, post,
+                               sl.d_bandflag, sl.d_worklist, sl.d_workcnt, g, wpf, 1);
+            hipLaunchKernelGGL(k_classic_close_t, dim3((unsigned)std::min(K * wpf, 16384)), dim3(64), 0, post, (const ActWord*)sl.d_cplanes,
+                               (const unsigned*)sl.d_worklist, (const unsigned*)sl.d_workcnt, sl.d_dst, sl.d_rowcount, sl.d_litcount, sl.d_bbox,
+                               sl.d_nzlist, sl.d_nzcount, g, wpf, (unsigned long long*)(sl.d_nzcount + 2));
+        } else
         if (classic_rb)
             hipLaunchKernelGGL(k_classic_stencil_rb, dim3((unsigned)((nb * c->WW + 255) / 256), K), dim3(256), 0, post, sl.d_planes, sl.d_dst,
                                sl.d_rowcount, sl.d_litcount, sl.d_bbox, g);
@@ -1545,7 +1615,8 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
 // set run_pixels (or mdh_hough_planes) queued the slot's planes and counters on; starts after sl.ev_pix.
 static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     HoughSet& hs = c->hset[c->pass_seq % c->nhset];
-    hipStream_t hstream[2] = {c->lean ? c->nstream : hs.stream[0], c->lean ? c->nstream : hs.stream[1]};
+    // (one stream per pass: the pass's own stream; the set index is the chain stream's index -- both pass_seq mod NHSET)
+    hipStream_t hstream[2] = {c->lean ? c->nstream : (c->one_stream ? c->stream : hs.stream[0]), c->lean ? c->nstream : (c->one_stream ? c->stream : hs.stream[1])};
     HoughParams P{};
     P.H = c->H; P.W = c->W; P.WW = c->WW; P.numrho = c->numrho; P.half = (c->numrho - 1) / 2;
     P.threshold = c->cfg.hough_threshold;
@@ -1643,7 +1714,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         // with a work queue (k_hough3_big)
         static const bool big = !(getenv("MDH_HOUGH_BIG") && atoi(getenv("MDH_HOUGH_BIG")) == 0);
         const bool split = split_env && !(big && !c->lean);
-        hipStream_t lstream = split ? hs.stream[2] : hstream[1];
+        hipStream_t lstream = (split && !c->one_stream) ? hs.stream[2] : hstream[1];
         if (!c->lean && !split && !big) {
             tier(1);
             launch_h3(false, std::min(K, grid_l), hstream[1]);
@@ -1686,7 +1757,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     hipLaunchKernelGGL(k_pack_lines, dim3(1), dim3(1024), 0, hstream[0], (const int4*)sl.d_lines, sl.d_nraw, K, MAX_LINES,
                        (int4*)sl.d_packed, sl.d_off, sl.d_litcount, sl.d_litcopy,
                        // the format cue: dense pass -> words of b with set bits (u64); sparse pass -> its number of dense frames
-                       sl.dense ? (const unsigned*)(sl.d_nzcount + 2) : (const unsigned*)sl.d_dense,
+                       (sl.dense || sl.classic_sparse) ? (const unsigned*)(sl.d_nzcount + 2) : (const unsigned*)sl.d_dense,
                        skip_hough ? (int*)nullptr : hs.d_tier_count);
     // ONE copy: offsets, counts, gaps, frame scalars and the head of the packed segments
     HIPCHK(hipMemcpyAsync(sl.h_res, sl.d_res, sl.res_lines_off + sizeof(int) * 4 * (size_t)std::min(PACK_HEAD, MAX_LINES) * K,
@@ -1751,7 +1822,7 @@ static int slot_begin(mdh_ctx* c, int K, Slot*& out) {
     // the main stream may not overwrite this slot's buffers before the Hough stage that last read them is done
     // Consecutive passes alternate between two main streams, so the next window kernel fills the machine while the last
     // workgroups of the previous one drain (+4 % once the post stages had streams of their own; MDH_MAIN_STREAMS=1 for A/B).
-    c->stream = c->mstream[c->pass_seq % c->nmain];
+    c->stream = (c->one_stream && !c->lean_entry) ? c->pass_stream[c->pass_seq % NHSET] : c->mstream[c->pass_seq % c->nmain];
     // (a per-frame pass runs on the staging stream alone, behind the slot's previous pass if that was a per-frame one too; the
     // event of a previous BATCHED pass -- recorded on a Hough stream -- is waited for by the staging stream instead: mdh_update)
     if (sl.used && !c->lean_entry) HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
@@ -1873,6 +1944,16 @@ static int submit_pass(mdh_ctx* c, const uint8_t* frames, int K, int on_device) 
 // a dense pass the number of words of b with set bits.
 static void format_cue(mdh_ctx* c, const Slot& sl) {
     const int K = sl.K;
+    if (c->cfg.detector != MDH_DET_M3) {
+        // ClassicDetector, sparse pass: the number of blocks its stencil was handed; more than a quarter of all of them -- the
+        // threshold lets the noise through -- and the next 32 passes run the dense kernels (then the sparse format is tried again)
+        if (sl.classic_sparse) {
+            const unsigned long long listed = (unsigned long long)(unsigned)sl.h_off[K + 1] | ((unsigned long long)(unsigned)sl.h_off[K + 2] << 32);
+            const double per_frame = (double)((c->H + MORPH_RB - 1) / MORPH_RB) * c->WW;
+            if ((double)listed > 0.25 * per_frame * K) c->classic_dense_passes = 32;
+        }
+        return;
+    }
     if (!sl.dense) {
         const double share = (double)(unsigned)sl.h_off[K + 1] / (double)K;  // frames whose binary was dense
         c->last_density = share;
@@ -2610,6 +2691,8 @@ extern "C" int mdh_seek(mdh_ctx* c, int64_t t0, int64_t ema_updates, double snr,
         if (c->d_act) HIPCHK(hipMemset(c->d_act, 0, sizeof(ActWord) * (size_t)c->R * c->words));
         for (int si = 0; si < c->nslot; ++si)
             if (c->slot[si].d_bbits) HIPCHK(hipMemset(c->slot[si].d_bbits, 0, sizeof(ActWord) * (size_t)c->Kmax * c->words));
+        for (int si = 0; si < c->nslot; ++si)
+            if (c->slot[si].d_cplanes) HIPCHK(hipMemset(c->slot[si].d_cplanes, 0, sizeof(ActWord) * 2 * (size_t)c->Kmax * c->words));
     }
     for (int si = 0; si < c->nslot; ++si) {
         Slot& sl = c->slot[si];
@@ -3039,9 +3122,9 @@ extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int 
     }
     uint8_t* dst = out_on_device ? out : p->d_out;
     if (p->span_cap > 0 && ((uintptr_t)src & 15) == 0 && n_out <= 65535 && p->g.dh <= 65535)
-        hipLaunchKernelGGL(k_preprocess_rows, dim3((p->g.dw + PRE_SEG - 1) / PRE_SEG, (p->g.dh + PRE_ROWS - 1) / PRE_ROWS, n_out), dim3(PRE_SEG),
+        hipLaunchKernelGGL(k_preprocess_rows, dim3((p->g.dw + PRE_SEG - 1) / PRE_SEG, (p->g.dh + PRE_ROWS - 1) / PRE_ROWS, (n_out + PRE_ZB - 1) / PRE_ZB), dim3(PRE_SEG),
                            2 * PRE_ROWS * (size_t)p->span_cap, p->stream,
-                           src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap);
+                           src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap, n_out);
     else
     hipLaunchKernelGGL(k_preprocess, dim3((px + 255) / 256, n_out), dim3(256), 0, p->stream, src, exp_frame, p->g, p->d_xi, p->d_xw,
                        p->d_yi, p->d_yw, p->d_mask, dst);

@@ -219,7 +219,10 @@ struct FrameScalars {
 #define NF_THREADS 1024  // (A/B builds: -DNF_THREADS=256)
 #endif
 #define NF_FRAMES 4096  // due frames whose frame numbers are searched in LDS when the per-frame tables are filled
-__global__ void __launch_bounds__(NF_THREADS) k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
+#ifndef NF_VGPR_CAP
+#define NF_VGPR_CAP  // (A/B builds: -DNF_THREADS=256 '-DNF_VGPR_CAP=__attribute__((amdgpu_num_vgpr(56)))': a workgroup that fits beside three window waves per SIMD)
+#endif
+__global__ void __launch_bounds__(NF_THREADS) NF_VGPR_CAP k_noise_finalize(const NoiseJob* __restrict__ jobs, int njobs,
                                                         const long long* __restrict__ sums, ScalarState* __restrict__ st,
                                                         ScalarState* __restrict__ jobres, FrameScalars* __restrict__ out,
                                                         int* __restrict__ thr_tab, int K, double roi_px, int adaptive,
@@ -2252,9 +2255,16 @@ __global__ void __launch_bounds__(256) k_classic_diff(const uint8_t* const* __re
 // byte is fetched once per pass instead of four times, by 16x fewer load instructions.  |a - b| > T on packed u16 pairs:
 // min(a - b, b - a) mod 2^16 is the absolute difference, and bit 15 of T - |d| is the comparison.  N = ring size (3 or 4:
 // int(4 / fps * fps) can truncate to 3, and numpy's negative ring indices then wrap -- Detector.py:258-261).
-template <int N>
+// SPARSE (round 6): both difference images of a frame are stored like the M3 window kernel's -- only the words with set bits, as
+// {bits, frame number} in cplanes [K][2][H][WW] (a reader takes a word whose tag is not its frame for zero), and a word of the SECOND
+// plane (|f3 - f2| > T: the one the output is made of, dst = dilate(second & ~dilate(first))) flags its 8-row block in the block
+// bitmap.  On a sky the planes are empty but for stars and streaks: up to round 5 the kernel wrote two plain bit planes per frame
+// (a quarter of its traffic, mixed into its reads) and the stencil read every word of them back -- 0.37 of the peak at the pipeline's
+// pace; now the kernel only reads, and the stencil (k_classic_close_t) visits the flagged blocks' neighbourhoods.
+template <int N, bool SPARSE = false>
 __global__ void __launch_bounds__(256) k_classic_diff_tb(const uint8_t* const* __restrict__ ptrtab, const int* __restrict__ thr_tab,
-                                                         u64* __restrict__ planes, PassGeom g, int Tc) {
+                                                         u64* __restrict__ planes, PassGeom g, int Tc,
+                                                         ActWord* __restrict__ cplanes = nullptr, unsigned* __restrict__ blockcnt = nullptr) {
     constexpr int PPL = 16, RW = 8, DW = 4;
     typedef unsigned dvec __attribute__((ext_vector_type(DW)));
     const int lane = threadIdx.x & 63;
@@ -2326,16 +2336,154 @@ __global__ void __launch_bounds__(256) k_classic_diff_tb(const uint8_t* const* _
         const unsigned bits1 = ((acc1 >> 8) & 0xFFu) | ((acc1 >> 16) & 0xFF00u);
         const unsigned bits2 = ((acc2 >> 8) & 0xFFu) | ((acc2 >> 16) & 0xFF00u);
         const unsigned both = bits1 | (bits2 << 16);
+        if constexpr (SPARSE) {
+            if (__ballot(both != 0) == 0) continue;  // (most wave-frames of a sky: nothing over the threshold in 1024 pixels)
+        }
         // gather the four lanes of a word: lane 0 <- 1, 2 <- 3, then 0 <- 2 (quad-permute DPP)
         const unsigned odd = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xF5, 0xF, 0xF, true);
         const unsigned p1 = (both & 0xFFFFu) | (odd << 16);          // plane 1, pixels 0..31 of the lane pair
         const unsigned p2 = (both >> 16) | (odd & 0xFFFF0000u);      // plane 2
         const unsigned p1u = (unsigned)__builtin_amdgcn_mov_dpp((int)p1, 0xAA, 0xF, 0xF, true);
         const unsigned p2u = (unsigned)__builtin_amdgcn_mov_dpp((int)p2, 0xAA, 0xF, 0xF, true);
+        if constexpr (SPARSE) {
+            const u64 w1 = (u64)p1 | ((u64)p1u << 32), w2 = (u64)p2 | ((u64)p2u << 32);
+            if (q == 0 && gw < words && (w1 | w2)) {  // rare: stores and non-returning atomics only (see the M3 window kernel)
+                int gwr = gw;
+                asm volatile("" : "+v"(gwr));
+                const u64 tag = (u64)(g.t_base + 1 + i);
+                if (w1) cplanes[((size_t)i * 2 + 0) * words + gwr] = ActWord{w1, tag};
+                if (w2) {
+                    cplanes[((size_t)i * 2 + 1) * words + gwr] = ActWord{w2, tag};
+                    note_block<true>(blockcnt, g, i, gwr, (unsigned)__popcll(w2));
+                }
+            }
+        } else
         if (q == 0 && gw < words) {
             planes[((size_t)i * 2 + 0) * words + gw] = (u64)p1 | ((u64)p1u << 32);
             planes[((size_t)i * 2 + 1) * words + gw] = (u64)p2 | ((u64)p2u << 32);
         }
+    }
+}
+
+// The ring of FOUR frames in the sparse format, rebuilt around what the M3 window kernel of round 6 does (the kernel above with
+// SPARSE = true reached 0.53 of the peak: two packed absolute differences per pixel pair and frame, 24 register moves to age its
+// three frames of history, one load in flight beyond the current frame, a descriptor and two table look-ups per frame on the
+// scalar unit):
+//  * the second difference of frame t, |f(t-3) - f(t-2)| > T(t), IS the first difference of frame t - 2 whenever T(t) = T(t-2)
+//    (the threshold moves at most every interval * n frames): its bits are kept from two frames ago -- one register -- instead of
+//    being recomputed; only the previous frame's pixels stay in registers.  When the threshold did change, and for the first two
+//    frames of a time chunk, the two old frames are fetched again through the table (a wave-uniform rare path);
+//  * bursts of four frames, double-buffered; pass tables (padded pointer table, global loads with a scalar base, the threshold
+//    from a WinRec made with len = 1: the low half IS T); a time chunk is a whole number of bursts.
+__global__ void __launch_bounds__(256) k_classic_diff4_sparse(const uint8_t* const* __restrict__ ptrtab, const WinRec* __restrict__ wrec,
+                                                              ActWord* __restrict__ cplanes, unsigned* __restrict__ blockcnt, PassGeom g, int Tc) {
+    constexpr int PPL = 16, RW = 8, DW = 4, U = 4;
+    typedef unsigned dvec __attribute__((ext_vector_type(DW)));
+    typedef const __attribute__((address_space(1))) dvec* gdvec_p;
+    typedef const __attribute__((address_space(1))) uint8_t* gbyte_p;
+    const int lane = threadIdx.x & 63;
+    const int words = g.H * g.WW;
+    const int gw0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPL;
+    if (gw0 >= words) return;
+    const int i0 = blockIdx.y * Tc;
+    const int steps = min(Tc, g.K - i0);
+    if (steps <= 0) return;
+    const int q = lane & 3;
+    const int gw = gw0 + (lane >> 2);
+    const int off = gw < words ? gw * 64 + q * PPL : 0;  // (past the frame: any valid address; such lanes store nothing)
+    union PK {
+        unsigned u;
+        u16x2 v;
+    };
+    auto fetchp = [&](const uint8_t* base) -> dvec {
+        unsigned o = (unsigned)off;
+        asm volatile("" : "+v"(o));
+        return __builtin_nontemporal_load((gdvec_p)((gbyte_p)base + o));
+    };
+    auto unpack = [&](const dvec& d, PK (&p)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const unsigned sel = 0x0C000C00u | (unsigned)(r & 3) | ((unsigned)(4 + (r & 3)) << 16);
+            p[r].u = __builtin_amdgcn_perm(d[r / 4 + DW / 2], d[r / 4], sel);
+        }
+    };
+    // |a - b| > T on packed pairs: min(a - b, b - a) mod 2^16 is the absolute difference, bit 15 of T - |d| the comparison;
+    // 16 result bits per lane: low half bits 8..15 = pixels 0..7, high half bits 24..31 = pixels 8..15, gathered below
+    auto diff_bits = [&](const PK (&a)[RW], const PK (&b)[RW], unsigned T) -> unsigned {
+        const u16x2 Tv = {(unsigned short)T, (unsigned short)T};
+        unsigned acc = 0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            PK d;
+            d.v = Tv - __builtin_elementwise_min((u16x2)(a[r].v - b[r].v), (u16x2)(b[r].v - a[r].v));
+            acc = (acc >> 1) | (d.u & 0x80008000u);
+        }
+        return ((acc >> 8) & 0xFFu) | ((acc >> 16) & 0xFF00u);
+    };
+    // table entry of the NEWEST frame of pass frame i is i + 3; pt[s] = entry of step s of the current burst pair
+    const uint8_t* const* pt = ptrtab + i0 + 3;
+    const WinRec* wr = wrec + i0;
+    PK prev[RW];
+    unpack(fetchp(pt[-1]), prev);
+    dvec buf[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[0][u] = fetchp(pt[u]);
+    unsigned b1_m1 = 0, b1_m2 = 0;       // first-difference bits of the previous frame and of the one before
+    unsigned T_m1 = ~0u, T_m2 = ~0u;     // their thresholds (~0: not computed yet -- the first two steps of a chunk take the rare path)
+    for (int sb = 0; sb < steps; sb += 2 * U) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (sb + h * U >= steps) break;
+            dvec(&cur)[U] = buf[h];
+            dvec(&nxt)[U] = buf[h ^ 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = fetchp(pt[(h + 1) * U + u]);  // (padded table: past the pass the last frame again)
+            unsigned Tq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) Tq[u] = wr[h * U + u].v & 0xFFFFu;  // (padding records: T = 256, nothing fires)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = sb + h * U + u;
+                const int i = i0 + s;
+                const unsigned T = Tq[u];
+                PK f0[RW];
+                unpack(cur[u], f0);
+                const unsigned bits1 = diff_bits(prev, f0, T);
+                unsigned bits2;
+                if (T == T_m2) {
+                    bits2 = b1_m2;
+                } else {  // rare (wave-uniform): the threshold moved, or the chunk has just begun -- frames t-2 and t-3 again, through the table
+                    PK f2[RW], f3[RW];
+                    unpack(fetchp(pt[h * U + u - 2]), f2);
+                    unpack(fetchp(pt[h * U + u - 3]), f3);
+                    bits2 = diff_bits(f3, f2, T);
+                }
+#pragma unroll
+                for (int r = 0; r < RW; ++r) prev[r] = f0[r];
+                b1_m2 = b1_m1; b1_m1 = bits1;
+                T_m2 = T_m1; T_m1 = T;
+                const unsigned both = bits1 | (bits2 << 16);
+                if (__ballot(both != 0) == 0) continue;  // (most wave-frames of a sky)
+                const unsigned odd = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xF5, 0xF, 0xF, true);
+                const unsigned p1 = (both & 0xFFFFu) | (odd << 16);
+                const unsigned p2 = (both >> 16) | (odd & 0xFFFF0000u);
+                const unsigned p1u = (unsigned)__builtin_amdgcn_mov_dpp((int)p1, 0xAA, 0xF, 0xF, true);
+                const unsigned p2u = (unsigned)__builtin_amdgcn_mov_dpp((int)p2, 0xAA, 0xF, 0xF, true);
+                const u64 w1 = (u64)p1 | ((u64)p1u << 32), w2 = (u64)p2 | ((u64)p2u << 32);
+                if (q == 0 && gw < words && (w1 | w2) && s < steps) {  // rare: stores and non-returning atomics only
+                    int gwr = gw;
+                    asm volatile("" : "+v"(gwr));
+                    const u64 tag = (u64)(g.t_base + 1 + i);
+                    if (w1) cplanes[((size_t)i * 2 + 0) * words + gwr] = ActWord{w1, tag};
+                    if (w2) {
+                        cplanes[((size_t)i * 2 + 1) * words + gwr] = ActWord{w2, tag};
+                        note_block<true>(blockcnt, g, i, gwr, (unsigned)__popcll(w2));
+                    }
+                }
+            }
+        }
+        pt += 2 * U;
+        wr += 2 * U;
     }
 }
 
@@ -2430,6 +2578,70 @@ __global__ void __launch_bounds__(256) k_classic_stencil_rb(const u64* __restric
         }
         h1a = h1b; h1b = h1c;
         k_a = k_b; k_b = k_c;
+    }
+}
+
+// The same stencil for the SPARSE planes of k_classic_diff_tb<N, true>: only the blocks k_morph_select_touched<false> lists -- the
+// 3x3 block neighbourhoods of the blocks in which the second difference has a set bit -- are visited, one lane per row of a block
+// (eight blocks per wave and step), tagged words read straight from the planes.  dst is all-zero elsewhere (the words a pass
+// writes are listed in nzlist, and the slot's next k_pass_prepare zeroes them), so only non-zero words are stored.
+// total_blocks: the pass's number of listed blocks (one atomic per frame), the host's cue to fall back to the dense kernels when a
+// lowered threshold lets the noise through.
+__global__ void __launch_bounds__(64) k_classic_close_t(const ActWord* __restrict__ cplanes, const unsigned* __restrict__ worklist,
+                                                        const unsigned* __restrict__ workcount, u64* __restrict__ dst_bits,
+                                                        int* __restrict__ rowcount, int* __restrict__ litcount, int* __restrict__ bbox,
+                                                        unsigned* __restrict__ nzlist, unsigned* __restrict__ nzcount, PassGeom g, int wpf,
+                                                        unsigned long long* __restrict__ total_blocks) {
+    RAISE_WAVE_PRIORITY();
+    const int lane = threadIdx.x, grp = lane >> 3, r = lane & 7;
+    const unsigned per_frame = (unsigned)(((g.H + MORPH_RB - 1) / MORPH_RB) * g.WW);
+    const size_t words = (size_t)g.H * g.WW;
+    for (unsigned u = blockIdx.x; u < (unsigned)g.K * (unsigned)wpf; u += gridDim.x) {
+        const unsigned i = u / (unsigned)wpf, sub = u - i * (unsigned)wpf;
+        const unsigned cnt = workcount[(size_t)i * WORKCNT_STRIDE];
+        if (cnt == 0) continue;
+        if (lane == 0 && sub == 0 && total_blocks != nullptr) atomicAdd(total_blocks, (unsigned long long)cnt);
+        const long long t = g.t_base + 1 + (long long)i;
+        if (t < g.n) continue;  // Detector.py:263: fewer than stack_maxsize frames -> no detection
+        const ActWord* p1 = cplanes + (size_t)i * 2 * words;  // |f1 - f0| > T
+        const ActWord* p2 = p1 + words;                       // |f3 - f2| > T
+        const unsigned* seg = worklist + (size_t)i * per_frame;
+        for (unsigned e0 = 8 * sub; e0 < cnt; e0 += 8 * (unsigned)wpf) {
+            const unsigned e = e0 + (unsigned)grp;
+            if (e >= cnt) continue;
+            const int blk = (int)(seg[e] - i * per_frame);
+            const int band = blk / g.WW, w = blk - band * g.WW;
+            const int y = band * MORPH_RB + r;
+            if (y >= g.H) continue;
+            const Win q = make_win(w, g.W);
+            u128 acc = 0;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= g.H) continue;
+                const u128 src = load_win_act(p2 + (size_t)yy * g.WW, w, g.WW, (u64)t);
+                if (src == 0) continue;  // (nothing to keep on this row: the first difference need not be looked at)
+                u128 d1 = 0;
+                for (int ey = -1; ey <= 1; ++ey) {
+                    const int y2 = yy + ey;
+                    if (y2 < 0 || y2 >= g.H) continue;
+                    d1 |= hor_or3(load_win_act(p1 + (size_t)y2 * g.WW, w, g.WW, (u64)t));
+                }
+                acc |= hor_or3(src & ~d1 & q.valid);
+            }
+            const u64 out = (u64)((acc & q.valid) >> 3);
+            if (out) {
+                const unsigned gw = (unsigned)(y * g.WW + w);
+                dst_bits[(size_t)i * words + gw] = out;
+                nzlist[atomicAdd(&nzcount[0], 1u)] = (unsigned)(i * words) + gw;
+                const int c = __popcll(out);
+                atomicAdd(&rowcount[i * g.H + y], c);
+                atomicAdd(&litcount[i], c);
+                atomicMax(&bbox[4 * i + 0], g.W - 1 - (w * 64 + __builtin_ctzll(out)));
+                atomicMax(&bbox[4 * i + 1], w * 64 + 63 - __builtin_clzll(out));
+                atomicMax(&bbox[4 * i + 2], g.H - 1 - y);
+                atomicMax(&bbox[4 * i + 3], y);
+            }
+        }
     }
 }
 

@@ -59,17 +59,26 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint8_t* __restrict__ 
 typedef unsigned pre_u4 __attribute__((ext_vector_type(4)));
 #define PRE_SEG 256
 #define PRE_ROWS 4  // output rows per workgroup: eight source-row spans in flight per workgroup before its one barrier
+// Output frames one workgroup walks through (round 6).  The counters of the launch say its waves are PARKED 79 % of the time
+// (SQ_WAIT_ANY; VALU 6.5 %, LDS 2 %: gpurun_out/r06_17): not arithmetic, not LDS -- latency.  A workgroup began with three
+// dependent round trips (the column table for its span, the row table for its rows, then the rows) for ONE frame's 24 KB; with
+// exp_frame = 3 the same kernel ran 25 % faster per byte.  Now the tables are read once per PRE_ZB frames of the same tile.
+#ifndef PRE_ZB
+#define PRE_ZB 4
+#endif
 __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __restrict__ src, int exp_frame, PreGeom g,
                                                               const int* __restrict__ xi, const short* __restrict__ xw,
                                                               const int* __restrict__ yi, const short* __restrict__ yw,
-                                                              const uint8_t* __restrict__ mask01, uint8_t* __restrict__ out, int span_cap) {
+                                                              const uint8_t* __restrict__ mask01, uint8_t* __restrict__ out, int span_cap,
+                                                              int n_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_rows[];  // [PRE_ROWS][2][span_cap]
     const int t = threadIdx.x;
     const int dx0 = blockIdx.x * PRE_SEG, dy0 = blockIdx.y * PRE_ROWS;
     const int cnt = min(PRE_SEG, g.dw - dx0);
     const int nrows = min(PRE_ROWS, g.dh - dy0);
-    src += (size_t)blockIdx.z * exp_frame * g.sh * g.sw * 3;
-    out += (size_t)blockIdx.z * g.dh * g.dw;
+    const int z0 = blockIdx.z * PRE_ZB, z1 = min(n_out, z0 + PRE_ZB);
+    const uint8_t* const src_all = src;
+    uint8_t* const out_all = out;
     const int c_first = xi[dx0], c_last = min(xi[dx0 + cnt - 1] + 1, g.sw - 1);
     const int byte0 = (c_first * 3) & ~15;
     const int span = (((c_last + 1) * 3 - byte0) + 15) & ~15;  // (<= span_cap: the host sized it from the same table)
@@ -84,16 +93,27 @@ __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __re
         a1 = xw[2 * dx + 1];
     }
     const size_t frame = (size_t)g.sh * g.sw * 3, row_bytes = (size_t)g.sw * 3;
+    int y0s[PRE_ROWS], b0s[PRE_ROWS], b1s[PRE_ROWS];  // the row table of this tile, once
+#pragma unroll
+    for (int r = 0; r < PRE_ROWS; ++r) {
+        const int dy = min(dy0 + r, g.dh - 1);
+        y0s[r] = yi[dy];
+        b0s[r] = yw[2 * dy];
+        b1s[r] = yw[2 * dy + 1];
+    }
+    for (int z = z0; z < z1; ++z) {
+    src = src_all + (size_t)z * exp_frame * frame;
+    out = out_all + (size_t)z * g.dh * g.dw;
     int best[PRE_ROWS];
 #pragma unroll
     for (int r = 0; r < PRE_ROWS; ++r) best[r] = 0;
     for (int e = 0; e < exp_frame; ++e) {
         const uint8_t* f = src + (size_t)e * frame + byte0;
-        if (e) __syncthreads();
+        if (e || z > z0) __syncthreads();
 #pragma unroll
         for (int r = 0; r < PRE_ROWS; ++r) {
             if (r < nrows) {
-                const int y0 = yi[dy0 + r], y1 = min(y0 + 1, g.sh - 1);
+                const int y0 = y0s[r], y1 = min(y0 + 1, g.sh - 1);
                 const uint8_t* r0 = f + (size_t)y0 * row_bytes;
                 const uint8_t* r1 = f + (size_t)y1 * row_bytes;
                 for (int o = t * 16; o < span; o += PRE_SEG * 16) {
@@ -110,7 +130,7 @@ __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __re
                 if (r < nrows) {
                     const uint8_t* l0 = lds_rows + (size_t)(2 * r) * span_cap;
                     const uint8_t* l1 = l0 + span_cap;
-                    const int b0 = yw[2 * (dy0 + r)], b1 = yw[2 * (dy0 + r) + 1];
+                    const int b0 = b0s[r], b1 = b1s[r];
                     int ch[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -133,6 +153,7 @@ __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __re
                 out[p] = (uint8_t)(mask01 ? best[r] * mask01[p] : best[r]);
             }
     }
+    }  // z
 }
 
 // acc = max(acc, frame) over K frames of `bytes` bytes each; 16 bytes per lane (requires bytes % 16 == 0 for the

@@ -500,6 +500,57 @@ def test_classic_detector_batched_equals_per_frame(n_eff, fps):
     b.close()
 
 
+def test_classic_sparse_format_equals_dense_kernels_under_a_moving_threshold(monkeypatch):
+    """ClassicDetector's sparse format (round 6): tagged difference planes + block lists, and for the ring of four the kernel that
+    takes the second difference from the first difference's bits of two frames ago.  That shortcut only holds while T(t) = T(t-2):
+    an ADAPTIVE threshold on a sky whose noise level steps up and down makes it move, so the re-fetch path runs in the middle of
+    passes (and at every time chunk's first two frames).  The oracle restates the fixed-threshold detect() only, so the three
+    variants of the library are compared with each other -- the dense kernels (round 5, pinned against the oracle by the tests
+    above) are the reference -- frame by frame: threshold, dst, raw segments, NMS lines; batched passes of two sizes and the
+    per-frame protocol.  A noisy stretch under a low threshold lists most blocks: the automatic fall-back to the dense kernels
+    and the return to the sparse format are crossed on the way."""
+    shape = (96, 256)
+    mask = np.ones(shape, np.uint8)
+    rng = np.random.default_rng(99)
+    s = SkyStream(*shape, 5, speed=6, streak_period=9, streak_life=6)
+    frames = []
+    for t in range(150):
+        f = s.next().astype(np.int16)
+        sigma = (0, 3, 9, 1, 14)[(t // 23) % 5]
+        if sigma:
+            f = f + np.rint(rng.normal(0, sigma, shape)).astype(np.int16)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    frames = np.stack(frames)
+
+    def run(sparse, fast4, batch):
+        monkeypatch.setenv("MDH_CLASSIC_SPARSE", sparse)
+        monkeypatch.setenv("MDH_CLASSIC_FAST4", fast4)
+        det = ClassicDetector(1, 25.0, mask, 10, binary_cfg("high"), None, max_batch=64)
+        out = []
+        if batch:
+            for lo in range(0, len(frames), batch):
+                res, info = det.detect_batch(frames[lo:lo + batch])
+                out += [(int(info[k]["bi_threshold"]), int(info[k]["lit_count"]), int(info[k]["n_raw"]), np.asarray(res[k][0]).reshape(-1, 4).copy())
+                        for k in range(len(res))]
+        else:
+            for f in frames:
+                det.update(f)
+                lines, _ = det.detect()
+                i1 = det._ctx._info1[0]
+                out.append((int(i1["bi_threshold"]), int(i1["lit_count"]), int(i1["n_raw"]), np.asarray(lines).reshape(-1, 4).copy()))
+        det.close()
+        return out
+
+    ref = run("0", "0", 37)
+    thresholds = {r[0] for r in ref}
+    assert len(thresholds) >= 3, thresholds  # the threshold really moved
+    assert sum(r[2] for r in ref) > 0
+    for sparse, fast4, batch in (("1", "1", 37), ("1", "1", 64), ("1", "0", 37), ("1", "1", 0), ("0", "0", 0)):
+        got = run(sparse, fast4, batch)
+        for t, (a, b) in enumerate(zip(ref, got)):
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (sparse, fast4, batch, t, a[:3], b[:3])
+
+
 def test_api_errors():
     shape = (32, 64)
     mask = np.ones(shape, np.uint8)
