@@ -648,7 +648,8 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=Fal
         nchunks = max(1, min(-(-8192 // waves), B // 8))
     else:                      # launch_wide: 16 pixels per lane up to n = 16
         waves = -(-words // 16) if W % 64 == 0 and n <= 16 else -(-words // 8)  # (n = 17 .. 32: the 8-pixels-per-lane variants)
-        nchunks = max(1, min(-(-4096 // waves), B // (2 * n)))
+        target = 16384 if B * frame <= 3.0e9 else 4096  # (launch_wide: short passes are cut into four times as many time chunks)
+        nchunks = max(1, min(-(-target // waves), B // (2 * n)))
     tc = -(-B // nchunks)
     if DETECTOR != "classic" and W % 64 == 0 and n <= 32:
         tc = -(-tc // n) * n  # (round 6: every time chunk but the last is a whole number of window periods, launch_wide)

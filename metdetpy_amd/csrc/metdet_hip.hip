@@ -1208,7 +1208,12 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean, con
     const int waves = (words + PPL - 1) / PPL;
     static const int target_waves = getenv("MDH_WIN_WAVES") ? atoi(getenv("MDH_WIN_WAVES")) : 4096;  // experiment switch
     static const int wpb = getenv("MDH_WIN_BLOCK") ? std::max(1, std::min(4, atoi(getenv("MDH_WIN_BLOCK")) / 64)) : 4;  // waves per workgroup
-    int nchunks = (target_waves + waves - 1) / waves;
+    // Short passes (under ~3 GB of frames: their window kernel lasts a few hundred microseconds) are cut into four times as many time
+    // chunks: the workgroups are shorter-lived, and the small kernels of the neighbouring passes -- which wait for a workgroup slot
+    // behind them -- get one sooner (1000-frame 1080p passes 1.94 -> 2.10 M frames/s, 250-frame ones +3 %: gpurun_out/r06_24; a
+    // 4000-frame pass gains nothing and pays the extra window histories).
+    const bool short_pass = (double)g.K * (double)c->HW <= 3.0e9 && !getenv("MDH_WIN_WAVES");
+    int nchunks = ((short_pass ? 4 * target_waves : target_waves) + waves - 1) / waves;
     const int cap = std::max(1, g.K / (2 * N));
     nchunks = std::max(1, std::min(nchunks, cap));
     {   // Time chunks so that the grid is close to a whole number of ROUNDS of resident workgroups (256 CUs x 3 workgroups of four
@@ -1584,8 +1589,18 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
             EV_WAIT(c, post, c->slot[c->prev_slot].ev_close);
         span_begin(c, KK_DY_APPLY, post);
         if (!(skip_stages() & 4))
-        hipLaunchKernelGGL(k_dy_sparse, dim3(c->lean && K == 1 ? 64 : 2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist, sl.d_nzcount,
-                           sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
+        {
+            // (k_dy_sparse<16>: sixteen history words per round trip for the long windows -- measured SLOWER, 0.29 -> 0.40 ms per
+            // 4000-frame pass at n = 25, gpurun_out/r06_25: most listed words are done after the first four, and the sixteen loads
+            // cost the kernel its place beside the window waves; MDH_DY_BATCH16=1 for A/B)
+            static const bool batch16 = getenv("MDH_DY_BATCH16") && atoi(getenv("MDH_DY_BATCH16")) != 0;
+            if (c->n > 16 && batch16)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dy_sparse<16>), dim3(c->lean && K == 1 ? 64 : 2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist,
+                                   sl.d_nzcount, sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dy_sparse<4>), dim3(c->lean && K == 1 ? 64 : 2048), dim3(256), 0, post, c->d_act, sl.d_dst, sl.d_nzlist,
+                                   sl.d_nzcount, sl.d_rowcount, sl.d_litcount, sl.d_bbox, g, c->cfg.dy_mask);
+        }
         span_end(c, post);
     } else {
         static const bool classic_rb = !(getenv("MDH_CLASSIC_TB") && atoi(getenv("MDH_CLASSIC_TB")) == 0);

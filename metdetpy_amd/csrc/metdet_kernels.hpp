@@ -1973,6 +1973,9 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {
 // y + dy from each of the len history frames (independent loads) and ANDs them; the 3x3 erode is finished by lanes 1,
 // 4, 7 of the group (one per row) and lane 0 stores the result.
 // (device function: `first_e` = this 16-lane group's first list entry, `ngroups` = groups walking the list)
+// BATCH: history words fetched per round trip behind the first four -- 4 up to n = 16 (54 registers: the kernel fits beside three
+// window waves per SIMD), 16 for the long windows
+template <int BATCH = 4>
 __device__ __forceinline__ void dy_sparse_items(const ActWord* __restrict__ act_ring, u64* __restrict__ dst_bits,
                                                 const unsigned* __restrict__ nzlist, unsigned total, int* __restrict__ rowcount,
                                                 int* __restrict__ litcount, int* __restrict__ bbox, const PassGeom& g, int use_dy,
@@ -2003,17 +2006,33 @@ __device__ __forceinline__ void dy_sparse_items(const ActWord* __restrict__ act_
                     // of them -- 144 tagged 16-byte loads per listed word at n = 16 -- each behind a 64-bit modulo for its ring slot)
                     const int slot0 = (int)((t - 1) % g.R);  // ring slot of frame t; frame t - j sits j slots back (len <= n <= R)
                     const int cell = yy * g.WW + ww;
-                    for (int j0 = 0; j0 < len && all != 0; j0 += 4) {
+                    // (round 6: behind the first four, the rest in batches of SIXTEEN independent loads -- with windows of 25 / 30
+                    // frames a persisting streak's word stays lit for most of them, and four at a time that was a chain of seven
+                    // dependent round trips per listed word: 0.29 ms per 4000-frame pass at n = 25 against 0.10 at n = 8)
+                    {
                         u64 v[4];
 #pragma unroll
                         for (int k2 = 0; k2 < 4; ++k2) {
+                            int sl = slot0 - k2;
+                            if (sl < 0) sl += g.R;
+                            v[k2] = k2 < len ? act_word(act_ring + (size_t)sl * words, cell, (u64)(t - k2)) : ~0ull;
+                        }
+                        first = v[0];
+                        all &= v[0] & v[1] & v[2] & v[3];
+                    }
+                    for (int j0 = 4; j0 < len && all != 0; j0 += BATCH) {
+                        u64 v[BATCH];
+#pragma unroll
+                        for (int k2 = 0; k2 < BATCH; ++k2) {
                             const int j = j0 + k2;
                             int sl = slot0 - j;
                             if (sl < 0) sl += g.R;
                             v[k2] = j < len ? act_word(act_ring + (size_t)sl * words, cell, (u64)(t - j)) : ~0ull;
                         }
-                        if (j0 == 0) first = v[0];
-                        all &= v[0] & v[1] & v[2] & v[3];
+                        u64 a = ~0ull;
+#pragma unroll
+                        for (int k2 = 0; k2 < BATCH; ++k2) a &= v[k2];
+                        all &= a;
                     }
                 } else {
                     all = 0;
@@ -2044,12 +2063,13 @@ __device__ __forceinline__ void dy_sparse_items(const ActWord* __restrict__ act_
         }
     }
 }
+template <int BATCH = 4>
 __global__ void __launch_bounds__(256) k_dy_sparse(const ActWord* __restrict__ act_ring, u64* __restrict__ dst_bits,
                                                    const unsigned* __restrict__ nzlist, const unsigned* __restrict__ nzcount,
                                                    int* __restrict__ rowcount, int* __restrict__ litcount,
                                                    int* __restrict__ bbox, PassGeom g, int use_dy) {
     RAISE_WAVE_PRIORITY();
-    dy_sparse_items(act_ring, dst_bits, nzlist, *nzcount, rowcount, litcount, bbox, g, use_dy, (blockIdx.x * blockDim.x + threadIdx.x) >> 4,
+    dy_sparse_items<BATCH>(act_ring, dst_bits, nzlist, *nzcount, rowcount, litcount, bbox, g, use_dy, (blockIdx.x * blockDim.x + threadIdx.x) >> 4,
                     gridDim.x * (blockDim.x >> 4));
 }
 
