@@ -6,7 +6,8 @@
 set -u
 TAG=${1:-r01}
 WL=${2:-C2}
-OUT=gpurun_out/profile_${TAG}_$WL
+NAME=${NAME:-$WL}   # (file names: NAME=C2n25 EXTRA="--window 25" bash tools/profile_round.sh r06 C2)
+OUT=gpurun_out/profile_${TAG}_$NAME
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="bench.py --workload $WL --steps 24 --warmup 6 --passes-per-step 1 --no-secondary --cpu-seconds 0 --parity-frames 0 --standalone-passes 0 --no-pmc ${EXTRA:-}"
@@ -17,19 +18,19 @@ rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r --output-format csv -- pyt
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_d1" -o r --output-format csv -- python $ARGS --depth 1 > "$OUT/stats_d1.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o r --output-format csv -- python $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o r --output-format csv -- python $ARGS > "$OUT/write.log" 2>&1
-python - "$OUT" "$TAG" "$WL" <<'PY'
+python - "$OUT" "$TAG" "$WL" "$NAME" <<'PY'
 import csv, glob, json, sys, collections, shutil, os
 sys.path.insert(0, os.getcwd())
-out, tag, wl = sys.argv[1], sys.argv[2], sys.argv[3]
+out, tag, wl, name = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 def one(pattern):
     f = glob.glob(pattern, recursive=True)
     return f[0] if f else None
 stats = one(f"{out}/stats/**/*kernel_stats.csv")
 if stats:
-    shutil.copy(stats, f"{out}/{tag}_rocprofv3_kernel_stats_{wl}.csv")
+    shutil.copy(stats, f"{out}/{tag}_rocprofv3_kernel_stats_{name}.csv")
 stats1 = one(f"{out}/stats_d1/**/*kernel_stats.csv")
 if stats1:
-    shutil.copy(stats1, f"{out}/{tag}_rocprofv3_kernel_stats_{wl}_depth1.csv")
+    shutil.copy(stats1, f"{out}/{tag}_rocprofv3_kernel_stats_{name}_depth1.csv")
 def per_kernel(path, counter):
     acc, cnt, seen = collections.defaultdict(float), collections.Counter(), set()
     for row in csv.DictReader(open(path)):
@@ -54,7 +55,7 @@ if fetch and write:
         if "stack_threshold" in k:
             res["stack_threshold_bytes_per_launch"] = res["kernels"][k]["hbm_read_bytes_per_launch"] + res["kernels"][k]["hbm_write_bytes_per_launch"]
 res["frames_per_launch"] = bench.WORKLOADS[wl]["batch"]
-json.dump(res, open(f"{out}/pmc_traffic_{wl}.json", "w"), indent=1)
+json.dump(res, open(f"{out}/pmc_traffic_{name}.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "note"})[:1500])
 PY
-head -14 "$OUT/${TAG}_rocprofv3_kernel_stats_${WL}.csv" 2>/dev/null | cut -c1-160
+head -14 "$OUT/${TAG}_rocprofv3_kernel_stats_${NAME}.csv" 2>/dev/null | cut -c1-160
