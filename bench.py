@@ -623,6 +623,34 @@ def pmc_traffic_live(a, dense, kern=None):
                      f"{int(got['WRITE_SIZE'][0] * 1024)} B per launch")
 
 
+def compulsory_bytes(H, W, n, B, dense, detector="m3"):
+    """Bytes ONE launch of the dominant pixel kernel must move for a pass of B frames: every frame byte once plus the window
+    history per time chunk (the launch geometry of launch_wide / run_pixels in metdet_hip.hip is restated here), plus what the
+    dense output formats write.  Returns (bytes, time chunks, bit words per frame).  tools/profiles_table.py prices the committed
+    rocprofv3 summaries with the same function."""
+    frame = H * W
+    words = H * ((W + 63) // 64)
+    if detector == "classic":  # launch geometry of run_pixels (metdet_hip.hip)
+        waves = -(-words // 16)
+        nchunks = max(1, min(-(-8192 // waves), B // 8))
+    else:                      # launch_wide: 16 pixels per lane up to n = 16
+        waves = -(-words // 16) if W % 64 == 0 and n <= 16 else -(-words // 8)  # (n = 17 .. 32: the 8-pixels-per-lane variants)
+        target = 16384 if B * frame <= 3.0e9 else 4096  # (launch_wide: short passes are cut into four times as many time chunks)
+        nchunks = max(1, min(-(-target // waves), B // (2 * n)))
+    tc = -(-B // nchunks)
+    if detector != "classic" and W % 64 == 0 and n <= 32:
+        tc = -(-tc // n) * n  # (round 6: every time chunk but the last is a whole number of window periods, launch_wide)
+    if detector == "classic" and not dense and n == 4:
+        tc = -(-tc // 4) * 4  # (k_classic_diff4_sparse: a time chunk is a whole number of four-frame bursts)
+    nchunks = -(-B // tc)
+    compulsory = frame * (B + nchunks * (n - 1))
+    if dense and detector != "classic":
+        compulsory += words * 8 * B  # the dense output format writes every word of the thresholded difference (1 bit per pixel)
+    if detector == "classic" and dense:
+        compulsory += 2 * words * 8 * B  # dense format: k_classic_diff_tb stores TWO plain bit planes per frame (|f1 - f0| > T and |f3 - f2| > T), every word
+    return compulsory, nchunks, words
+
+
 def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=False, live_traffic=None):
     """Physical roofline of the dominant pixel kernel (the window kernel; Classic: the difference kernel).  Bytes one launch
     MUST move: every frame of the pass once plus the n-1 frames of history its window starts from, per time chunk (the
@@ -641,24 +669,8 @@ def roofline(prof_pipe, prof_alone, H, W, n, B, ms_per_pass, workload, dense=Fal
     ms, launches = prof_pipe.get(kern, (0.0, 0))
     if not launches:
         return None
+    compulsory, nchunks, words = compulsory_bytes(H, W, n, B, dense, DETECTOR)
     frame = H * W
-    words = H * ((W + 63) // 64)
-    if DETECTOR == "classic":  # launch geometry of run_pixels (metdet_hip.hip)
-        waves = -(-words // 16)
-        nchunks = max(1, min(-(-8192 // waves), B // 8))
-    else:                      # launch_wide: 16 pixels per lane up to n = 16
-        waves = -(-words // 16) if W % 64 == 0 and n <= 16 else -(-words // 8)  # (n = 17 .. 32: the 8-pixels-per-lane variants)
-        target = 16384 if B * frame <= 3.0e9 else 4096  # (launch_wide: short passes are cut into four times as many time chunks)
-        nchunks = max(1, min(-(-target // waves), B // (2 * n)))
-    tc = -(-B // nchunks)
-    if DETECTOR != "classic" and W % 64 == 0 and n <= 32:
-        tc = -(-tc // n) * n  # (round 6: every time chunk but the last is a whole number of window periods, launch_wide)
-    nchunks = -(-B // tc)
-    compulsory = frame * (B + nchunks * (n - 1))
-    if dense and DETECTOR != "classic":
-        compulsory += words * 8 * B  # the dense output format writes every word of the thresholded difference (1 bit per pixel)
-    if DETECTOR == "classic" and dense:
-        compulsory += 2 * words * 8 * B  # dense format: k_classic_diff_tb stores TWO plain bit planes per frame (|f1 - f0| > T and |f3 - f2| > T), every word
     avg_ms = ms / launches
     frac_of = lambda t_ms: compulsory / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out.update({

@@ -180,8 +180,11 @@ int mdh_device_copy(mdh_ctx* ctx, void* dst_device, const void* src_device, uint
 void* mdh_host_alloc(mdh_ctx* ctx, uint64_t bytes);
 int mdh_host_free(mdh_ctx* ctx, void* ptr);   /* a pool may be freed through any context of the process, never by hipHostFree directly */
 /* The per-frame protocol reads a frame IN PLACE (no copy in front of the window kernel) when the caller's buffer is memory a
- * kernel can reach: a pool of mdh_host_alloc, memory the caller pinned itself (hipHostMalloc / hipHostRegister), or ordinary
- * memory registered here.  The reference's loaders hand over plain NumPy arrays (MetDetPy.py:192; videoloader.py:569-593), and
+ * kernel can reach AND the library knows about: a pool of mdh_host_alloc, or a range announced with mdh_host_register -- ordinary
+ * memory (registered here) or memory the caller pinned itself (hipHostMalloc / hipHostRegister of its own: accepted as it is since
+ * round 6, and left to the caller to release).  Up to round 5 the library also asked the runtime about any other pointer
+ * (hipPointerGetAttributes); the runtime gives the same answer for a range that was registered once and freed without being
+ * unregistered, and a read through such a stale mapping is a GPU memory fault that aborts the process.  The reference's loaders hand over plain NumPy arrays (MetDetPy.py:192; videoloader.py:569-593), and
  * ProcessVideoLoader recycles a fixed ring of them (a shared RawArray, videoloader.py:696-701, 746-772):
  *   mdh_host_register(ctx, ring_base, ring_bytes)   once, by a loader that knows its ring;  mdh_host_unregister before freeing it
  *   mdh_set_auto_register(ctx, 1)  (OFF by default since ABI 4; MDH_AUTO_REGISTER=1 in the environment switches it on): the

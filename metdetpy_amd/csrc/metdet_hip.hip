@@ -175,6 +175,7 @@ struct mdh_ctx {
     // kernel, but a 250-frame pass (window kernel 0.1 ms) lasted 0.6 ms from its first launch to its results, one such pass
     // completing every 0.23 ms (rocprofv3 kernel trace, gpurun_out/r06_12).  On one stream the stages follow each other at kernel-boundary
     // cost, and NCHAIN passes run side by side.
+    bool win_missing = false;  // launch_wide asked the window translation units for an instantiation none of them holds (a build error: loud)
     bool one_stream = false;
     hipStream_t pass_stream[NHSET] = {nullptr, nullptr, nullptr, nullptr};
     int nmain = 2;  // main streams in use (MDH_MAIN_STREAMS): with 2, the window kernel of pass p+1 ramps up while that of pass p drains
@@ -1283,14 +1284,14 @@ static void launch_wide(mdh_ctx* c, const PassGeom& g, const LeanArgs& lean, con
             mail_cancel(c);
         }
         if (!c->mail_used)
-            win_launch(WindowLaunch{N, PPL, WIN_LEAN, dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr, c->d_bbits,
+            c->win_missing |= !win_launch(WindowLaunch{N, PPL, WIN_LEAN, dim3((waves + 3) / 4, nchunks), dim3(256), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr, c->d_bbits,
                                     c->d_bandflag, g, Tc, lean, nullptr, nullptr});
     }
     else if (wide_has_dense(N, PPL) && c->win_dense)  // dense output format (its own instantiation as well)
-        win_launch(WindowLaunch{N, PPL, WIN_DENSE, dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr,
+        c->win_missing |= !win_launch(WindowLaunch{N, PPL, WIN_DENSE, dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr,
                                 (ActWord*)c->win_plain, dense_candidates_inline() ? c->d_bandflag : (unsigned*)nullptr, g, Tc, lean, c->win_nzwords, c->d_wrec});
     else
-        win_launch(WindowLaunch{N, PPL, WIN_SPARSE, dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr,
+        c->win_missing |= !win_launch(WindowLaunch{N, PPL, WIN_SPARSE, dim3((waves + wpb - 1) / wpb, nchunks), dim3(64 * wpb), c->tag_lds, c->stream, c->d_ptrtab, c->d_thr,
                                 c->d_bbits, getenv("MDH_ALL_DENSE") ? (unsigned*)nullptr : c->d_bandflag, g, Tc, lean, c->win_nzwords, c->d_wrec});
     c->win_dense_used = wide_has_dense(N, PPL) && c->win_dense && !lean.copy_dst;
 }
@@ -1471,6 +1472,10 @@ static int run_pixels(mdh_ctx* c, Slot& sl, int K) {
         }
         if (!skip_window) launch_stack_threshold(c, g, copy_dst);  // (nothing stored = all zero: the words are tagged)
         span_end(c, c->stream);
+        if (c->win_missing) {
+            set_err("internal: no window-kernel instantiation for n = " + std::to_string(g.n) + " (metdet_window.hip parts out of step with launch_wide)");
+            return MDH_E_STATE;
+        }
         // the caller's buffer has been read when the kernel is done: announced by the kernel itself (polled word), or by an event
         if (c->lean_direct && !c->lean_poll) HIPCHK(hipEventRecord(c->ev_copy, c->stream));
     } else {

@@ -433,6 +433,30 @@ def test_bench_refuses_the_store_fallback_when_every_rank_has_a_gpu(tmp_path, fo
     assert res == ({"exit": None, "backend": "store"} if forced_store else {"exit": 3})
 
 
+def test_profiles_readme_table_matches_the_tracked_csv():
+    """profiles/README.md quoted an AverageNs the tracked CSV did not hold.  The README's table of the
+    round's `*_depth1.csv` summaries is generated (tools/profiles_table.py) and checked here against the files themselves: the
+    duration as the CSV has it, the bytes of bench.compulsory_bytes, the fraction within 1 %; DESIGN.md may quote a file's
+    fraction only as the README has it."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import profiles_table as pt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "profiles", "README.md")).read()
+    listed = pt.parse(text)
+    assert listed, "profiles/README.md holds no generated table"
+    tag = listed[0][0].split("_")[0]
+    now = {r[0]: r for r in pt.rows(tag)}
+    assert {f for f, *_ in listed} == set(now), (sorted(f for f, *_ in listed), sorted(now))
+    for f, avg, nbytes, frac in listed:
+        r = now[f]
+        assert abs(avg - r[3]) <= 0.5 and nbytes == r[4], (f, avg, r[3], nbytes, r[4])
+        assert abs(frac - r[6]) <= 0.01 * r[6] + 0.0006, (f, frac, r[6])
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    for f, avg, nbytes, frac in listed:  # every "<file> ... 0.xxx" quote of DESIGN.md in the same sentence must be the README's figure
+        for m in re.finditer(re.escape(f) + r"[^.\n]{0,120}?\b(0\.\d{3})\b", design):
+            assert abs(float(m.group(1)) - frac) <= 0.01 * frac + 0.0006, (f, m.group(1), frac)
+
+
 def test_every_environment_switch_is_documented():
     """The library and the bench read MDH_* switches from the environment (A/B builds of one path, experiments, instrumentation);
     INTEGRATION.md's table is where a maintainer finds out what each does: none may be missing from it."""

@@ -9,6 +9,7 @@ from metdetpy_amd.synth import SkyStream
 
 WL = os.environ.get("WL", "C2")
 H, W, n, B, uniq = {"C2": (1080, 1920, 8, 1024, 250), "C3": (2160, 3840, 16, 256, 100), "C5": (4320, 7680, 8, 64, 50), "C1s": (540, 960, 8, 2048, 250)}[WL]
+n = int(os.environ.get("WINDOW", n))  # WINDOW=25: the reference's default window length on the same stream
 mask = np.ones((H, W), np.uint8)
 bench.SENSITIVITY = bench.WORKLOADS[WL].get("sensitivity", "normal")
 STREAM = os.environ.get("STREAM", "sky")  # bench.py --stream: sky | noisy | hot | cloud | sparse | dense
