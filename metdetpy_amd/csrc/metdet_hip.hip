@@ -210,6 +210,7 @@ struct mdh_ctx {
     const unsigned short* d_perm = nullptr;  // PPHT visiting-order tables (shared by every context on the device)
     const unsigned* d_rnd = nullptr;         // the first HOUGH_BIG_LIST outputs of cv::RNG(-1) (likewise)
     int lds_small = 80 * 1024, lds_large = 160 * 1024;  // dynamic LDS of the two three-wave PPHT launches (MDH_HOUGH_LDS_SMALL / _LARGE)
+    bool hough_bands = true;                            // frames routed by their band windows where the corner windows miss the small launch (MDH_HOUGH_BANDS)
     int lds_tiny = 40 * 1024;                           // ... and of the launch for short streaks (MDH_HOUGH_LDS_TINY; 0: no such launch)
     long long* d_hdbg = nullptr;  // MDH_HOUGH_DEBUG=1: per-frame cycle stamps of the last pass
     uint8_t* d_expand = nullptr;
@@ -898,6 +899,7 @@ extern "C" mdh_ctx* mdh_create(int device, int H, int W, int n_window, const mdh
         c->one_stream = role == MDH_ROLE_FULL && cfg->detector == MDH_DET_M3 && (double)c->Kmax * H * W <= max_mb * 1e6 && c->Kmax > 8;
         if (c->one_stream) c->nhset = NHSET;
     }
+    if (const char* v = getenv("MDH_HOUGH_BANDS")) c->hough_bands = atoi(v) != 0;
     if (const char* v = getenv("MDH_HOUGH_LDS_SMALL")) c->lds_small = std::max(16 * 1024, std::min(160 * 1024, atoi(v)));
     if (const char* v = getenv("MDH_HOUGH_LDS_LARGE")) c->lds_large = std::max(c->lds_small, std::min(160 * 1024, atoi(v)));
     // (frames of up to a megapixel only: at 960x540 the Hough stage is the largest item next to the window kernel and four
@@ -1665,6 +1667,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
     P.perm_big = hs.d_perm_big;
     P.mute = (int)std::max<int64_t>(0, std::min<int64_t>(K, c->mute_until - sl.t_base));
     P.acc_mode = c->cfg.hough_mode == MDH_HOUGH_ACCUMULATOR;
+    P.band_routing = c->hough_bands && !c->lean;  // (the per-frame protocol's one launch has the whole LDS anyway)
     P.list_cap = HOUGH_MAX_LIST; P.cell_cap = 61440;  // the one-wave kernel's LDS
     // Routing first (k_hough_classify: adaptive gap, and which launch replays each frame), then the launches side by side:
     // the small-LDS three-wave launch on stream [0]; the large-LDS launch, the hybrid launch (pooled global accumulator) and

@@ -2709,6 +2709,7 @@ struct HoughParams {
     unsigned short* perm_big;    // ... into its pool slot's [HOUGH_BIG_LIST] entries of this buffer (hough3_frame<true>)
     const int* bbox;       // [K][4] {W-1 - min x, max x, H-1 - min y, max y} of the lit pixels
     int mute;              // the first `mute` frames of the pass are not replayed (time-window warm-up: results dropped anyway)
+    int band_routing;      // 1 = frames that miss the small launch by their corner windows are routed by their band windows (round 6; MDH_HOUGH_BANDS=0: off)
     int acc_mode;          // 1 = full-accumulator Hough (h3_accumulate) instead of the exact replay, in the three-wave kernels
 };
 
@@ -3279,7 +3280,18 @@ __device__ __forceinline__ int hough3_lds_need(int N, int uv_cap, int cells, int
 }
 
 // One wave per frame.  Returns the tier (-1: nothing to replay).
-__device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
+// Round 6: BAND WINDOWS in the routing.  The rho windows of a frame's 180 angles come from the corners of the bounding box of its lit
+// pixels; a streak is thin and oblique, so the range its points really span is 15-35 % smaller -- and at long windows (n = 25: a
+// streak stays in the window for 37 of 50 frames, two or three streaks per frame) a quarter to a half of the frames need 85-100 KB by
+// their corners: the whole LDS of a CU each (tier 1) instead of half of it.  A frame that misses the small launch by its corner
+// windows is looked at again with the x-extent of its lit pixels per band of HB_ROWS rows (what hough3_frame derives from its point
+// list when the corner windows do not fit: the same boxes, hence the same windows); if THOSE fit, the frame takes the small launch.
+#ifndef HOUGH_BAND_ROUTING
+#define HOUGH_BAND_ROUTING 1
+#endif
+#define HOUGH_HB_ROWS 8          // rows per band
+#define HOUGH_CLS_MAXBANDS 136   // bands the routing looks at (bounding boxes of up to 1088 rows); scratch: 2 x this many dwords per wave
+__device__ int hough_classify_frame(const HoughParams& P, int i, int lane, unsigned* scratch) {
     const int N = P.litcount[i];
     double gap = P.max_gap;
     if (!P.fixed_gap) {
@@ -3320,8 +3332,70 @@ __device__ int hough_classify_frame(const HoughParams& P, int i, int lane) {
         return (fits && !P.acc_mode && !P.no_lds_acc && P.perm_big != nullptr) ? 2 : 3;
     }
     if (P.no_lds_acc) return 2;
-    const int need = hough3_lds_need(N, hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1), cells, mask_dw);
+    const int uvc = hough3_uv_cap(N, bx1 - bx0 + 1, by1 - by0 + 1);
+    const int need = hough3_lds_need(N, uvc, cells, mask_dw);
     if (P.lds_tiny > 0 && need <= P.lds_tiny) return 4;
+#if HOUGH_BAND_ROUTING
+    const int rows = by1 - by0 + 1, nhb = (rows + HOUGH_HB_ROWS - 1) / HOUGH_HB_ROWS;
+    // The launch the band windows might bring the frame into: the next smaller one than its corner windows ask for -- and only if
+    // those miss it by less than half (the band windows save a third at best).  The scratch hough3_frame keeps the boxes in -- the
+    // cells region of THAT launch -- must hold them: the same test as there, with that launch's budget.
+    const int limit = (P.lds_tiny > 0 && need <= P.lds_tiny / 2 * 3) ? P.lds_tiny : P.lds_small;
+    const int budget_dw = limit / 4 - HOUGH3_FIXED_DWORDS - ((N + 3) & ~3) - 2 * uvc - HOUGH3_THREADS;
+    if (P.band_routing && need > limit && need <= limit / 2 * 3 && nhb <= HOUGH_CLS_MAXBANDS && scratch != nullptr && !P.acc_mode &&
+        2 * nhb + HOUGH3_THREADS <= budget_dw - mask_dw) {
+        unsigned* const bmin = scratch;
+        unsigned* const bmax = scratch + HOUGH_CLS_MAXBANDS;
+        for (int b = lane; b < nhb; b += 64) { bmin[b] = 0xFFFFu; bmax[b] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int wlo = bx0 >> 6, wpr = (bx1 >> 6) - wlo + 1, TW = rows * wpr;
+        const u64* dst = P.dst_bits + (size_t)i * ((size_t)P.H * P.WW);
+#pragma unroll 2
+        for (int e = lane; e < TW; e += 64) {
+            const int ry = e / wpr, w = wlo + (e - ry * wpr);
+            const u64 word = dst[(size_t)(by0 + ry) * P.WW + w];
+            if (word) {
+                atomicMin(&bmin[ry / HOUGH_HB_ROWS], (unsigned)(w * 64 + __builtin_ctzll(word)));
+                atomicMax(&bmax[ry / HOUGH_HB_ROWS], (unsigned)(w * 64 + 63 - __builtin_clzll(word)));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (kept small on purpose: this kernel's waves must find room beside the window kernel's -- no unrolling of the band loop)
+        float c3[3], s3[3];
+        int rmin3[3], rmax3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = min(lane + 64 * q, NUM_ANGLE - 1);
+            c3[q] = P.trig[2 * n];
+            s3[q] = P.trig[2 * n + 1];
+            rmin3[q] = 0x7FFFFFFF;
+            rmax3[q] = -0x7FFFFFFF;
+        }
+#pragma unroll 1
+        for (int b = 0; b < nhb; ++b) {
+            const int x_lo = (int)bmin[b], x_hi = (int)bmax[b];
+            if (x_lo > x_hi) continue;
+            const int y_lo = by0 + b * HOUGH_HB_ROWS, y_hi = min(y_lo + HOUGH_HB_ROWS - 1, by1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool cpos = c3[q] >= 0.f, spos = s3[q] >= 0.f;
+                rmin3[q] = min(rmin3[q], rho_bin(cpos ? x_lo : x_hi, spos ? y_lo : y_hi, c3[q], s3[q], 0));
+                rmax3[q] = max(rmax3[q], rho_bin(cpos ? x_hi : x_lo, spos ? y_hi : y_lo, c3[q], s3[q], 0));
+            }
+        }
+        int cells_b = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int size = lane + 64 * q < NUM_ANGLE ? rmax3[q] - rmin3[q] + 1 : 0;
+            cells_b += max(size, __shfl_xor(size, 1));
+        }
+        for (int o = 32; o > 0; o >>= 1) cells_b += __shfl_xor(cells_b, o);
+        __builtin_amdgcn_wave_barrier();  // (the scratch is this wave's for the next frame too)
+        if (hough3_lds_need(N, uvc, cells_b, mask_dw) <= limit) return limit == P.lds_small ? 0 : 4;
+    }
+#endif
     return need <= P.lds_small ? 0 : (need <= P.lds_large ? 1 : 2);
 }
 
@@ -3330,7 +3404,8 @@ __global__ void __launch_bounds__(256) k_hough_classify(HoughParams P) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= P.K) return;
-    const int tier = hough_classify_frame(P, i, lane);
+    __shared__ unsigned cls_scratch[4][2 * HOUGH_CLS_MAXBANDS];
+    const int tier = hough_classify_frame(P, i, lane, cls_scratch[threadIdx.x >> 6]);
     if (tier >= 0 && lane == 0) P.tier_list[tier * P.K + atomicAdd(&P.tier_count[tier], 1)] = i;
 }
 
@@ -3850,7 +3925,9 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     const bool big_n = HYBRID && N > HOUGH_MAX_LIST;  // (its own visiting-order table, built below in the region behind the un-vote list)
     if (HYBRID) mask_lds = !big_n && mask_dw <= budget_dw / 4;  // a huge bounding box: the mask stays in global memory, the LDS goes to the cells
     unsigned* cells = lmask + (mask_lds ? mask_dw : 0);
-    const int cell_cap = HYBRID ? (P.no_lds_acc ? 0 : 2 * (budget_dw - (mask_lds ? mask_dw : 0))) : 0x7FFFFFFF;
+    // halves the cells may take (the all-LDS launches: the routing made sure the frame's windows fit -- its corner windows, or, round 6,
+    // its band windows: hough_classify_frame)
+    const int cell_cap = HYBRID ? (P.no_lds_acc ? 0 : 2 * (budget_dw - (mask_lds ? mask_dw : 0))) : 2 * (budget_dw - mask_dw);
     if (tid < HOUGH3_FIXED_DWORDS) fix[tid] = 0;
     // ---- row-major point list + working mask from the words of the bounding box
     const size_t words = (size_t)P.H * P.WW;
@@ -3943,9 +4020,8 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
     // both threads of a pair ask for `w_st` halves, so every decision below (fits / goes to the global accumulator) is the pair's
     int w_st = max(w_size, __shfl_xor(w_size, 1));
     int placed = w_st, total = 0;
-    if (HYBRID) {
-        h3_scan(w_st, total, fix + 32, lane, wave);
-        if (total > cell_cap && cell_cap > 0) {
+    auto band_windows = [&]() {
+        {
             // The corner windows do not fit.  A streak is thin and usually oblique, so the rho range its points really span is
             // up to a third smaller than what the corners of its bounding box span.  Round 2 swept the point list for the exact
             // window of every angle (the cost of voting every point once: 40 of a 2100-point frame's 69 us of set-up); round 3
@@ -3954,7 +4030,7 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
             // monotone -- so a box's extremes are at two of its corners.  The windows come out at most HB_ROWS - 1 rows' worth
             // of rho wider than the exact ones (a superset is all the replay needs); the cells region is free until it is
             // initialised below and serves as scratch.
-            constexpr int HB_ROWS = 8;
+            constexpr int HB_ROWS = HOUGH_HB_ROWS;
             const int nhb = (rows + HB_ROWS - 1) / HB_ROWS;
             unsigned* const bmin = cells;
             unsigned* const bmax = cells + nhb;
@@ -3971,6 +4047,8 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
                 if (tid < NUM_ANGLE) {
                     int rmin = 0x7FFFFFFF, rmax = -0x7FFFFFFF;
                     const bool cpos = tc >= 0.f, spos = ts >= 0.f;
+                    // (the all-LDS kernel lives on 54 registers -- a wave of it beside three window waves: no unrolling there)
+#pragma unroll(HYBRID ? 4 : 1)
                     for (int b = 0; b < nhb; ++b) {
                         const int x_lo = (int)bmin[b], x_hi = (int)bmax[b];
                         if (x_lo > x_hi) continue;  // (no point in this band: the same test for every thread)
@@ -3984,6 +4062,7 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
                 __syncthreads();  // (the scratch is read for the last time above; the size search below reuses it)
             } else if (tid < NUM_ANGLE) {  // (no room for the boxes: the exact sweep)
                 int rmin = 0x7FFFFFFF, rmax = -0x7FFFFFFF;
+#pragma unroll(HYBRID ? 4 : 1)
                 for (int p = 0; p < N; ++p) {
                     const unsigned q = list[p];
                     const int r = rho_bin(q & 0xFFFF, q >> 16, tc, ts, 0);
@@ -3995,6 +4074,12 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
             }
             w_st = max(w_size, __shfl_xor(w_size, 1));
             placed = w_st;
+        }
+    };
+    if (HYBRID) {
+        h3_scan(w_st, total, fix + 32, lane, wave);
+        if (total > cell_cap && cell_cap > 0) {
+            band_windows();
             h3_scan(w_st, total, fix + 32, lane, wave);
         }
         if (total > cell_cap) {
@@ -4028,7 +4113,13 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
             }
         }
     }
-    const int off = h3_scan(placed, total, fix + 32, lane, wave);  // (in halves; both threads of a pair placed the same amount, so a pair starts on a dword)
+    int off = h3_scan(placed, total, fix + 32, lane, wave);  // (in halves; both threads of a pair placed the same amount, so a pair starts on a dword)
+    if (!HYBRID && total > cell_cap) {
+        // the routing sent this frame here on its band windows (round 6): the corner windows do not fit this launch's LDS
+        band_windows();
+        off = h3_scan(placed, total, fix + 32, lane, wave);
+        if (total > cell_cap) __builtin_trap();  // (the routing and this kernel disagree: never go on into the neighbour's LDS)
+    }
     const int cell_dw = (total + 1) / 2;
     // ---- initialise: cells at the bias, one private zero cell per thread for the spare lanes
     for (int p = tid; p < cell_dw; p += HOUGH3_THREADS) cells[p] = (CELL_BIAS << 16) | CELL_BIAS;
@@ -4250,7 +4341,7 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough_single(HoughParams P, 
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int tid = threadIdx.x;
     if (tid < 64) {
-        const int tier = hough_classify_frame(P, 0, tid);
+        const int tier = hough_classify_frame(P, 0, tid, lds_dyn + 64);  // (band scratch: dynamic LDS nothing uses yet)
         if (tid == 0) lds_dyn[0] = (unsigned)(tier + 1);
     }
     __syncthreads();

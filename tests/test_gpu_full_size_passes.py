@@ -89,14 +89,26 @@ def compare(rows, out, K):
 
 def test_1080p_pass_of_4000_frames_twice():
     """The headline shape: K = 4000 at 1920x1080, n = 8 -- three time chunks per launch -- submitted twice, so the second pass
-    starts from the first one's window history, ring of binaries and scalar state."""
-    K = 4000
-    frames, idx, out, _ = run_passes("C2", K, 2, 250)
-    rows = oracle_rows(frames, idx, 8, np.ones(frames.shape[1:], np.uint8), "normal")
-    segs = compare(rows, out, K)
-    assert segs > 2 * 16 * 400, segs  # (550 segments per 250-frame period once the threshold has settled)
+    starts from the first one's window history, ring of binaries and scalar state.  The oracle runs the first pass and the first
+    four periods of the second (the hand-over); the rest of the second pass is the same periodic stream at a settled threshold, and
+    is held frame by frame to the period the oracle did check."""
+    K, P = 4000, 250
+    frames, idx, out, _ = run_passes("C2", K, 2, P)
+    rows = oracle_rows(frames, idx[:K + 4 * P], 8, np.ones(frames.shape[1:], np.uint8), "normal")
+    for a, b in zip(rows[K + 2 * P:K + 3 * P], rows[K + 3 * P:K + 4 * P]):  # the oracle itself repeats from period to period there
+        assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
+    info2, raw2, nms2 = out[1]
+    segs = compare(rows[:K], out[:1], K) + compare(rows[K:], [(info2[:4 * P], raw2[:4 * P], nms2[:4 * P])], 4 * P)
+    for s in range(4 * P, K, P):  # every later period of the second pass == its fourth period, which the oracle checked
+        for name in ("bi_threshold", "lit_count", "n_raw", "n_nms"):
+            assert np.array_equal(info2[name][s:s + P], info2[name][3 * P:4 * P]), (s, name)
+        live_raw = np.arange(raw2.shape[1])[None, :] < info2["n_raw"][s:s + P, None]   # (rows past a frame's count are not written)
+        live_nms = np.arange(nms2.shape[1])[None, :] < info2["n_nms"][s:s + P, None]
+        assert np.array_equal(raw2[s:s + P][live_raw], raw2[3 * P:4 * P][live_raw]), s
+        assert np.array_equal(nms2[s:s + P][live_nms], nms2[3 * P:4 * P][live_nms]), s
+    assert segs > 16 * 400 + 4 * 400, segs  # (550 segments per 250-frame period once the threshold has settled)
     # steady state: from the third period on every period repeats the same tallies -- what bench.py's timed region relies on
-    per = [(int(out[1][0]["n_raw"][s:s + 250].sum()), int(out[1][0]["lit_count"][s:s + 250].sum())) for s in range(0, K, 250)]
+    per = [(int(out[1][0]["n_raw"][s:s + P].sum()), int(out[1][0]["lit_count"][s:s + P].sum())) for s in range(0, K, P)]
     assert len(set(per)) == 1, per
 
 

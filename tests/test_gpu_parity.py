@@ -620,6 +620,87 @@ def test_hough_global_accumulator_path(monkeypatch):
     assert total > 0
 
 
+def _hough_lds_needs(d):
+    """(points, LDS bytes by the corner windows, LDS bytes by the band windows) of a binary frame: hough3_lds_need of
+    metdet_kernels.hpp restated (float32 products, round half to even, angle pairs share the larger window)."""
+    ys, xs = np.nonzero(d)
+    N = len(ys)
+    th = np.arange(180, dtype=np.float64) * (np.pi / 180)
+    c, s = np.cos(th).astype(np.float32), np.sin(th).astype(np.float32)
+    bx0, bx1, by0, by1 = int(xs.min()), int(xs.max()), int(ys.min()), int(ys.max())
+
+    def rb(x, y):
+        return np.rint((np.float32(1) * x * c).astype(np.float32) + (np.float32(1) * y * s).astype(np.float32)).astype(int)
+    corners = np.stack([rb(bx0, by0), rb(bx1, by0), rb(bx0, by1), rb(bx1, by1)])
+    size_c = corners.max(0) - corners.min(0) + 1
+    rows = by1 - by0 + 1
+    rmin, rmax = np.full(180, 1 << 30), np.full(180, -(1 << 30))
+    for b in range((rows + 7) // 8):
+        sel = (ys - by0) // 8 == b
+        if not sel.any():
+            continue
+        xl, xh = int(xs[sel].min()), int(xs[sel].max())
+        yl, yh = by0 + 8 * b, min(by0 + 8 * b + 7, by1)
+        rmin = np.minimum(rmin, rb(np.where(c >= 0, xl, xh), np.where(s >= 0, yl, yh)))
+        rmax = np.maximum(rmax, rb(np.where(c >= 0, xh, xl), np.where(s >= 0, yh, yl)))
+    size_b = rmax - rmin + 1
+    pair = lambda z: 2 * int(np.maximum(z[0::2], z[1::2]).sum())
+    uvc = (min(N, max(bx1 - bx0 + 1, rows) + 2) + 3) & ~3
+    mdw = rows * ((bx1 >> 6) - (bx0 >> 6) + 1) * 2
+    need = lambda cells: 4 * (64 + ((N + 3) & ~3) + 2 * uvc + mdw + (cells + 1) // 2 + 192)
+    return N, need(pair(size_c)), need(pair(size_b))
+
+
+@pytest.mark.parametrize("bands", ["1", "0"])
+def test_hough_band_windows_route_oblique_streaks_to_the_small_launch(bands, monkeypatch):
+    """Round 6: two oblique streaks whose rho windows, taken from the corners of their bounding box, need more LDS than the small
+    Hough launch has (80 KB) while the windows their pixels really span (x-extent per band of 8 rows) fit: the routing sends the
+    frame to the small launch (tier 0: two frames per CU) instead of the large one (tier 1: a CU's whole LDS), the kernel derives the
+    same band windows from its point list, and the segments are the oracle's either way (MDH_HOUGH_BANDS=0: round 5's routing)."""
+    import ctypes as C
+    from metdetpy_amd import _lib
+    monkeypatch.setenv("MDH_HOUGH_DEBUG", "1")
+    monkeypatch.setenv("MDH_HOUGH_BANDS", bands)
+    shape, n = (1080, 1920), 2
+    mask = np.ones(shape, np.uint8)
+    cfg = binary_cfg(adaptive=False, init_value=5, dy_mask=False)
+    base = np.full(shape, 10, np.uint8)
+    imgs = []
+    for L, sep, thick, x0 in ((150, 40, 3, 700), (140, 50, 3, 1200), (130, 60, 3, 200)):
+        img = base.copy()
+        for k in range(L):
+            img[300 + k:300 + k + thick, x0 + k:x0 + k + thick] = 220
+            img[300 + k:300 + k + thick, x0 + sep + k:x0 + sep + k + thick] = 220
+        imgs.append(img)
+    frames = np.stack([base, imgs[0], base, imgs[1], base, imgs[2], base, base])
+    orc = mo.M3Oracle(n, mask, hough_fn=co.hough_lines_p, **oracle_kwargs(cfg))
+    want, routed = [], []
+    for t, f in enumerate(frames):
+        orc.update(f)
+        orc.detect()
+        want.append((orc.lines_num, orc.raw_lines.reshape(-1, 4).copy(), orc.lit_count))
+        if orc.lit_count > 500:
+            N, need_corner, need_band = _hough_lds_needs(orc.dst)
+            assert need_band + 2048 < 80 * 1024 < need_corner - 2048 and need_corner < 120 * 1024, (t, N, need_corner, need_band)
+            routed.append(t)
+    assert len(routed) >= 3, routed  # (a streak stays in the window for n frames)
+    det = M3Detector(1, n, mask, 10, cfg, None, max_batch=len(frames))
+    ctx = det._ctx
+    K = len(frames)
+    info = np.zeros(K, _lib.FRAME_INFO_DTYPE)
+    raw = np.zeros((K, _lib.MDH_MAX_LINES, 4), np.int32)
+    ctx.process_batch_into(frames.ctypes.data, K, False, info, raw, None, None)
+    dbg = np.zeros((2, K, 8), np.int64)
+    assert ctx.L.mdh_debug_hough(C.c_void_p(ctx.handle), dbg.ctypes.data_as(C.POINTER(C.c_longlong)), K) == 0
+    for t in range(K):
+        assert int(info[t]["lit_count"]) == want[t][2] and int(info[t]["n_raw"]) == want[t][0], t
+        assert np.array_equal(raw[t][:want[t][0]], want[t][1][:_lib.MDH_MAX_LINES]), f"frame {t}: raw segments"
+    assert sum(w[0] for w in want) >= 15
+    tiers = [int(dbg[0, t, 1]) & 0xFF for t in routed]
+    assert tiers == [0 if bands == "1" else 1] * len(routed), tiers
+    det.close()
+
+
 def test_hough_windows_too_big_for_lds_fall_back():
     """Lit pixels spread over a 1920x1080 frame: the 180 rho windows of their bounding box exceed the LDS budget."""
     shape, n = (1080, 1920), 2
