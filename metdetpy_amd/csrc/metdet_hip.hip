@@ -1711,9 +1711,12 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         EV_REC(c, hs.ev_cls, hstream[0]);
         EV_WAIT(c, hstream[1], hs.ev_cls);
         const int Kmax = c->Kmax;
+        static const bool queue_on = getenv("MDH_HOUGH_QUEUE") && atoi(getenv("MDH_HOUGH_QUEUE")) != 0;  // (measured: no gain, gpurun_out/r06_34)
         auto tier = [&](int t) {
             P.flist = hs.d_tier_list + (size_t)t * K;
             P.fcount = hs.d_tier_count + t;
+            // (queue heads behind the counts: [HOUGH_TIERS] k_hough3_big, + 1 small launch, + 2 tiny launch, + 3 large launch on its own)
+            P.fqueue = (queue_on && (t == 0 || t == 4 || t == 1)) ? hs.d_tier_count + HOUGH_TIERS + (t == 0 ? 1 : (t == 4 ? 2 : 3)) : nullptr;
         };
         P.lds_bytes = c->lds_large;
         auto launch_h3 = [&](bool hybrid, int grid, hipStream_t st) {
@@ -1742,12 +1745,19 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
             tier(1);
             launch_h3(false, std::min(K, grid_l), hstream[1]);
         }
-        if (P.lds_tiny > 0) {  // short streaks, four frames per CU: in front of the (at such sizes empty) launches of this stream
+        // Short streaks, four frames per CU (tier 4).  Up to round 5 this launch went IN FRONT of the whole-LDS launches of its stream
+        // (k_hough3_big, k_hough_ppht: at such frame sizes usually empty): an empty launch of 256 workgroups that each want a CU's
+        // whole LDS then waits for the tiny launch's last workgroups to leave -- 50-170 us at the end of a 960x540 pass's Hough stage,
+        // which is the pipeline's critical chain there (gpurun_out/r06_36).  Round 6: behind them -- the empty launches run through
+        // while the LDS is still free (MDH_HOUGH_TINY_FIRST=1: the old order).
+        static const bool tiny_first = getenv("MDH_HOUGH_TINY_FIRST") && atoi(getenv("MDH_HOUGH_TINY_FIRST")) != 0;
+        auto launch_tiny = [&]() {
             tier(4);
             P.lds_bytes = P.lds_tiny;
             launch_h3(false, std::min(K, grid_s), hstream[1]);
             P.lds_bytes = c->lds_large;
-        }
+        };
+        if (P.lds_tiny > 0 && tiny_first) launch_tiny();
         tier(2);
         if (big && !c->lean) {
             const int gb = std::min(K, hs.pool);  // (a work queue: any grid is correct; capped at 8 or 1 it changes nothing at 1080p / 960x540, where the launch is empty)
@@ -1758,6 +1768,7 @@ static int run_hough(mdh_ctx* c, Slot& sl, int K) {
         tier(3);
         hipLaunchKernelGGL(k_hough_ppht, dim3(std::min(K, hs.pool_list)), dim3(64), (P.list_cap + P.cell_cap / 2 + 64) * sizeof(unsigned),
                            hstream[1], P);
+        if (P.lds_tiny > 0 && !tiny_first) launch_tiny();
         EV_REC(c, hs.ev_big, hstream[1]);
         if (!c->lean && split) {
             EV_WAIT(c, lstream, hs.ev_cls);

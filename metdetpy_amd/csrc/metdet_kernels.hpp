@@ -2133,7 +2133,7 @@ __global__ void __launch_bounds__(1024) k_pack_lines(const int4* __restrict__ li
     if (threadIdx.x < 2) off[K + 1 + threadIdx.x] = nzwords ? (int)nzwords[threadIdx.x] : 0;  // words of b with set bits (u64)
     // the routing counters of the Hough set: every launch that read them is done (this kernel runs behind them), so they are
     // left at zero for the set's next pass -- one memset command per pass less on the Hough stream
-    if (tier_count && threadIdx.x < HOUGH_TIERS + 1) tier_count[threadIdx.x] = 0;  // (+ the work queue's head of k_hough3_big)
+    if (tier_count && threadIdx.x < HOUGH_TIERS + 4) tier_count[threadIdx.x] = 0;  // (+ the work queues' heads: k_hough3_big, k_hough3 per launch)
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2698,7 +2698,8 @@ struct HoughParams {
     const int* flist;      // frames of this launch's tier
     const int* fcount;     // their number
     int* tier_list;        // [HOUGH_TIERS][K] lists being built by the classifier
-    int* tier_count;       // [HOUGH_TIERS]
+    int* tier_count;       // [HOUGH_TIERS] + the heads of the launches' work queues
+    int* fqueue;           // this launch's queue head (k_hough3; nullptr: the frames are dealt out by workgroup index, up to round 5)
     int K;                 // frames in the pass
     int lds_small, lds_large;  // dynamic LDS bytes of the two three-wave launches (the classifier's fit test)
     int lds_tiny;          // ... and of the launch for frames that need even less (tier 4; 0: no such launch)
@@ -4278,8 +4279,23 @@ __global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3(HoughParams P) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int count = *P.fcount;
-    for (int j = blockIdx.x; j < count; j += gridDim.x) {
-        hough3_frame<false, TM>(P, P.flist[j], 0, lds_dyn);
+    if (P.fqueue == nullptr) {
+        for (int j = blockIdx.x; j < count; j += gridDim.x) {
+            hough3_frame<false, TM>(P, P.flist[j], 0, lds_dyn);
+            __syncthreads();
+        }
+        return;
+    }
+    // Round 6: a work queue, as in k_hough3_big.  A 4000-frame pass at n = 25 has ~2800 frames with points for the 512 workgroups that
+    // are resident at a time, 50-300 us each: dealt out by workgroup index the launch lasts as long as the unluckiest workgroup's
+    // five or six frames; from a queue, as long as the average plus one frame.
+    for (;;) {
+        if (threadIdx.x == 0) lds_dyn[0] = (unsigned)atomicAdd(P.fqueue, 1);
+        __syncthreads();
+        const int q = (int)lds_dyn[0];
+        __syncthreads();
+        if (q >= count) break;
+        hough3_frame<false, TM>(P, P.flist[q], 0, lds_dyn);
         __syncthreads();
     }
 }
