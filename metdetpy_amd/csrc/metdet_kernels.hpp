@@ -184,6 +184,9 @@ __global__ void __launch_bounds__(256) k_noise_sums_bytes(const uint8_t* const* 
 #ifndef WIDE_EVEN_BURSTS
 #define WIDE_EVEN_BURSTS 1  // (A/B builds: -DWIDE_EVEN_BURSTS=0: bursts of the requested size plus a remainder, as up to round 5)
 #endif
+#ifndef CLASSIC4_PIN_V
+#define CLASSIC4_PIN_V "v87"
+#endif
 #ifndef WIDE_PIN152
 #define WIDE_PIN152 1  // (A/B builds: -DWIDE_PIN152=0)
 #endif
@@ -1115,11 +1118,18 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     if constexpr (DENSE) {
         if (nzwords != nullptr && lane == 0 && nz_mine) atomicAdd(nzwords, (unsigned long long)nz_mine);
     }
+#ifndef WIDE_PIN_V
+#define WIDE_PIN_V "v135"  // (A/B builds: -DWIDE_PIN_V='"v151"' -- round 5's 152 registers)
+#endif
 #if WIDE_PIN152
-    // With the pass tables the n = 7 .. 9 instantiations need 128-140 registers: FOUR waves per SIMD, which leave a Hough wave (54
-    // registers) no room beside them -- 960x540 at the pipeline's pace 8.5 M -> 7.5 M frames/s (gpurun_out/r06_04).  Naming v151
-    // as clobbered makes the kernel's allocation 152 registers: three window waves and 56 registers for a Hough wave, as in round 5.
-    if constexpr (TAB && !DENSE && PPL == 16 && N >= 7 && N <= 9) asm volatile("" ::: "v151");
+    // With the pass tables the n = 7 .. 9 instantiations need 118-140 registers: FOUR waves per SIMD, which leave a Hough wave (54
+    // registers) no room beside them -- 960x540 at the pipeline's pace 8.5 M -> 7.5 M frames/s (gpurun_out/r06_04).  Naming a high
+    // register as clobbered holds the kernel's allocation up.  First at 152 (round 5's figure: three window waves and 56 registers for
+    // ONE Hough wave); but the stages queued beside a window launch are not all that small -- k_noise_finalize, which every window
+    // launch waits for, takes 64 registers, k_morph_close_dense 85, k_morph_close_t 52 -- and a kernel that finds no room on any SIMD
+    // waits for a window workgroup to leave.  At 136 (the smallest allocation that still means three waves) 104 registers per SIMD
+    // stay free: 1080p / n = 8 at the pipeline's pace +4 % on the same box, 960x540 +3-5 % (gpurun_out/r06_41).
+    if constexpr (TAB && !DENSE && PPL == 16 && N >= 7 && N <= 9) asm volatile("" ::: WIDE_PIN_V);
 #endif
 }
 // waves per SIMD the instantiation is held to (0: whatever its natural register use allows).  Only the raw-window build asks: its
@@ -2505,6 +2515,11 @@ __global__ void __launch_bounds__(256) k_classic_diff4_sparse(const uint8_t* con
         pt += 2 * U;
         wr += 2 * U;
     }
+    // The kernel needs 62 registers: EIGHT waves per SIMD -- every wave slot and every register of the machine, so that each launch
+    // of the post stages (and the next pass's noise chain) waits for a workgroup of this one to leave.  Held at 88 registers (five
+    // waves, 72 registers free per SIMD) the launch alone is as fast and the pipeline 3.5-4 % faster (gpurun_out/r06_42;
+    // A/B builds: -DCLASSIC4_PIN_V='"v63"').
+    asm volatile("" ::: CLASSIC4_PIN_V);
 }
 
 __global__ void __launch_bounds__(256) k_classic_stencil(const u64* __restrict__ planes, u64* __restrict__ dst_bits,
@@ -4274,8 +4289,11 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
 
 // tiers 0 / 1: a machine-sized grid walks the tier's frame list (a pass has thousands of frames and most of them carry no
 // streak: one workgroup per frame would be thousands of workgroups that leave at once, each waiting for its LDS first)
+#ifndef HOUGH3_OCC
+#define HOUGH3_OCC
+#endif
 template <bool TM>
-__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3(HoughParams P) {
+__global__ void __launch_bounds__(HOUGH3_THREADS) HOUGH3_OCC k_hough3(HoughParams P) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int count = *P.fcount;
