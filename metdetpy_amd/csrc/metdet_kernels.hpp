@@ -1129,7 +1129,8 @@ __device__ __forceinline__ void stack_threshold_wide_body(const uint8_t* const* 
     // launch waits for, takes 64 registers, k_morph_close_dense 85, k_morph_close_t 52 -- and a kernel that finds no room on any SIMD
     // waits for a window workgroup to leave.  At 136 (the smallest allocation that still means three waves) 104 registers per SIMD
     // stay free: 1080p / n = 8 at the pipeline's pace +4 % on the same box, 960x540 +3-5 % (gpurun_out/r06_41).
-    if constexpr (TAB && !DENSE && PPL == 16 && N >= 7 && N <= 9) asm volatile("" ::: WIDE_PIN_V);
+    // (n = 17, 18 with 8 pixels per lane: 122-128 registers, the same four waves)
+    if constexpr (TAB && ((!DENSE && PPL == 16 && N >= 7 && N <= 9) || (PPL == 8 && (N == 17 || N == 18)))) asm volatile("" ::: WIDE_PIN_V);
 #endif
 }
 // waves per SIMD the instantiation is held to (0: whatever its natural register use allows).  Only the raw-window build asks: its
