@@ -1632,7 +1632,10 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
 // neighbour with one DPP wave shift each (lanes 0 and 63 fetch theirs), and the halo is 6 rows in 22 instead of 6 in 14: 1.4
 // loads per word instead of 5.25.  Blocks the list would not have named produce zeros here and store nothing -- same result.
 #define MORPH_DENSE_ROWS 16
-__global__ void __launch_bounds__(64) k_morph_close_dense(const ActWord* __restrict__ bbits, const unsigned* __restrict__ dense,
+#ifndef CLOSE_DENSE_OCC
+#define CLOSE_DENSE_OCC
+#endif
+__global__ void __launch_bounds__(64) CLOSE_DENSE_OCC k_morph_close_dense(const ActWord* __restrict__ bbits, const unsigned* __restrict__ dense,
                                                           ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
                                                           unsigned* __restrict__ nzcount, PassGeom g) {
     // dense[0] = number of dense frames of the pass, dense[1..] = their indices (written by k_morph_close, which looks at every
