@@ -1632,10 +1632,7 @@ __device__ __forceinline__ void morph_close_item(const ActWord* __restrict__ bbi
 // neighbour with one DPP wave shift each (lanes 0 and 63 fetch theirs), and the halo is 6 rows in 22 instead of 6 in 14: 1.4
 // loads per word instead of 5.25.  Blocks the list would not have named produce zeros here and store nothing -- same result.
 #define MORPH_DENSE_ROWS 16
-#ifndef CLOSE_DENSE_OCC
-#define CLOSE_DENSE_OCC
-#endif
-__global__ void __launch_bounds__(64) CLOSE_DENSE_OCC k_morph_close_dense(const ActWord* __restrict__ bbits, const unsigned* __restrict__ dense,
+__global__ void __launch_bounds__(64) k_morph_close_dense(const ActWord* __restrict__ bbits, const unsigned* __restrict__ dense,
                                                           ActWord* __restrict__ act_ring, unsigned* __restrict__ nzlist,
                                                           unsigned* __restrict__ nzcount, PassGeom g) {
     // dense[0] = number of dense frames of the pass, dense[1..] = their indices (written by k_morph_close, which looks at every
@@ -4293,11 +4290,8 @@ __device__ void hough3_frame(const HoughParams& P, int i, int slot, unsigned* ld
 
 // tiers 0 / 1: a machine-sized grid walks the tier's frame list (a pass has thousands of frames and most of them carry no
 // streak: one workgroup per frame would be thousands of workgroups that leave at once, each waiting for its LDS first)
-#ifndef HOUGH3_OCC
-#define HOUGH3_OCC
-#endif
 template <bool TM>
-__global__ void __launch_bounds__(HOUGH3_THREADS) HOUGH3_OCC k_hough3(HoughParams P) {
+__global__ void __launch_bounds__(HOUGH3_THREADS) k_hough3(HoughParams P) {
     __builtin_amdgcn_s_setprio(HOUGH_WAVE_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int count = *P.fcount;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How long do the host's own calls take in the pipelined loop?  bench.py's stream loop with the duration of every mdh_submit_batch
 and mdh_collect_batch call: a pass whose submit + collect cost the host more than the GPU needs for it is bound by the host.
-    python tools/host_call_times.py --workload C1s [--window 25] [--steps 40]"""
+    python tools/host_call_times.py --workload C1s [--window 25] [--batch 250] [--steps 40]"""
 import argparse
 import os
 import sys
@@ -18,11 +18,12 @@ ap.add_argument("--workload", default="C2")
 ap.add_argument("--window", type=int, default=None)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--unique", type=int, default=250)
+ap.add_argument("--batch", type=int, default=None, help="frames per pass (default: the workload's)")
 a = ap.parse_args()
 wl = dict(bench.WORKLOADS[a.workload])
 if a.window:
     wl["n"] = a.window
-B, H, W, n = wl["batch"], wl["H"], wl["W"], wl["n"]
+B, H, W, n = a.batch or wl["batch"], wl["H"], wl["W"], wl["n"]
 mask = np.ones((H, W), np.uint8)
 if a.workload == "C3" and bench.load_mask(H, W) is not None:
     mask = bench.load_mask(H, W)
