@@ -3155,7 +3155,17 @@ extern "C" int mdh_pre_run_batch(mdh_pre* p, const uint8_t* bgr, int n_out, int 
         p->out_cap = (size_t)px * n_out;
     }
     uint8_t* dst = out_on_device ? out : p->d_out;
-    if (p->span_cap > 0 && ((uintptr_t)src & 15) == 0 && n_out <= 65535 && p->g.dh <= 65535)
+    // (MDH_PRE_PREFETCH=0: the kernel without the register prefetch of the next stage, as up to the first half of round 6)
+    const bool pre_pf = !(getenv("MDH_PRE_PREFETCH") && atoi(getenv("MDH_PRE_PREFETCH")) == 0);  // (read per call: tests switch it inside one process)
+    const bool rows_ok = p->span_cap > 0 && ((uintptr_t)src & 15) == 0 && n_out <= 65535 && p->g.dh <= 65535;
+    const dim3 rows_grid((p->g.dw + PRE_SEG - 1) / PRE_SEG, (p->g.dh + PRE_ROWS - 1) / PRE_ROWS, (n_out + PRE_ZB - 1) / PRE_ZB);
+    if (rows_ok && pre_pf && p->span_cap <= PRE_SEG * 16)
+        hipLaunchKernelGGL(k_preprocess_rows_pf<1>, rows_grid, dim3(PRE_SEG), 2 * PRE_ROWS * (size_t)p->span_cap, p->stream,
+                           src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap, n_out);
+    else if (rows_ok && pre_pf && p->span_cap <= 2 * PRE_SEG * 16)
+        hipLaunchKernelGGL(k_preprocess_rows_pf<2>, rows_grid, dim3(PRE_SEG), 2 * PRE_ROWS * (size_t)p->span_cap, p->stream,
+                           src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap, n_out);
+    else if (rows_ok)
         hipLaunchKernelGGL(k_preprocess_rows, dim3((p->g.dw + PRE_SEG - 1) / PRE_SEG, (p->g.dh + PRE_ROWS - 1) / PRE_ROWS, (n_out + PRE_ZB - 1) / PRE_ZB), dim3(PRE_SEG),
                            2 * PRE_ROWS * (size_t)p->span_cap, p->stream,
                            src, exp_frame, p->g, p->d_xi, p->d_xw, p->d_yi, p->d_yw, p->d_mask, dst, p->span_cap, n_out);

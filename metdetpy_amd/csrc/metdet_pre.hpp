@@ -156,6 +156,144 @@ __global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows(const uint8_t* __re
     }  // z
 }
 
+// Round 6, second half: the same kernel with the NEXT stage's source rows requested before the current stage is computed.  A stage is
+// one source frame of one output frame (exp_frame stages per output frame, PRE_ZB output frames per workgroup).  Above, a stage is
+// load -> barrier -> compute -> barrier: the workgroup's waves sit out every load's round trip (SQ_WAIT_ANY 0.79).  Here the eight
+// row spans of stage s + 1 travel into registers (IT x 16 bytes per lane and span) while stage s is computed from LDS, and are
+// written to LDS behind the barrier that ends stage s: one round trip per stage is hidden behind the other stage's arithmetic.
+// IT = 16-byte pieces per lane and span: 1 for spans of up to 4 KB (reductions of up to 5x), 2 up to 8 KB; longer spans keep the
+// kernel above.
+#ifndef PRE_AHEAD
+#define PRE_AHEAD 1  // stages requested ahead (A/B builds: -DPRE_AHEAD=2: two register sets)
+#endif
+template <int IT>
+__global__ void __launch_bounds__(PRE_SEG) k_preprocess_rows_pf(const uint8_t* __restrict__ src, int exp_frame, PreGeom g,
+                                                                 const int* __restrict__ xi, const short* __restrict__ xw,
+                                                                 const int* __restrict__ yi, const short* __restrict__ yw,
+                                                                 const uint8_t* __restrict__ mask01, uint8_t* __restrict__ out, int span_cap,
+                                                                 int n_out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_rows[];  // [PRE_ROWS][2][span_cap]
+    const int t = threadIdx.x;
+    const int dx0 = blockIdx.x * PRE_SEG, dy0 = blockIdx.y * PRE_ROWS;
+    const int cnt = min(PRE_SEG, g.dw - dx0);
+    const int nrows = min(PRE_ROWS, g.dh - dy0);
+    const int z0 = blockIdx.z * PRE_ZB, z1 = min(n_out, z0 + PRE_ZB);
+    const int c_first = xi[dx0], c_last = min(xi[dx0 + cnt - 1] + 1, g.sw - 1);
+    const int byte0 = (c_first * 3) & ~15;
+    const int span = (((c_last + 1) * 3 - byte0) + 15) & ~15;  // (<= span_cap <= IT * PRE_SEG * 16: the host checked)
+    const int dx = dx0 + t;
+    const bool live = t < cnt;
+    int o0 = 0, o1 = 0, a0 = 0, a1 = 0;
+    if (live) {
+        const int x0 = xi[dx], x1 = min(x0 + 1, g.sw - 1);
+        o0 = x0 * 3 - byte0;
+        o1 = x1 * 3 - byte0;
+        a0 = xw[2 * dx];
+        a1 = xw[2 * dx + 1];
+    }
+    const size_t frame = (size_t)g.sh * g.sw * 3, row_bytes = (size_t)g.sw * 3;
+    int b0s[PRE_ROWS], b1s[PRE_ROWS];
+    unsigned roff0[PRE_ROWS], roff1[PRE_ROWS];  // byte offsets of the tile's two source rows per output row, inside a source frame (a frame is < 4 GB)
+#pragma unroll
+    for (int r = 0; r < PRE_ROWS; ++r) {
+        const int dy = min(dy0 + r, g.dh - 1);
+        const int y0 = yi[dy], y1 = min(y0 + 1, g.sh - 1);
+        roff0[r] = (unsigned)((size_t)y0 * row_bytes + byte0);
+        roff1[r] = (unsigned)((size_t)y1 * row_bytes + byte0);
+        b0s[r] = yw[2 * dy];
+        b1s[r] = yw[2 * dy + 1];
+    }
+    const int stages = (z1 - z0) * exp_frame;
+    typedef pre_u4 RegSet[2 * PRE_ROWS][IT];
+    auto request = [&](RegSet& regs, int s) {  // source frame of stage s: frame (z0 * exp_frame + s) of the input
+        const uint8_t* f = src + ((size_t)z0 * exp_frame + s) * frame;
+#pragma unroll
+        for (int r = 0; r < PRE_ROWS; ++r) {
+            if (r < nrows) {
+#pragma unroll
+                for (int k = 0; k < IT; ++k) {
+                    const int o = (t + k * PRE_SEG) * 16;
+                    if (o < span) {
+                        regs[2 * r][k] = __builtin_nontemporal_load((const pre_u4*)(f + roff0[r] + o));
+                        regs[2 * r + 1][k] = __builtin_nontemporal_load((const pre_u4*)(f + roff1[r] + o));
+                    }
+                }
+            }
+        }
+    };
+    int best[PRE_ROWS];
+#pragma unroll
+    for (int r = 0; r < PRE_ROWS; ++r) best[r] = 0;
+    int e = 0, z = z0;
+    // one stage: its rows from registers to LDS, the stage PRE_AHEAD later requested into the registers just freed, the arithmetic
+    auto step = [&](RegSet& regs, int s) {
+        if (s) __syncthreads();  // (stage s - 1 has been computed: its rows may be overwritten)
+#pragma unroll
+        for (int r = 0; r < PRE_ROWS; ++r) {
+            if (r < nrows) {
+#pragma unroll
+                for (int k = 0; k < IT; ++k) {
+                    const int o = (t + k * PRE_SEG) * 16;
+                    if (o < span) {
+                        *(pre_u4*)(lds_rows + (size_t)(2 * r) * span_cap + o) = regs[2 * r][k];
+                        *(pre_u4*)(lds_rows + (size_t)(2 * r + 1) * span_cap + o) = regs[2 * r + 1][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s + PRE_AHEAD < stages) request(regs, s + PRE_AHEAD);  // in flight while this stage (and the next) is computed
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < PRE_ROWS; ++r) {
+                if (r < nrows) {
+                    const uint8_t* l0 = lds_rows + (size_t)(2 * r) * span_cap;
+                    const uint8_t* l1 = l0 + span_cap;
+                    const int b0 = b0s[r], b1 = b1s[r];
+                    int ch[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int s0 = l0[o0 + c] * a0 + l0[o1 + c] * a1;
+                        const int s1 = l1[o0 + c] * a0 + l1[o1 + c] * a1;
+                        int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+                        ch[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    }
+                    const int gray = (ch[0] * 3735 + ch[1] * 19235 + ch[2] * 9798 + 16384) >> 15;
+                    best[r] = max(best[r], gray & 0xFF);
+                }
+            }
+        }
+        if (++e == exp_frame) {  // the output frame's last source frame
+            if (live) {
+                uint8_t* o_z = out + (size_t)z * g.dh * g.dw;
+#pragma unroll
+                for (int r = 0; r < PRE_ROWS; ++r)
+                    if (r < nrows) {
+                        const size_t p = (size_t)(dy0 + r) * g.dw + dx;
+                        o_z[p] = (uint8_t)(mask01 ? best[r] * mask01[p] : best[r]);
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < PRE_ROWS; ++r) best[r] = 0;
+            e = 0;
+            z += 1;
+        }
+    };
+#if PRE_AHEAD == 2
+    RegSet ra, rb;
+    if (stages > 0) request(ra, 0);
+    if (stages > 1) request(rb, 1);
+    for (int s = 0; s < stages; s += 2) {
+        step(ra, s);
+        if (s + 1 < stages) step(rb, s + 1);
+    }
+#else
+    RegSet ra;
+    if (stages > 0) request(ra, 0);
+    for (int s = 0; s < stages; ++s) step(ra, s);
+#endif
+}
+
 // acc = max(acc, frame) over K frames of `bytes` bytes each; 16 bytes per lane (requires bytes % 16 == 0 for the
 // vector body, the tail goes byte-wise).
 __global__ void __launch_bounds__(256) k_max_stack(const uint8_t* __restrict__ frames, int K, size_t bytes,

@@ -24,6 +24,27 @@ def test_preprocess_matches_oracle(src_hw, dst_wh, exp):
         pre.close()
 
 
+@pytest.mark.parametrize("prefetch", ["1", "0"])
+@pytest.mark.parametrize("src_hw,dst_wh", [((72, 1536), (384, 18)),    # 4x: a 3 KB row span per workgroup -- one 16-byte piece per lane
+                                           ((40, 3840), (480, 10)),    # 8x: 6 KB spans -- two pieces per lane
+                                           ((24, 7680), (512, 6)),     # 15x: 11.5 KB spans -- the kernel without the register prefetch
+                                           ((54, 1000), (250, 27))])   # rows that are no multiple of 16 bytes: the one-thread-per-pixel kernel
+def test_preprocess_batch_kernels_by_span_and_prefetch(src_hw, dst_wh, prefetch, monkeypatch):
+    """Round 6: the batched launch requests the next source frame's rows into registers while the current one is computed
+    (k_preprocess_rows_pf, one or two 16-byte pieces per lane and row span; MDH_PRE_PREFETCH=0: the kernel without).  Seven output
+    frames of three source frames each -- two workgroup rounds of four and three frames, 21 stages -- per geometry of each kernel."""
+    monkeypatch.setenv("MDH_PRE_PREFETCH", prefetch)
+    exp, n_out = 3, 7
+    rng = np.random.default_rng(src_hw[1] + int(prefetch))
+    bgr = rng.integers(0, 256, (exp * n_out, src_hw[0], src_hw[1], 3), dtype=np.uint8)
+    mask = (rng.random((dst_wh[1], dst_wh[0])) < 0.9).astype(np.uint8)
+    pre = Preprocessor(src_hw, dst_wh, mask)
+    got = pre.batch(bgr, exp)
+    want = np.stack([mo.merge_max([mo.preprocess_frame(f, dst_wh, mask) for f in bgr[i * exp:(i + 1) * exp]]) for i in range(n_out)])
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    pre.close()
+
+
 def test_preprocess_smooth_image_and_identity():
     y, x = np.mgrid[0:120, 0:200]
     img = np.stack([(x + y) % 256, (2 * x) % 256, (3 * y) % 256], axis=-1).astype(np.uint8)
