@@ -106,7 +106,7 @@ def test_bench_secondary_block_of_the_headline_run():
     assert d["config"]["passes_per_step"] == 64 and d["config"]["frames_per_step"] == 256000
     sec = d["secondary"]
     unfriendly = {"C2_noisy_sky_m3det_low", "C2_hot_pixels_1pct", "C2_cloud_edge_every_50", "C2_streak_share_5pct", "C2_streak_share_80pct"}
-    long_windows = {"C2_n25_reference_default_window", "C1s_960x540_n25", "C1s_960x540_n30"}
+    long_windows = {"C2_n25_reference_default_window", "C2_n25_streak_share_5pct", "C1s_960x540_n25", "C1s_960x540_n30"}
     assert set(sec) == {"C3_4k_n16_mask", "C5_8k_high", "C1s_960x540", "C5_8k_as_8_row_bands_one_gpu", "per_frame_pinned",
                         "per_frame_recycled_ring", "per_frame_pageable", "C2_pass_1000_frames", "C2_pass_250_frames",
                         "C2_with_collector"} | unfriendly | long_windows
