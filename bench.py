@@ -968,7 +968,7 @@ SECONDARY = [
     # ... and the same window on the stream with a streak in 5 % of the frames instead of 26 %: at n = 25 a streak stays in the window
     # for 37 frames, so the default stream has points for the Hough stage in 70 % of its frames -- this leg is the window kernel's pace
     # when the Hough load is a meteor camera's, not a stress test's
-    ("C2_n25_streak_share_5pct", ["--window", "25", "--stream", "sparse", "--unique", "400", "--steps", "6", "--warmup", "1"]),
+    ("C2_n25_streak_share_5pct", ["--window", "25", "--stream", "sparse", "--unique", "400", "--steps", "10", "--warmup", "1"]),
     ("C1s_960x540_n25", ["--workload", "C1s", "--window", "25", "--unique", "100", "--steps", "8", "--warmup", "1"]),
     ("C1s_960x540_n30", ["--workload", "C1s", "--window", "30", "--unique", "100", "--steps", "8", "--warmup", "1"]),
     # what a consumer with a latency budget sees: the headline workload in passes of 1000 and 250 frames
